@@ -1,0 +1,179 @@
+/*
+ * btrapz_oracle.h -- CPU restatement of the reference's Bezier-in-corridor
+ * trajectory QP (Srujan-D/spectral).
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check
+ * in __graft_entry__.py and bench.py's cpu_baseline leg may load it.  The
+ * product path (spectral_amd/) never links, imports or calls anything here.
+ *
+ * PARITY UNPINNED: the reference has no tests and no golden vectors, its
+ * sources need Eigen + OSQP (absent from this image, so oracle/_ref cannot be
+ * built) and its prebuilt libraries need libosqp.so (absent).  The arithmetic
+ * of the solve lives in OSQP (oxfordcontrol/osqp, version unpinned by the
+ * reference: only the comment "osqp-0.4.1, 0.5.0" at src/solve_3d.cc:1246),
+ * whose published ADMM algorithm is restated in orc_osqp_solve().  What IS
+ * pinned: (1) assembly against the closed forms of solve_3d.cc / cuboid_3d.cc,
+ * (2) the optimum x* through KKT residuals and an independent third-party QP
+ * solver (HiGHS, shipped inside scipy) in tests/, (3) the reference's saved
+ * 3-decimal output trajectories as a weak external anchor (tests/golden).
+ *
+ * All citations are file:line relative to /root/reference.
+ */
+#ifndef BTRAPZ_ORACLE_H
+#define BTRAPZ_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef long long orc_int; /* OSQP c_int built with DLONG (libtrp.so mangled names) */
+
+/* include/btrapz/cube_type.h:2-24 */
+typedef struct {
+  int beg_t, end_t;
+  double t;
+  double beg_l, end_l;
+  double upp_skew, upp_bias, down_skew, down_bias;
+  double l_upp_skew, l_upp_bias, l_down_skew, l_down_bias;
+  int count;
+} orc_cube;
+
+/* include/btrapz/py_cpp_.h:6-21 (88 bytes) */
+typedef struct {
+  double s_acc_weight, s_jerk_weight, l_acc_weight, l_jerk_weight;
+  double weight_s_ref, weight_ds_ref, weight_l_ref, weight_dl_ref;
+  double weight_end_s, weight_end_l;
+  int iteration;
+} orc_params;
+
+enum { ORC_TRAPEZOID = 0, ORC_CUBOID = 1 };
+
+/* Parsed input file, grammar of src/trp_wrapper.cpp:39-144. */
+typedef struct {
+  int N;
+  double delta;
+  double init_s[3], init_l[3];
+  int num_obs;
+  double ds_ref, dl_ref;
+  double dds[2], ddds[2], ddl[2], dddl[2];
+  double *x_bounds; /* [num_obs][N][2] */
+  double *y_bounds; /* [num_obs][N][2] */
+  double *dx_bounds; /* [N][2] */
+  double *dy_bounds; /* [N][2] */
+  double *x_ref, *y_ref, *x_kappa, *y_kappa; /* [N] */
+} orc_input;
+
+int orc_input_read(const char *path, orc_input *in); /* 0 ok, <0 error */
+void orc_input_free(orc_input *in);
+
+/* Corridor pipeline -------------------------------------------------------*/
+/* CorridorGeneration + CorridorSplit for one obstacle's per-knot bounds.
+ * solve_3d.cc:323-486,729-772 ; cuboid_3d.cc:301-407,588-625.
+ * Returns number of cubes written (<= cap) or <0 on error. */
+int orc_corridor_generation(int variant, int N, double delta,
+                            const double *x_bounds, const double *y_bounds,
+                            orc_cube *out, int cap);
+
+/* CollisionCheck: solve_3d.cc:488-714 ; cuboid_3d.cc:409-573.
+ * cubes: concatenated per-obstacle lists, counts[num_obs].  Returns S (number
+ * of cubes in new_corridor) or <0 (e.g. empty set, where the reference
+ * underflows an unsigned loop bound: defined here as failure -2). */
+int orc_collision_check(int variant, int N, double delta, const orc_cube *cubes,
+                        const int *counts, int num_obs, const double *x_ref,
+                        const double *y_ref, orc_cube *out, int cap);
+
+/* Assembly ----------------------------------------------------------------*/
+typedef struct {
+  /* weights (Params) */
+  double w_s[4]; /* weight_x_ref, weight_dx_ref, weight_ddx, weight_dddx */
+  double w_l[4];
+  double weight_end_s, weight_end_l;
+  double ds_ref, dl_ref;
+  double dds[2], ddds[2], ddl[2], dddl[2];
+  double init_s[3], init_l[3];
+  int N;
+  double delta;
+  const double *dx_bounds; /* [N][2] per-knot */
+  const double *dy_bounds; /* [N][2] */
+  const double *x_ref, *y_ref; /* [N] */
+} orc_qp_params;
+
+/* Sizes: n = 12S, m = 42S, nnzP = 42S, nnzA = 104S-12. */
+typedef struct {
+  int n, m;
+  orc_int *P_p, *P_i; double *P_x; int P_nnz;
+  orc_int *A_p, *A_i; double *A_x; int A_nnz;
+  double *q, *l, *u;
+} orc_qp;
+
+int orc_assemble(int variant, int S, const orc_cube *corridor,
+                 const orc_qp_params *pp, orc_qp *qp);
+void orc_qp_free(orc_qp *qp);
+
+/* OSQP-style ADMM -----------------------------------------------------------*/
+typedef struct {
+  double rho, sigma, alpha;
+  double eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+  int max_iter, scaling, scaled_termination, check_termination;
+  int adaptive_rho, adaptive_rho_interval;
+  double adaptive_rho_tolerance;
+  int polish; /* 0: none (reference); 1: oracle-side active-set polish */
+} orc_settings;
+
+/* Effective settings of the reference: OSQP defaults + solve_3d.cc:1446-1462
+ * + :1236-1243 + max_iter=5000 (trp_wrapper.cpp:191). */
+void orc_settings_reference(orc_settings *s);
+/* High-accuracy settings used to compute x* for parity. */
+void orc_settings_tight(orc_settings *s);
+
+typedef struct {
+  int status; /* OSQP status_val: 1 solved, 2 solved inaccurate, -2 max iter,
+                 -3 primal infeasible, 3 p.i. inaccurate, -4 dual infeasible,
+                 4 d.i. inaccurate, -10 unsolved */
+  int iter;
+  int rho_updates;
+  double obj_val, pri_res, dua_res, rho;
+} orc_info;
+
+int orc_osqp_solve(const orc_qp *qp, const orc_settings *s, double *x,
+                   double *y, orc_info *info);
+
+/* High-accuracy optimum x* by a dense Mehrotra interior-point method on the
+ * general (P,q,A,l,u); independent of orc_osqp_solve and of the product's
+ * structured solver.  info->pri_res returns the final KKT score
+ * max(|r_dual|/(1+|q|), |r_prim|/(1+|bounds|), mu). */
+int orc_ipm_solve(const orc_qp *qp, double eps, int max_iter, double *x,
+                  double *y, orc_info *info);
+
+/* Unscaled KKT residuals of (x,y): stationarity inf-norm, primal violation,
+ * complementarity; res[0..2]. */
+void orc_kkt_residuals(const orc_qp *qp, const double *x, const double *y,
+                       double *res);
+
+/* Post-solve ---------------------------------------------------------------*/
+/* Bernstein sampling, solve_3d.cc:1279-1392.  out: 6 arrays of length
+ * *npoints (s,ds,dds,l,dl,ddl), cap each.  Returns 0 ok, <0 if the
+ * reference's CHECK_EQ(var_index,num_of_points_) (:1407) would abort. */
+int orc_sample(int S, const orc_cube *corridor, double delta,
+               const double *x /*12S*/, const double init_s[3],
+               const double init_l[3], double *s, double *ds, double *dds,
+               double *l, double *dl, double *ddl, int cap, int *npoints);
+
+/* a_cost: trp_wrapper.cpp:207-286 ; cub_wrapper.cpp:201-262. */
+double orc_acost(int variant, const orc_params *p, const orc_input *in,
+                 int npoints, const double *s, const double *ds,
+                 const double *dds, const double *l, const double *dl,
+                 const double *ddl);
+
+/* Whole find_traj (trp_wrapper.cpp:20-305 / cub_wrapper.cpp:20-283) with the
+ * two hard-coded paths made explicit.  Returns a_cost or 1e11. Extra outputs
+ * (may be NULL): S, control points (cap 12*64), info. */
+double orc_find_traj(int variant, const char *input_path,
+                     const char *output_path, const orc_params *p,
+                     const orc_settings *settings, int *S_out, double *ctrl_out,
+                     orc_cube *corridor_out, orc_info *info_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
