@@ -1,0 +1,159 @@
+/*
+ * btrapz_hip.h -- C-ABI of the MI355X-native Bezier-in-corridor trajectory QP path.
+ *
+ * Two groups of entry points:
+ *
+ *  (1) `find_traj` -- the reference's ONLY exported symbol, unchanged:
+ *        extern "C" double find_traj(Params *p);
+ *      replaces  src/trp_wrapper.cpp:16-20 (libtrp.so),
+ *                src/cub_wrapper.cpp:16-19 (libcub.so),
+ *                the older libbtrapz.so build (same symbol; strings: c1.txt -> slt_3d.txt).
+ *      `Params` is include/btrapz/py_cpp_.h:6-21 == src/trp_wrapper.py:19-32 (88 bytes).
+ *      libtrp.so / libcub.so / libbtrapz.so built from this repo export exactly that
+ *      symbol and forward to btrapz_find_traj() below with the library's variant and
+ *      default paths.  The reference's hard-coded file paths are kept as defaults and
+ *      can be redirected with BTRAPZ_INPUT / BTRAPZ_OUTPUT_PREFIX.
+ *
+ *  (2) the batched entry points (no reference counterpart: the reference solves one
+ *      QP per call, src/solve_3d.cc:1231-1414).  They replace, for B candidates at
+ *      once, FormulateProblem + osqp_setup + osqp_solve (src/solve_3d.cc:1143-1229,
+ *      1246, 1249; src/cuboid_3d.cc:632-988) and the acceptance test (:1251-1277).
+ *
+ * Plain C: opaque handle, POD structs, raw pointers and sizes.  No torch types.
+ * Every function returns 0 on success or a negative BTRAPZ_E* code; it never aborts
+ * the host process (the reference's CHECK_* do: include/btrapz/logging.h:256-258).
+ */
+#ifndef BTRAPZ_HIP_H
+#define BTRAPZ_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- reference ABI: include/btrapz/py_cpp_.h:6-21 ------------------------------ */
+typedef struct Params {
+  double s_acc_weight;
+  double s_jerk_weight;
+  double l_acc_weight;
+  double l_jerk_weight;
+  double weight_s_ref;
+  double weight_ds_ref;
+  double weight_l_ref;
+  double weight_dl_ref;
+  double weight_end_s;
+  double weight_end_l;
+  int iteration;
+} Params;
+
+#define BTRAPZ_FAIL_SENTINEL 100000000000.0 /* src/trp_wrapper.cpp:199 */
+
+enum { BTRAPZ_TRAPEZOID = 0, /* src/solve_3d.cc   */
+       BTRAPZ_CUBOID = 1 /* src/cuboid_3d.cc  */ };
+
+/* find_traj with the library-specific constants made explicit.
+ * variant: BTRAPZ_TRAPEZOID (trp_wrapper.cpp) or BTRAPZ_CUBOID (cub_wrapper.cpp).
+ * input_path / output_path: NULL -> environment override -> reference default.
+ * Returns a_cost (trp_wrapper.cpp:217-286 / cub_wrapper.cpp:201-262) or 1e11. */
+double btrapz_find_traj(int variant, const char *input_path, const char *output_path,
+                        const Params *p);
+
+/* ---- error codes ----------------------------------------------------------------- */
+enum {
+  BTRAPZ_OK = 0,
+  BTRAPZ_EINVAL = -1,   /* bad argument (B<1, S<1 or S>64, null pointer) */
+  BTRAPZ_ENODEVICE = -2, /* no HIP device / HIP runtime error at create */
+  BTRAPZ_EHIP = -3,     /* HIP runtime error during a call (see btrapz_last_error) */
+  BTRAPZ_ENOMEM = -4
+};
+
+/* ---- per-candidate status: OSQP status_val vocabulary (solve_3d.cc:1251-1253) ------ */
+enum {
+  BTRAPZ_SOLVED = 1,
+  BTRAPZ_SOLVED_INACCURATE = 2,
+  BTRAPZ_MAX_ITER_REACHED = -2,
+  BTRAPZ_PRIMAL_INFEASIBLE = -3
+};
+
+/* ---- batch layout ------------------------------------------------------------------
+ * seg[f][b][k]: field-major SoA, float64, f in [0,BTRAPZ_NUM_SEG_FIELDS), b candidate,
+ * k segment.  Fields 0-10 are the reference's Cube (include/btrapz/cube_type.h:2-24);
+ * 11-12 the per-segment ds bounds of solve_3d.cc:835-845; 13-16 the piecewise-linear
+ * reference of solve_3d.cc:1159-1166.                                               */
+enum {
+  BTRAPZ_F_T = 0,
+  BTRAPZ_F_DOWN_BIAS, BTRAPZ_F_DOWN_SKEW, BTRAPZ_F_UPP_BIAS, BTRAPZ_F_UPP_SKEW,
+  BTRAPZ_F_L_DOWN_BIAS, BTRAPZ_F_L_DOWN_SKEW, BTRAPZ_F_L_UPP_BIAS, BTRAPZ_F_L_UPP_SKEW,
+  BTRAPZ_F_BEG_L, BTRAPZ_F_END_L,
+  BTRAPZ_F_DS_LO, BTRAPZ_F_DS_HI,
+  BTRAPZ_F_X_SKEW, BTRAPZ_F_X_BIAS, BTRAPZ_F_Y_SKEW, BTRAPZ_F_Y_BIAS,
+  BTRAPZ_NUM_SEG_FIELDS
+};
+#define BTRAPZ_MAX_SEGMENTS 64
+
+/* Weights (Params) and limits (input-file header, trp_wrapper.cpp:59-64) shared by all
+ * candidates of a batch. */
+typedef struct btrapz_shared {
+  double w_s[4]; /* weight_s_ref, weight_ds_ref, s_acc_weight, s_jerk_weight */
+  double w_l[4]; /* weight_l_ref, weight_dl_ref, l_acc_weight, l_jerk_weight */
+  double weight_end_s, weight_end_l;
+  double ds_ref, dl_ref;
+  double dds[2], ddds[2], ddl[2], dddl[2];
+  double delta;
+  int variant;
+  int reserved;
+} btrapz_shared;
+
+typedef struct btrapz_options {
+  int max_iter;  /* interior-point iterations; 0 -> default (60) */
+  double eps;    /* KKT score target; 0 -> default (1e-9) */
+} btrapz_options;
+
+typedef struct btrapz_ctx btrapz_ctx;
+
+int btrapz_create(btrapz_ctx **ctx, int device);
+int btrapz_destroy(btrapz_ctx *ctx);
+const char *btrapz_last_error(const btrapz_ctx *ctx);
+/* Number of HIP devices visible (0 when the runtime finds none). */
+int btrapz_device_count(void);
+
+/* Solve B candidates of S segments each; all pointers are DEVICE pointers.
+ *   seg        [NUM_SEG_FIELDS][B][S]     init     [B][6] (s, ds, dds, l, dl, ddl at t=0)
+ *   ref_end    [B][2]  x_ref[N-1], y_ref[N-1]  (solve_3d.cc:268,315)
+ *   dl_bounds  [B][10] dy_bounds_[i], i=0..4, as lo,hi pairs (solve_3d.cc:1003-1004)
+ * outputs
+ *   ctrl   [B][12*S] control points in the reference's variable order (solve_3d.cc:1343-1344)
+ *   cost   [B] OSQP-style obj_val 0.5 x'Px + q'x ; +inf when status is not 1/2
+ *   status [B] ; iters [B] (may be NULL)
+ * stream: a hipStream_t (NULL = default stream).  Asynchronous: returns after launch. */
+int btrapz_solve_batch_device(btrapz_ctx *ctx, const btrapz_shared *shared,
+                              const btrapz_options *opt, int B, int S, const double *seg,
+                              const double *init, const double *ref_end,
+                              const double *dl_bounds, double *ctrl, double *cost,
+                              int *status, int *iters, void *stream);
+
+/* Arg-min of cost over contiguous groups of `group` candidates (B % group == 0).
+ * best_idx[g] = global candidate index (index_base + local), ties -> lowest index;
+ * -1 when no candidate of the group was solved.  Device pointers. */
+int btrapz_argmin_device(btrapz_ctx *ctx, int B, int group, long long index_base,
+                         const double *cost, long long *best_idx, double *best_cost,
+                         void *stream);
+
+/* Bernstein sampling (solve_3d.cc:1279-1392) of nsel selected candidates on device.
+ *   sel [nsel] candidate indices; t taken from seg; out [nsel][6][max_points]
+ *   (s, ds, dds, l, dl, ddl); npoints [nsel].  Device pointers. */
+int btrapz_sample_device(btrapz_ctx *ctx, int B, int S, double delta, const double *seg,
+                         const double *init, const double *ctrl, int nsel,
+                         const long long *sel, int max_points, double *out, int *npoints,
+                         void *stream);
+
+/* Host-pointer convenience wrapper: H2D, solve, D2H, synchronous. */
+int btrapz_solve_batch_host(btrapz_ctx *ctx, const btrapz_shared *shared,
+                            const btrapz_options *opt, int B, int S, const double *seg,
+                            const double *init, const double *ref_end,
+                            const double *dl_bounds, double *ctrl, double *cost,
+                            int *status, int *iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

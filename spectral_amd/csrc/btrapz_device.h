@@ -1,0 +1,45 @@
+// btrapz_device.h -- types shared by the kernels and the host side of libbtrapz_hip.so.
+#ifndef BTRAPZ_DEVICE_H
+#define BTRAPZ_DEVICE_H
+
+#include "../../include/btrapz_hip.h"
+
+namespace btrapz {
+
+// Device view of btrapz_shared: limits already in the form the rows use them.
+struct Shared {
+  double w_s[4], w_l[4];
+  double weight_end_s, weight_end_l;
+  double ds_ref, dl_ref;
+  double acc_s[2];   // dds clamped to [-1000,1000] (solve_3d.cc:836,843-844; ddx_bounds_ is uniform)
+  double acc_l[2];   // ddy_bounds_[i] (uniform, solve_3d.cc:1019-1020)
+  double jerk_s[2], jerk_l[2];
+  int variant;
+};
+
+struct KernelArgs {
+  int B, S;
+  const double *seg;        // [NUM_SEG_FIELDS][B][S]
+  const double *init;       // [B][6]
+  const double *ref_end;    // [B][2]
+  const double *dl_bounds;  // [B][10]
+  const double *mqm;        // [2][4][21]  M' pQp_d M, packed upper triangle (solve_3d.cc:87-143)
+  double *ctrl;             // [B][12 S]
+  double *axis_obj;         // [2B]
+  int *axis_status;         // [2B]
+  int *axis_iters;          // [2B]
+  Shared sh;
+  double eps;
+  int max_iter;
+};
+
+__global__ void ipm_solve_kernel(const KernelArgs a);
+__global__ void finalize_kernel(int B, const double *axis_obj, const int *axis_status, const int *axis_iters,
+                                double *cost, int *status, int *iters);
+__global__ void argmin_kernel(int group, long long index_base, const double *cost, long long *best_idx,
+                              double *best_cost);
+__global__ void sample_kernel(int B, int S, double delta, const double *seg, const double *init, const double *ctrl,
+                              int nsel, const long long *sel, int max_points, double *out, int *npoints);
+
+}  // namespace btrapz
+#endif

@@ -1,0 +1,214 @@
+// btrapz_host.hip -- host side of the batched C-ABI (include/btrapz_hip.h): context,
+// workspace, kernel launches.  No CPU fallback: without a HIP device every entry point
+// fails with BTRAPZ_ENODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "btrapz_device.h"
+
+using namespace btrapz;
+
+struct btrapz_ctx {
+  int device = 0;
+  std::string err;
+  // workspace (grown on demand)
+  double *d_axis_obj = nullptr;
+  int *d_axis_status = nullptr, *d_axis_iters = nullptr;
+  size_t axis_cap = 0;
+  double *d_mqm = nullptr;          // [2][4][21]
+  double h_mqm_w[8] = {NAN, NAN, NAN, NAN, NAN, NAN, NAN, NAN};  // weights the table was built for
+  // staging for the host-pointer wrapper
+  double *d_stage = nullptr; size_t stage_cap = 0;
+  int *d_istage = nullptr; size_t istage_cap = 0;
+};
+
+#define HIPCHK(ctx, call)                                                                     \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+      return BTRAPZ_EHIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+// M' pQp_d M, solve_3d.cc:87-143 (batch-invariant: depends on the weights only).
+static void build_mqm(const double w[4], double out[4][21]) {
+  static const double M[6][6] = {{1, 0, 0, 0, 0, 0},      {-5, 5, 0, 0, 0, 0},      {10, -20, 10, 0, 0, 0},
+                                 {-10, 30, -30, 10, 0, 0}, {5, -20, 30, -20, 5, 0}, {-1, 5, -10, 10, -5, 1}};
+  for (int d = 0; d < 4; d++) {
+    double pq[6][6] = {};
+    for (int i = d; i < 6; i++)
+      for (int j = d; j < 6; j++) {
+        double num = w[d];
+        for (int r = 0; r < d; r++) num *= double((i - r) * (j - r));
+        pq[i][j] = num / double(i + j - 2 * d + 1);
+      }
+    double T[6][6];
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) {
+        double s = 0;
+        for (int r = 0; r < 6; r++) s += M[r][i] * pq[r][j];
+        T[i][j] = s;
+      }
+    for (int j = 0; j < 6; j++)
+      for (int i = 0; i <= j; i++) {
+        double s = 0;
+        for (int r = 0; r < 6; r++) s += T[i][r] * M[r][j];
+        out[d][j * (j + 1) / 2 + i] = s;
+      }
+  }
+}
+
+extern "C" int btrapz_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int btrapz_create(btrapz_ctx **out, int device) {
+  if (!out) return BTRAPZ_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return BTRAPZ_ENODEVICE;
+  if (hipSetDevice(device) != hipSuccess) return BTRAPZ_ENODEVICE;
+  btrapz_ctx *c = new btrapz_ctx();
+  c->device = device;
+  if (hipMalloc(&c->d_mqm, sizeof(double) * 168) != hipSuccess) { delete c; return BTRAPZ_ENOMEM; }
+  *out = c;
+  return BTRAPZ_OK;
+}
+
+extern "C" int btrapz_destroy(btrapz_ctx *c) {
+  if (!c) return BTRAPZ_EINVAL;
+  (void)hipSetDevice(c->device);
+  (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters);
+  (void)hipFree(c->d_mqm); (void)hipFree(c->d_stage); (void)hipFree(c->d_istage);
+  delete c;
+  return BTRAPZ_OK;
+}
+
+extern "C" const char *btrapz_last_error(const btrapz_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+static int ensure_axis_ws(btrapz_ctx *c, size_t nprob) {
+  if (nprob <= c->axis_cap) return BTRAPZ_OK;
+  (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters);
+  c->d_axis_obj = nullptr; c->d_axis_status = nullptr; c->d_axis_iters = nullptr; c->axis_cap = 0;
+  HIPCHK(c, hipMalloc(&c->d_axis_obj, sizeof(double) * nprob));
+  HIPCHK(c, hipMalloc(&c->d_axis_status, sizeof(int) * nprob));
+  HIPCHK(c, hipMalloc(&c->d_axis_iters, sizeof(int) * nprob));
+  c->axis_cap = nprob;
+  return BTRAPZ_OK;
+}
+
+extern "C" int btrapz_solve_batch_device(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B,
+                                         int S, const double *seg, const double *init, const double *ref_end,
+                                         const double *dl_bounds, double *ctrl, double *cost, int *status, int *iters,
+                                         void *stream_) {
+  if (!c) return BTRAPZ_EINVAL;
+  if (!sh || B < 1 || S < 1 || S > BTRAPZ_MAX_SEGMENTS || !seg || !init || !ref_end || !dl_bounds || !ctrl || !cost ||
+      !status) {
+    c->err = "invalid argument";
+    return BTRAPZ_EINVAL;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure_axis_ws(c, 2 * (size_t)B);
+  if (rc != BTRAPZ_OK) return rc;
+  // batch-invariant M'QM table: rebuilt only when the weights change
+  double wkey[8];
+  memcpy(wkey, sh->w_s, sizeof(double) * 4); memcpy(wkey + 4, sh->w_l, sizeof(double) * 4);
+  if (memcmp(wkey, c->h_mqm_w, sizeof(wkey)) != 0) {
+    double tab[2][4][21];
+    build_mqm(sh->w_s, tab[0]); build_mqm(sh->w_l, tab[1]);
+    HIPCHK(c, hipMemcpyAsync(c->d_mqm, tab, sizeof(tab), hipMemcpyHostToDevice, stream));
+    HIPCHK(c, hipStreamSynchronize(stream));  // tab is a stack buffer
+    memcpy(c->h_mqm_w, wkey, sizeof(wkey));
+  }
+  KernelArgs a;
+  a.B = B; a.S = S; a.seg = seg; a.init = init; a.ref_end = ref_end; a.dl_bounds = dl_bounds; a.mqm = c->d_mqm;
+  a.ctrl = ctrl; a.axis_obj = c->d_axis_obj; a.axis_status = c->d_axis_status; a.axis_iters = c->d_axis_iters;
+  memcpy(a.sh.w_s, sh->w_s, sizeof(a.sh.w_s)); memcpy(a.sh.w_l, sh->w_l, sizeof(a.sh.w_l));
+  a.sh.weight_end_s = sh->weight_end_s; a.sh.weight_end_l = sh->weight_end_l;
+  a.sh.ds_ref = sh->ds_ref; a.sh.dl_ref = sh->dl_ref;
+  a.sh.acc_s[0] = fmax(sh->dds[0], -1000.0); a.sh.acc_s[1] = fmin(sh->dds[1], 1000.0);  // solve_3d.cc:836,843-844
+  a.sh.acc_l[0] = sh->ddl[0]; a.sh.acc_l[1] = sh->ddl[1];
+  a.sh.jerk_s[0] = sh->ddds[0]; a.sh.jerk_s[1] = sh->ddds[1];
+  a.sh.jerk_l[0] = sh->dddl[0]; a.sh.jerk_l[1] = sh->dddl[1];
+  a.sh.variant = sh->variant;
+  a.eps = (opt && opt->eps > 0) ? opt->eps : 1e-9;
+  a.max_iter = (opt && opt->max_iter > 0) ? opt->max_iter : 60;
+  const int gpw = 64 / S;
+  const long long nprob = 2LL * B;
+  const unsigned blocks = (unsigned)((nprob + gpw - 1) / gpw);
+  hipLaunchKernelGGL(ipm_solve_kernel, dim3(blocks), dim3(64), 0, stream, a);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, B, c->d_axis_obj, c->d_axis_status,
+                     c->d_axis_iters, cost, status, iters);
+  HIPCHK(c, hipGetLastError());
+  return BTRAPZ_OK;
+}
+
+extern "C" int btrapz_argmin_device(btrapz_ctx *c, int B, int group, long long index_base, const double *cost,
+                                    long long *best_idx, double *best_cost, void *stream_) {
+  if (!c) return BTRAPZ_EINVAL;
+  if (B < 1 || group < 1 || B % group != 0 || !cost || !best_idx || !best_cost) { c->err = "invalid argument"; return BTRAPZ_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(argmin_kernel, dim3(B / group), dim3(256), 0, (hipStream_t)stream_, group, index_base, cost,
+                     best_idx, best_cost);
+  HIPCHK(c, hipGetLastError());
+  return BTRAPZ_OK;
+}
+
+extern "C" int btrapz_sample_device(btrapz_ctx *c, int B, int S, double delta, const double *seg, const double *init,
+                                    const double *ctrl, int nsel, const long long *sel, int max_points, double *out,
+                                    int *npoints, void *stream_) {
+  if (!c) return BTRAPZ_EINVAL;
+  if (B < 1 || S < 1 || nsel < 1 || !(delta > 0) || !seg || !init || !ctrl || !sel || !out || !npoints || max_points < 1) {
+    c->err = "invalid argument"; return BTRAPZ_EINVAL;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(sample_kernel, dim3(nsel), dim3(64), 0, (hipStream_t)stream_, B, S, delta, seg, init, ctrl, nsel,
+                     sel, max_points, out, npoints);
+  HIPCHK(c, hipGetLastError());
+  return BTRAPZ_OK;
+}
+
+extern "C" int btrapz_solve_batch_host(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B, int S,
+                                       const double *seg, const double *init, const double *ref_end,
+                                       const double *dl_bounds, double *ctrl, double *cost, int *status, int *iters) {
+  if (!c) return BTRAPZ_EINVAL;
+  if (B < 1 || S < 1 || S > BTRAPZ_MAX_SEGMENTS) { c->err = "invalid argument"; return BTRAPZ_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n_seg = (size_t)BTRAPZ_NUM_SEG_FIELDS * B * S, n_init = (size_t)B * 6, n_re = (size_t)B * 2, n_dl = (size_t)B * 10;
+  const size_t n_ctrl = (size_t)B * 12 * S, n_cost = B;
+  const size_t need = n_seg + n_init + n_re + n_dl + n_ctrl + n_cost;
+  if (need > c->stage_cap) {
+    (void)hipFree(c->d_stage); c->d_stage = nullptr; c->stage_cap = 0;
+    HIPCHK(c, hipMalloc(&c->d_stage, sizeof(double) * need));
+    c->stage_cap = need;
+  }
+  if ((size_t)2 * B > c->istage_cap) {
+    (void)hipFree(c->d_istage); c->d_istage = nullptr; c->istage_cap = 0;
+    HIPCHK(c, hipMalloc(&c->d_istage, sizeof(int) * 2 * (size_t)B));
+    c->istage_cap = 2 * (size_t)B;
+  }
+  double *d_seg = c->d_stage, *d_init = d_seg + n_seg, *d_re = d_init + n_init, *d_dl = d_re + n_re;
+  double *d_ctrl = d_dl + n_dl, *d_cost = d_ctrl + n_ctrl;
+  int *d_status = c->d_istage, *d_iters = c->d_istage + B;
+  HIPCHK(c, hipMemcpy(d_seg, seg, sizeof(double) * n_seg, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(d_init, init, sizeof(double) * n_init, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(d_re, ref_end, sizeof(double) * n_re, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(d_dl, dl_bounds, sizeof(double) * n_dl, hipMemcpyHostToDevice));
+  int rc = btrapz_solve_batch_device(c, sh, opt, B, S, d_seg, d_init, d_re, d_dl, d_ctrl, d_cost, d_status, d_iters, nullptr);
+  if (rc != BTRAPZ_OK) return rc;
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(ctrl, d_ctrl, sizeof(double) * n_ctrl, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(cost, d_cost, sizeof(double) * n_cost, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(status, d_status, sizeof(int) * B, hipMemcpyDeviceToHost));
+  if (iters) HIPCHK(c, hipMemcpy(iters, d_iters, sizeof(int) * B, hipMemcpyDeviceToHost));
+  return BTRAPZ_OK;
+}

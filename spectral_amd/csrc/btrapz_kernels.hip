@@ -1,0 +1,591 @@
+// btrapz_kernels.hip -- gfx950 (CDNA4) kernels of the batched Bezier-in-corridor QP path.
+//
+// What one launch computes, per candidate corridor (reference call sites in /root/reference):
+//   FormulateProblem   src/solve_3d.cc:1143-1229   (P,q,A,l,u from S Cube records)
+//   CalculateKernel    src/solve_3d.cc:70-224      P_k = 2(t^3 MQM0 + t MQM1 + MQM2/t + MQM3/t^3)
+//   CalculateOffset    src/solve_3d.cc:226-321     q_k
+//   CalculateAffineConstraint  src/solve_3d.cc:779-1129 (trapezoid), src/cuboid_3d.cc:632-988
+//   osqp_setup + osqp_solve    src/solve_3d.cc:1246,1249  (external OSQP) -> replaced, see below
+//   acceptance         src/solve_3d.cc:1251-1277
+//
+// The reference hands the assembled sparse QP to OSQP (ADMM).  On these problems ADMM needs
+// hundreds to thousands of iterations and stops ~1e-3 away from the optimum; the QP is
+// strictly convex (unique x*), so any exact method returns the same answer.  This kernel
+// uses the QP's structure instead:
+//   * the two axes (s, l) share no row and no P entry -> 2B independent axis problems;
+//   * every equality row is C2-continuity at a joint or the initial state
+//     (solve_3d.cc:896-949): the feasible set of the equalities is parametrised EXACTLY by
+//     the joint states X_j = (p, v, a), j = 1..S (null-space form, no equality multipliers);
+//   * every inequality row touches one segment only -> the Newton matrix of a primal-dual
+//     interior-point method in X is block tridiagonal with 3x3 blocks.
+// Mapping: one lane per segment, floor(64/S) axis problems per wavefront, the whole
+// interior-point state in VGPRs (+LDS for group reductions and the P blocks); neighbour
+// exchange with wavefront shuffles; the block-tridiagonal LDL^T and its sweeps run as S
+// sequential steps in which lane k owns pivot block k.  No HBM traffic inside the solve.
+#include <hip/hip_runtime.h>
+
+#include "btrapz_device.h"
+
+namespace btrapz {
+
+#define UNROLL _Pragma("unroll")
+#define SYM(i, j) ((j) * ((j) + 1) / 2 + (i))  // i <= j, packed upper triangle, column-wise
+
+__device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+
+// ---- constraint rows of one segment (solve_3d.cc:823-888): 6 pos, 5 vel, 4 acc, 3 jerk ----
+__device__ __forceinline__ void G_apply(const double (&c)[6], double t, double (&o)[18]) {
+  UNROLL for (int i = 0; i < 6; i++) o[i] = t * c[i];
+  UNROLL for (int i = 0; i < 5; i++) o[6 + i] = 5.0 * (c[i + 1] - c[i]);
+  UNROLL for (int i = 0; i < 4; i++) o[11 + i] = 20.0 * ((c[i] - 2.0 * c[i + 1]) + c[i + 2]);
+  UNROLL for (int i = 0; i < 3; i++) o[15 + i] = 60.0 * ((c[i + 3] - c[i]) + 3.0 * (c[i + 1] - c[i + 2]));
+}
+__device__ __forceinline__ void GT_apply(const double (&y)[18], double t, double (&o)[6]) {
+  UNROLL for (int i = 0; i < 6; i++) o[i] = t * y[i];
+  UNROLL for (int i = 0; i < 5; i++) { o[i] -= 5.0 * y[6 + i]; o[i + 1] += 5.0 * y[6 + i]; }
+  UNROLL for (int i = 0; i < 4; i++) { o[i] += 20.0 * y[11 + i]; o[i + 1] -= 40.0 * y[11 + i]; o[i + 2] += 20.0 * y[11 + i]; }
+  UNROLL for (int i = 0; i < 3; i++) {
+    o[i] -= 60.0 * y[15 + i]; o[i + 1] += 180.0 * y[15 + i]; o[i + 2] -= 180.0 * y[15 + i]; o[i + 3] += 60.0 * y[15 + i];
+  }
+}
+// H += G' diag(w) G   (packed symmetric 6x6)
+__device__ __forceinline__ void GWG_accumulate(const double (&w)[18], double t, double (&H)[21]) {
+  const double t2 = t * t;
+  UNROLL for (int i = 0; i < 6; i++) H[SYM(i, i)] += t2 * w[i];
+  UNROLL for (int i = 0; i < 5; i++) {
+    const double a = 25.0 * w[6 + i];
+    H[SYM(i, i)] += a; H[SYM(i + 1, i + 1)] += a; H[SYM(i, i + 1)] -= a;
+  }
+  UNROLL for (int i = 0; i < 4; i++) {
+    const double a = 400.0 * w[11 + i];
+    H[SYM(i, i)] += a; H[SYM(i, i + 1)] -= 2.0 * a; H[SYM(i, i + 2)] += a;
+    H[SYM(i + 1, i + 1)] += 4.0 * a; H[SYM(i + 1, i + 2)] -= 2.0 * a; H[SYM(i + 2, i + 2)] += a;
+  }
+  UNROLL for (int i = 0; i < 3; i++) {
+    const double a = 3600.0 * w[15 + i];
+    H[SYM(i, i)] += a; H[SYM(i, i + 1)] -= 3.0 * a; H[SYM(i, i + 2)] += 3.0 * a; H[SYM(i, i + 3)] -= a;
+    H[SYM(i + 1, i + 1)] += 9.0 * a; H[SYM(i + 1, i + 2)] -= 9.0 * a; H[SYM(i + 1, i + 3)] += 3.0 * a;
+    H[SYM(i + 2, i + 2)] += 9.0 * a; H[SYM(i + 2, i + 3)] -= 3.0 * a; H[SYM(i + 3, i + 3)] += a;
+  }
+}
+__device__ __forceinline__ double symget(const double (&H)[21], int i, int j) { return i <= j ? H[SYM(i, j)] : H[SYM(j, i)]; }
+
+// Null-space maps.  X = (p, v, a) physical state at a joint; segment duration t.
+//   start of segment:  c0 = p/t, c1 = c0 + v/5, c2 = c0 + 2v/5 + a t/20
+//   end of segment:    c5 = p/t, c4 = c5 - v/5, c3 = c5 - 2v/5 + a t/20
+// (the inverse of the reference's equality rows solve_3d.cc:896-949).
+struct NullMap { double it, t20; };
+__device__ __forceinline__ void U_apply(const NullMap m, const double (&X)[3], double &c0, double &c1, double &c2) {
+  c0 = m.it * X[0]; c1 = c0 + 0.2 * X[1]; c2 = c0 + 0.4 * X[1] + m.t20 * X[2];
+}
+__device__ __forceinline__ void V_apply(const NullMap m, const double (&X)[3], double &c3, double &c4, double &c5) {
+  c5 = m.it * X[0]; c4 = c5 - 0.2 * X[1]; c3 = c5 - 0.4 * X[1] + m.t20 * X[2];
+}
+// transposes: (h0,h1,h2) -> U'h ; (h3,h4,h5) -> V'h
+__device__ __forceinline__ void UT_apply(const NullMap m, double h0, double h1, double h2, double (&o)[3]) {
+  o[0] = m.it * ((h0 + h1) + h2); o[1] = 0.2 * h1 + 0.4 * h2; o[2] = m.t20 * h2;
+}
+__device__ __forceinline__ void VT_apply(const NullMap m, double h3, double h4, double h5, double (&o)[3]) {
+  o[0] = m.it * ((h3 + h4) + h5); o[1] = -0.4 * h3 - 0.2 * h4; o[2] = m.t20 * h3;
+}
+
+// ---- 3x3 SPD helpers: LDL^T factor F = (l10, l20, l21, 1/d0, 1/d1, 1/d2) ----
+__device__ __forceinline__ void ldl3(const double (&A)[6] /*00 01 02 11 12 22*/, double (&F)[6]) {
+  const double id0 = rcp(A[0]);
+  const double l10 = A[1] * id0, l20 = A[2] * id0;
+  const double d1 = A[3] - l10 * A[1];
+  const double id1 = rcp(d1);
+  const double e = A[4] - l20 * A[1];
+  const double l21 = e * id1;
+  const double d2 = A[5] - l20 * A[2] - l21 * e;
+  F[0] = l10; F[1] = l20; F[2] = l21; F[3] = id0; F[4] = id1; F[5] = rcp(d2);
+}
+__device__ __forceinline__ void ldl3_solve(const double (&F)[6], double b0, double b1, double b2, double &x0, double &x1, double &x2) {
+  const double z0 = b0, z1 = b1 - F[0] * z0, z2 = b2 - F[1] * z0 - F[2] * z1;
+  x2 = z2 * F[5];
+  x1 = z1 * F[4] - F[2] * x2;
+  x0 = z0 * F[3] - F[0] * x1 - F[1] * x2;
+}
+
+// ---- reductions over the S lanes of a group through LDS (block = one wavefront) ----
+struct Red4 { double a, b, c, d; };
+__device__ __forceinline__ Red4 group_reduce(double (*red)[64], int lane, int gbase, int S, double vsum, double vmax0,
+                                             double vmax1, double vmin) {
+  __syncthreads();
+  red[0][lane] = vsum; red[1][lane] = vmax0; red[2][lane] = vmax1; red[3][lane] = vmin;
+  __syncthreads();
+  Red4 r = {0.0, 0.0, 0.0, 1e300};
+  for (int j = 0; j < S; j++) {
+    r.a += red[0][gbase + j];
+    r.b = fmax(r.b, red[1][gbase + j]);
+    r.c = fmax(r.c, red[2][gbase + j]);
+    r.d = fmin(r.d, red[3][gbase + j]);
+  }
+  return r;
+}
+
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a) {
+  __shared__ double red[4][64];
+  __shared__ double Psm[21][64];
+
+  const int lane = threadIdx.x;
+  const int S = a.S;
+  const int gpw = 64 / S;
+  const int g = lane / S;
+  const int k = lane - g * S;
+  const bool lane_in_group = g < gpw;
+  const int gl = lane_in_group ? g : gpw - 1;
+  const int gbase = gl * S;
+  const long long nprob = 2LL * a.B;
+  long long prob = (long long)blockIdx.x * gpw + gl;
+  const bool valid = lane_in_group && prob < nprob;
+  if (prob >= nprob) prob = nprob - 1;
+  const int b = (int)(prob >> 1);
+  const int axis = (int)(prob & 1);
+  const bool first = (k == 0), last = (k == S - 1);
+
+  // ---------------- load the segment record (coalesced: lanes -> consecutive (b,k)) ----------
+  const size_t BS = (size_t)a.B * S;
+  const size_t e = (size_t)b * S + k;
+  const double *sg = a.seg;
+  const double t = sg[BTRAPZ_F_T * BS + e];
+  const double it = rcp(t);
+  const NullMap nm = {it, t * 0.05};
+  const Shared &sh = a.sh;
+  const int variant = sh.variant;
+
+  // position rows: lo_i = plo0 + i*dplo , up_i = phi0 + i*dphi  (solve_3d.cc:827-828,965-966)
+  double plo0, dplo, phi0, dphi;
+  {
+    double lb, ls, ub, us;
+    if (axis == 0) {
+      lb = sg[BTRAPZ_F_DOWN_BIAS * BS + e]; ls = sg[BTRAPZ_F_DOWN_SKEW * BS + e];
+      ub = sg[BTRAPZ_F_UPP_BIAS * BS + e];  us = sg[BTRAPZ_F_UPP_SKEW * BS + e];
+    } else {
+      lb = sg[BTRAPZ_F_L_DOWN_BIAS * BS + e]; ls = sg[BTRAPZ_F_L_DOWN_SKEW * BS + e];
+      ub = sg[BTRAPZ_F_L_UPP_BIAS * BS + e];  us = sg[BTRAPZ_F_L_UPP_SKEW * BS + e];
+    }
+    plo0 = lb; dplo = ls * 0.2 * t; phi0 = ub; dphi = us * 0.2 * t;
+    if (variant == BTRAPZ_CUBOID) {
+      if (axis == 0) {  // cuboid_3d.cc:677-689: inscribed interval, clamped to [0,100]
+        const double lo = fmax(0.0, fmax(lb, lb + ls * t));
+        const double hi = fmin(100.0, fmin(ub, ub + us * t));
+        plo0 = lo; phi0 = hi;
+      } else {  // cuboid_3d.cc:826-827
+        plo0 = sg[BTRAPZ_F_BEG_L * BS + e]; phi0 = sg[BTRAPZ_F_END_L * BS + e];
+      }
+      dplo = 0.0; dphi = 0.0;
+    }
+  }
+  // velocity rows (solve_3d.cc:835-859 s axis; :1003-1004 l axis: dy_bounds_[i], i = row index)
+  double vlo[5], vhi[5];
+  if (axis == 0) {
+    const double lo = sg[BTRAPZ_F_DS_LO * BS + e], hi = sg[BTRAPZ_F_DS_HI * BS + e];
+    UNROLL for (int i = 0; i < 5; i++) { vlo[i] = lo; vhi[i] = hi; }
+  } else {
+    UNROLL for (int i = 0; i < 5; i++) { vlo[i] = a.dl_bounds[(size_t)b * 10 + 2 * i]; vhi[i] = a.dl_bounds[(size_t)b * 10 + 2 * i + 1]; }
+  }
+  // acceleration / jerk rows (solve_3d.cc:862-888, 1010-1037)
+  const double alo = (axis == 0 ? sh.acc_s[0] : sh.acc_l[0]) * t, ahi = (axis == 0 ? sh.acc_s[1] : sh.acc_l[1]) * t;
+  const double jlo = (axis == 0 ? sh.jerk_s[0] : sh.jerk_l[0]) * t * t, jhi = (axis == 0 ? sh.jerk_s[1] : sh.jerk_l[1]) * t * t;
+
+#define LO(r) ((r) < 6 ? plo0 + (double)(r) * dplo : (r) < 11 ? vlo[((r) >= 6 && (r) < 11) ? (r) - 6 : 0] : (r) < 15 ? alo : jlo)
+#define UP(r) ((r) < 6 ? phi0 + (double)(r) * dphi : (r) < 11 ? vhi[((r) >= 6 && (r) < 11) ? (r) - 6 : 0] : (r) < 15 ? ahi : jhi)
+
+  // P block (solve_3d.cc:159-171) from the batch-invariant MQM_d = M' pQp_d M (device constant table)
+  double P[21];
+  {
+    const double *mq = a.mqm + axis * 84;
+    const double t3 = t * t * t, it3 = it * it * it;
+    UNROLL for (int i = 0; i < 21; i++)
+      P[i] = 2.0 * (t3 * mq[i] + t * mq[21 + i] + mq[42 + i] * it + mq[63 + i] * it3);
+    if (last) P[SYM(5, 5)] += 2.0 * (axis == 0 ? sh.weight_end_s : sh.weight_end_l) * t * t;  // :164-168
+    UNROLL for (int i = 0; i < 21; i++) Psm[i][lane] = P[i];
+  }
+  // q block (solve_3d.cc:248-268): q_p in the monomial basis, then q_p * M
+  double q[6];
+  {
+    const double skew = sg[(axis == 0 ? BTRAPZ_F_X_SKEW : BTRAPZ_F_Y_SKEW) * BS + e];
+    const double bias = sg[(axis == 0 ? BTRAPZ_F_X_BIAS : BTRAPZ_F_Y_BIAS) * BS + e];
+    const double wr = axis == 0 ? sh.w_s[0] : sh.w_l[0], wd = axis == 0 ? sh.w_s[1] : sh.w_l[1];
+    const double dref = axis == 0 ? sh.ds_ref : sh.dl_ref;
+    double qp[6];
+    UNROLL for (int i = 0; i < 6; i++) {
+      qp[i] = -2.0 * (t * t * t) * wr * skew / (double)(i + 2) - 2.0 * (t * t) * wr * bias / (double)(i + 1);
+      if (i > 0) qp[i] += -2.0 * wd * dref * t;
+    }
+    // M (Bernstein -> monomial, solve_3d.cc:122-127), row = power, col = control point
+    q[0] = qp[0] - 5.0 * qp[1] + 10.0 * qp[2] - 10.0 * qp[3] + 5.0 * qp[4] - qp[5];
+    q[1] = 5.0 * qp[1] - 20.0 * qp[2] + 30.0 * qp[3] - 20.0 * qp[4] + 5.0 * qp[5];
+    q[2] = 10.0 * qp[2] - 30.0 * qp[3] + 30.0 * qp[4] - 10.0 * qp[5];
+    q[3] = 10.0 * qp[3] - 20.0 * qp[4] + 10.0 * qp[5];
+    q[4] = 5.0 * qp[4] - 5.0 * qp[5];
+    q[5] = qp[5];
+    if (last) q[5] -= dref * 2.0 * a.ref_end[(size_t)b * 2 + axis] * t;  // :268/:315 (multiplies by d_ref: bug-compatible)
+  }
+  double Xinit[3];
+  UNROLL for (int i = 0; i < 3; i++) Xinit[i] = a.init[(size_t)b * 6 + axis * 3 + i];
+
+  // ---------------- consistency of the bounds -------------------------------------------
+  double gapmin = 1e300, bnorm = 0.0, qn = 0.0;
+  UNROLL for (int r = 0; r < 18; r++) {
+    gapmin = fmin(gapmin, UP(r) - LO(r));
+    bnorm = fmax(bnorm, fmax(fabs(LO(r)), fabs(UP(r))));
+  }
+  UNROLL for (int i = 0; i < 6; i++) qn = fmax(qn, fabs(q[i]));
+  // ---------------- starting point: constant-velocity propagation of the initial state -----
+  double X[3];
+  {
+    __syncthreads();
+    red[0][lane] = t;
+    __syncthreads();
+    double tsum = 0.0;
+    for (int j = 0; j < S; j++) tsum += (j <= k) ? red[0][gbase + j] : 0.0;
+    X[0] = Xinit[0] + Xinit[1] * tsum; X[1] = Xinit[1]; X[2] = 0.0;
+  }
+  Red4 r0 = group_reduce(red, lane, gbase, S, 0.0, bnorm, qn, gapmin);
+  bnorm = r0.b; qn = r0.c; gapmin = r0.d;
+  const bool infeasible_bounds = !(gapmin >= 0.0) || !(t > 0.0);
+
+  double sl[18], su[18], ll[18], lu[18];
+  {
+    double Xp[3], c[6], Gc[18];
+    UNROLL for (int i = 0; i < 3; i++) { const double v = __shfl_up(X[i], 1); Xp[i] = first ? Xinit[i] : v; }
+    U_apply(nm, Xp, c[0], c[1], c[2]);
+    V_apply(nm, X, c[3], c[4], c[5]);
+    G_apply(c, t, Gc);
+    UNROLL for (int r = 0; r < 18; r++) {
+      sl[r] = fmax(Gc[r] - LO(r), 1.0); su[r] = fmax(UP(r) - Gc[r], 1.0);
+      ll[r] = 1.0; lu[r] = 1.0;
+    }
+  }
+
+  const double eps = a.eps;
+  const double inv_m = 1.0 / (36.0 * (double)S);
+  double best_score = 1e300, Xb[3] = {X[0], X[1], X[2]};
+  int best_it = 0, iters = 0;
+  bool done = !valid || infeasible_bounds;
+
+  for (int iter = 0; iter < a.max_iter; ++iter) {
+    // ---- 1. control points of this segment, rows, residuals ----
+    double Xp[3], c[6], Gc[18];
+    UNROLL for (int i = 0; i < 3; i++) { const double v = __shfl_up(X[i], 1); Xp[i] = first ? Xinit[i] : v; }
+    U_apply(nm, Xp, c[0], c[1], c[2]);
+    V_apply(nm, X, c[3], c[4], c[5]);
+    G_apply(c, t, Gc);
+    double mu_part = 0.0, rp_part = 0.0, y[18];
+    UNROLL for (int r = 0; r < 18; r++) {
+      const double rpl = Gc[r] - sl[r] - LO(r), rpu = Gc[r] + su[r] - UP(r);
+      rp_part = fmax(rp_part, fmax(fabs(rpl), fabs(rpu)));
+      mu_part += sl[r] * ll[r] + su[r] * lu[r];
+      y[r] = lu[r] - ll[r];
+    }
+    double gc[6], Pc[6], dscale = 0.0;
+    GT_apply(y, t, gc);
+    UNROLL for (int i = 0; i < 6; i++) dscale = fmax(dscale, fabs(gc[i]));
+    UNROLL for (int i = 0; i < 6; i++) {
+      double s = 0.0;
+      UNROLL for (int j = 0; j < 6; j++) s += (i <= j ? Psm[SYM(i, j)][lane] : Psm[SYM(j, i)][lane]) * c[j];
+      Pc[i] = s;
+      dscale = fmax(dscale, fabs(s));
+      gc[i] += s + q[i];
+    }
+    // reduced gradient for X_{k+1}: V' gc[3..5] + (lane k+1) U' gc[0..2]
+    double rd[3], un[3];
+    VT_apply(nm, gc[3], gc[4], gc[5], rd);
+    UT_apply(nm, gc[0], gc[1], gc[2], un);
+    UNROLL for (int i = 0; i < 3; i++) { const double v = __shfl_down(un[i], 1); rd[i] += last ? 0.0 : v; }
+    const double rd_part = fmax(fabs(rd[0]), fmax(fabs(rd[1]), fabs(rd[2])));
+    Red4 rr = group_reduce(red, lane, gbase, S, mu_part, rd_part, rp_part, -dscale);
+    const double mu = rr.a * inv_m;
+    const double rdn = rr.b, rpn = rr.c, dsc = -rr.d;
+    // KKT score: dual residual relative to (1+|q|) with a round-off floor, primal residual
+    // relative to the bound scale, complementarity absolute.
+    const double rd_eff = fmax(rdn - 2e-13 * dsc, 0.0);
+    const double score = fmax(fmax(rd_eff / (1.0 + qn), rpn / (1.0 + bnorm)), mu);
+    if (!done) {
+      iters = iter;
+      if (score < best_score) { best_score = score; best_it = iter; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
+      if (score < eps || (best_score < 1e-5 && iter - best_it >= 3) || !(score == score)) done = true;
+    }
+    if (__all(done)) break;
+
+    // ---- 2. Newton matrix: H = P + G'WG ; M = Phi' H Phi ; block tridiagonal T, M01 ----
+    double isl[18], isu[18], H[21];
+    UNROLL for (int i = 0; i < 21; i++) H[i] = Psm[i][lane];
+    {
+      double W[18];
+      UNROLL for (int r = 0; r < 18; r++) {
+        isl[r] = rcp(sl[r]); isu[r] = rcp(su[r]);
+        W[r] = ll[r] * isl[r] + lu[r] * isu[r];
+      }
+      GWG_accumulate(W, t, H);
+    }
+    double M01[9], T[6];
+    {
+      double w0[3], w1[3], w2[3], col[3], M00[6];
+      // M00 = U' H00 U
+      UT_apply(nm, H[SYM(0, 0)], H[SYM(0, 1)], H[SYM(0, 2)], w0);
+      UT_apply(nm, H[SYM(0, 1)], H[SYM(1, 1)], H[SYM(1, 2)], w1);
+      UT_apply(nm, H[SYM(0, 2)], H[SYM(1, 2)], H[SYM(2, 2)], w2);
+      UT_apply(nm, w0[0], w1[0], w2[0], col); M00[0] = col[0]; M00[1] = col[1]; M00[2] = col[2];
+      UT_apply(nm, w0[1], w1[1], w2[1], col); M00[3] = col[1]; M00[4] = col[2];
+      UT_apply(nm, w0[2], w1[2], w2[2], col); M00[5] = col[2];
+      // M01 = U' H01 V  (rows: X_k components, cols: X_{k+1} components)
+      VT_apply(nm, H[SYM(0, 3)], H[SYM(0, 4)], H[SYM(0, 5)], w0);
+      VT_apply(nm, H[SYM(1, 3)], H[SYM(1, 4)], H[SYM(1, 5)], w1);
+      VT_apply(nm, H[SYM(2, 3)], H[SYM(2, 4)], H[SYM(2, 5)], w2);
+      UNROLL for (int j = 0; j < 3; j++) {
+        UT_apply(nm, w0[j], w1[j], w2[j], col);
+        M01[0 * 3 + j] = col[0]; M01[1 * 3 + j] = col[1]; M01[2 * 3 + j] = col[2];
+      }
+      // M11 = V' H11 V
+      VT_apply(nm, H[SYM(3, 3)], H[SYM(3, 4)], H[SYM(3, 5)], w0);
+      VT_apply(nm, H[SYM(3, 4)], H[SYM(4, 4)], H[SYM(4, 5)], w1);
+      VT_apply(nm, H[SYM(3, 5)], H[SYM(4, 5)], H[SYM(5, 5)], w2);
+      VT_apply(nm, w0[0], w1[0], w2[0], col); T[0] = col[0]; T[1] = col[1]; T[2] = col[2];
+      VT_apply(nm, w0[1], w1[1], w2[1], col); T[3] = col[1]; T[4] = col[2];
+      VT_apply(nm, w0[2], w1[2], w2[2], col); T[5] = col[2];
+      // diagonal block of X_{k+1}: M11_k + M00_{k+1}
+      UNROLL for (int i = 0; i < 6; i++) { const double v = __shfl_down(M00[i], 1); T[i] += last ? 0.0 : v; }
+    }
+    // ---- 3. block LDL^T: S_0 = T_0 ; C_k = S_{k-1}^{-1} M01_k ; S_k = T_k - M01_k' C_k ----
+    double F[6] = {0.0, 0.0, 0.0, 1.0, 1.0, 1.0}, C[9];
+    UNROLL for (int i = 0; i < 9; i++) C[i] = 0.0;
+    for (int step = 0; step < S; ++step) {
+      double pF[6];
+      UNROLL for (int i = 0; i < 6; i++) pF[i] = __shfl_up(F[i], 1);
+      if (k == step) {
+        double Sk[6] = {T[0], T[1], T[2], T[3], T[4], T[5]};
+        if (!first) {
+          UNROLL for (int j = 0; j < 3; j++) ldl3_solve(pF, M01[j], M01[3 + j], M01[6 + j], C[j], C[3 + j], C[6 + j]);
+          // Sk(a,b) -= sum_r M01(r,a) C(r,b)
+          Sk[0] -= M01[0] * C[0] + M01[3] * C[3] + M01[6] * C[6];
+          Sk[1] -= M01[0] * C[1] + M01[3] * C[4] + M01[6] * C[7];
+          Sk[2] -= M01[0] * C[2] + M01[3] * C[5] + M01[6] * C[8];
+          Sk[3] -= M01[1] * C[1] + M01[4] * C[4] + M01[7] * C[7];
+          Sk[4] -= M01[1] * C[2] + M01[4] * C[5] + M01[7] * C[8];
+          Sk[5] -= M01[2] * C[2] + M01[5] * C[5] + M01[8] * C[8];
+        }
+        ldl3(Sk, F);
+      }
+    }
+
+    // ---- 4. predictor (sigma = 0) and corrector solves ----
+    double Gdc_aff[18];
+    double sigma_mu = 0.0;
+    double alpha = 0.0;
+    UNROLL for (int pass = 0; pass < 2; ++pass) {
+      // rhs in c space: h = gc + G' tv ; tv = rcl/sl - rcu/su + (ll/sl) rpl + (lu/su) rpu
+      double tv[18];
+      UNROLL for (int r = 0; r < 18; r++) {
+        const double rpl = Gc[r] - sl[r] - LO(r), rpu = Gc[r] + su[r] - UP(r);
+        double rcl = sl[r] * ll[r], rcu = su[r] * lu[r];
+        if (pass == 1) {
+          const double dsl = Gdc_aff[r] + rpl, dsu = -Gdc_aff[r] - rpu;
+          const double dll = -ll[r] - ll[r] * dsl * isl[r], dlu = -lu[r] - lu[r] * dsu * isu[r];
+          rcl += dsl * dll - sigma_mu; rcu += dsu * dlu - sigma_mu;
+        }
+        tv[r] = (rcl + ll[r] * rpl) * isl[r] - (rcu - lu[r] * rpu) * isu[r];
+      }
+      double h[6];
+      GT_apply(tv, t, h);
+      UNROLL for (int i = 0; i < 6; i++) h[i] += gc[i];
+      double u[3], hn[3];
+      VT_apply(nm, h[3], h[4], h[5], u);
+      UT_apply(nm, h[0], h[1], h[2], hn);
+      UNROLL for (int i = 0; i < 3; i++) { const double v = __shfl_down(hn[i], 1); u[i] = -(u[i] + (last ? 0.0 : v)); }
+      // forward: u_k -= C_k' u_{k-1}
+      for (int step = 1; step < S; ++step) {
+        double pu[3];
+        UNROLL for (int i = 0; i < 3; i++) pu[i] = __shfl_up(u[i], 1);
+        if (k == step) {
+          u[0] -= C[0] * pu[0] + C[3] * pu[1] + C[6] * pu[2];
+          u[1] -= C[1] * pu[0] + C[4] * pu[1] + C[7] * pu[2];
+          u[2] -= C[2] * pu[0] + C[5] * pu[1] + C[8] * pu[2];
+        }
+      }
+      // backward: dX_{k+1} = S_k^{-1} u_k - C_{k+1} dX_{k+2}
+      double v[3], dX[3], w[3];
+      ldl3_solve(F, u[0], u[1], u[2], v[0], v[1], v[2]);
+      UNROLL for (int i = 0; i < 3; i++) dX[i] = v[i];
+      UNROLL for (int i = 0; i < 3; i++) w[i] = C[3 * i] * dX[0] + C[3 * i + 1] * dX[1] + C[3 * i + 2] * dX[2];
+      for (int step = S - 2; step >= 0; --step) {
+        double pw[3];
+        UNROLL for (int i = 0; i < 3; i++) pw[i] = __shfl_down(w[i], 1);
+        if (k == step) {
+          UNROLL for (int i = 0; i < 3; i++) dX[i] = v[i] - pw[i];
+          UNROLL for (int i = 0; i < 3; i++) w[i] = C[3 * i] * dX[0] + C[3 * i + 1] * dX[1] + C[3 * i + 2] * dX[2];
+        }
+      }
+      // directions in the rows
+      double dXp[3], dc[6], Gdc[18];
+      UNROLL for (int i = 0; i < 3; i++) { const double vv = __shfl_up(dX[i], 1); dXp[i] = first ? 0.0 : vv; }
+      U_apply(nm, dXp, dc[0], dc[1], dc[2]);
+      V_apply(nm, dX, dc[3], dc[4], dc[5]);
+      G_apply(dc, t, Gdc);
+      // step to the boundary: max over rows of -d/v kept as a fraction (no divisions)
+      double pn = 0.0, pd = 1.0, dn = 0.0, dd = 1.0;  // primal ratio pn/pd, dual ratio dn/dd
+      double mua_part = 0.0;
+      double dsl_[18], dsu_[18], dll_[18], dlu_[18];
+      UNROLL for (int r = 0; r < 18; r++) {
+        const double rpl = Gc[r] - sl[r] - LO(r), rpu = Gc[r] + su[r] - UP(r);
+        double rcl = sl[r] * ll[r], rcu = su[r] * lu[r];
+        if (pass == 1) {
+          const double dsl = Gdc_aff[r] + rpl, dsu = -Gdc_aff[r] - rpu;
+          const double dll = -ll[r] - ll[r] * dsl * isl[r], dlu = -lu[r] - lu[r] * dsu * isu[r];
+          rcl += dsl * dll - sigma_mu; rcu += dsu * dlu - sigma_mu;
+        }
+        const double dsl = Gdc[r] + rpl, dsu = -Gdc[r] - rpu;
+        const double dll = (-rcl - ll[r] * dsl) * isl[r], dlu = (-rcu - lu[r] * dsu) * isu[r];
+        dsl_[r] = dsl; dsu_[r] = dsu; dll_[r] = dll; dlu_[r] = dlu;
+        // ratio = -d/v ; keep the largest (v > 0)
+        if (-dsl * pd > pn * sl[r]) { pn = -dsl; pd = sl[r]; }
+        if (-dsu * pd > pn * su[r]) { pn = -dsu; pd = su[r]; }
+        if (-dll * dd > dn * ll[r]) { dn = -dll; dd = ll[r]; }
+        if (-dlu * dd > dn * lu[r]) { dn = -dlu; dd = lu[r]; }
+      }
+      const double pr_ratio = pn / pd, du_ratio = dn / dd;  // step = 1/max(ratio,1)
+      Red4 ra = group_reduce(red, lane, gbase, S, 0.0, pr_ratio, du_ratio, 0.0);
+      const double ap = 1.0 / fmax(ra.b, 1.0), ad = 1.0 / fmax(ra.c, 1.0);
+      if (pass == 0) {
+        UNROLL for (int r = 0; r < 18; r++) {
+          mua_part += (sl[r] + ap * dsl_[r]) * (ll[r] + ad * dll_[r]) + (su[r] + ap * dsu_[r]) * (lu[r] + ad * dlu_[r]);
+          Gdc_aff[r] = Gdc[r];
+        }
+        Red4 rm = group_reduce(red, lane, gbase, S, mua_part, 0.0, 0.0, 0.0);
+        const double mua = rm.a * inv_m;
+        const double sr = mua / mu;
+        sigma_mu = sr * sr * sr * mu;
+      } else {
+        alpha = fmin(1.0, 0.995 * fmin(ap, ad));
+        if (done) alpha = 0.0;
+        UNROLL for (int i = 0; i < 3; i++) X[i] += alpha * dX[i];
+        UNROLL for (int r = 0; r < 18; r++) {
+          sl[r] += alpha * dsl_[r]; su[r] += alpha * dsu_[r];
+          ll[r] += alpha * dll_[r]; lu[r] += alpha * dlu_[r];
+        }
+      }
+    }
+  }
+
+  // ---------------- write back: control points, per-axis objective/status ------------------
+  {
+    double Xp[3], c[6];
+    UNROLL for (int i = 0; i < 3; i++) { const double v = __shfl_up(Xb[i], 1); Xp[i] = first ? Xinit[i] : v; }
+    U_apply(nm, Xp, c[0], c[1], c[2]);
+    V_apply(nm, Xb, c[3], c[4], c[5]);
+    double obj = 0.0;
+    UNROLL for (int i = 0; i < 6; i++) {
+      double s = 0.0;
+      UNROLL for (int j = 0; j < 6; j++) s += (i <= j ? Psm[SYM(i, j)][lane] : Psm[SYM(j, i)][lane]) * c[j];
+      obj += c[i] * (0.5 * s + q[i]);
+    }
+    Red4 ro = group_reduce(red, lane, gbase, S, obj, 0.0, 0.0, 0.0);
+    if (valid) {
+      double *dst = a.ctrl + (size_t)b * 12 * S + (size_t)axis * 6 * S + (size_t)k * 6;
+      UNROLL for (int i = 0; i < 6; i++) dst[i] = c[i];
+      if (first) {
+        int st;
+        if (infeasible_bounds) st = BTRAPZ_PRIMAL_INFEASIBLE;
+        else if (best_score < 1e-7) st = BTRAPZ_SOLVED;
+        else if (best_score < 1e-5) st = BTRAPZ_SOLVED_INACCURATE;
+        else st = BTRAPZ_MAX_ITER_REACHED;
+        a.axis_obj[prob] = ro.a;
+        a.axis_status[prob] = st;
+        a.axis_iters[prob] = iters;
+      }
+    }
+  }
+}
+
+// ---- per-candidate cost/status from the two axis problems (acceptance: solve_3d.cc:1251-1277)
+__global__ void finalize_kernel(int B, const double *axis_obj, const int *axis_status, const int *axis_iters,
+                                double *cost, int *status, int *iters) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int s0 = axis_status[2 * b], s1 = axis_status[2 * b + 1];
+  int st;
+  if (s0 == BTRAPZ_SOLVED && s1 == BTRAPZ_SOLVED) st = BTRAPZ_SOLVED;
+  else if (s0 > 0 && s1 > 0) st = BTRAPZ_SOLVED_INACCURATE;
+  else st = s0 < s1 ? s0 : s1;  // most severe failure code
+  const double c = axis_obj[2 * b] + axis_obj[2 * b + 1];
+  status[b] = st;
+  cost[b] = (st > 0 && c == c) ? c : __builtin_huge_val();
+  if (iters) iters[b] = axis_iters[2 * b] > axis_iters[2 * b + 1] ? axis_iters[2 * b] : axis_iters[2 * b + 1];
+}
+
+// ---- arg-min over contiguous groups: one block per group, ties -> lowest index -------------
+__global__ __launch_bounds__(256) void argmin_kernel(int group, long long index_base, const double *cost,
+                                                      long long *best_idx, double *best_cost) {
+  __shared__ double sc[256];
+  __shared__ long long si[256];
+  const long long g = blockIdx.x;
+  double bc = __builtin_huge_val();
+  long long bi = -1;
+  for (int j = threadIdx.x; j < group; j += blockDim.x) {
+    const double c = cost[g * group + j];
+    if (c < bc) { bc = c; bi = g * group + j; }
+  }
+  sc[threadIdx.x] = bc; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double c2 = sc[threadIdx.x + s]; const long long i2 = si[threadIdx.x + s];
+      const double c1 = sc[threadIdx.x]; const long long i1 = si[threadIdx.x];
+      if (c2 < c1 || (c2 == c1 && i2 >= 0 && (i1 < 0 || i2 < i1))) { sc[threadIdx.x] = c2; si[threadIdx.x] = i2; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    best_idx[g] = si[0] >= 0 ? si[0] + index_base : -1;
+    best_cost[g] = sc[0];
+  }
+}
+
+// ---- Bernstein sampling of selected candidates (solve_3d.cc:1279-1392) ---------------------
+// one block per selected candidate; thread = sample point.
+__global__ void sample_kernel(int B, int S, double delta, const double *seg, const double *init, const double *ctrl,
+                              int nsel, const long long *sel, int max_points, double *out, int *npoints) {
+  const int j = blockIdx.x;
+  if (j >= nsel) return;
+  const long long b = sel[j];
+  double *o = out + (size_t)j * 6 * max_points;
+  if (b < 0 || b >= B) { if (threadIdx.x == 0) npoints[j] = 0; return; }
+  const size_t BS = (size_t)B * S;
+  // num_of_points_: int accumulated with += double (solve_3d.cc:1279-1282)
+  int np = 1;
+  for (int k = 0; k < S; k++) np = (int)((double)np + seg[BTRAPZ_F_T * BS + b * S + k] / delta);
+  if (threadIdx.x == 0) npoints[j] = np;
+  if (threadIdx.x == 0 && max_points > 0) {
+    UNROLL for (int a = 0; a < 6; a++) o[(size_t)a * max_points] = init[b * 6 + a];
+  }
+  const double bc0[6] = {1, 5, 10, 10, 5, 1}, bc1[5] = {1, 4, 6, 4, 1}, bc2[4] = {1, 3, 3, 1};
+  int base = 1;
+  for (int k = 0; k < S; k++) {
+    const double t = seg[BTRAPZ_F_T * BS + b * S + k];
+    const int linter = (int)(t / delta);  // :1351
+    for (int l = 1 + (int)threadIdx.x; l <= linter; l += blockDim.x) {
+      const int vi = base + l - 1;
+      if (vi >= max_points) continue;
+      const double tau = (double)l / (double)linter, om = 1.0 - tau;
+      double pw[6], qw[6];
+      pw[0] = 1.0; qw[0] = 1.0;
+      UNROLL for (int i = 1; i < 6; i++) { pw[i] = pw[i - 1] * tau; qw[i] = qw[i - 1] * om; }
+      UNROLL for (int ax = 0; ax < 2; ax++) {
+        const double *c = ctrl + (size_t)b * 12 * S + (size_t)ax * 6 * S + (size_t)k * 6;
+        double x = 0, dx = 0, ddx = 0;
+        UNROLL for (int i = 0; i < 6; i++) x += c[i] * bc0[i] * pw[i] * qw[5 - i];
+        UNROLL for (int i = 0; i < 5; i++) dx += 5.0 * (c[i + 1] - c[i]) * bc1[i] * pw[i] * qw[4 - i];
+        UNROLL for (int i = 0; i < 4; i++) ddx += 20.0 * (c[i + 2] - 2.0 * c[i + 1] + c[i]) * bc2[i] * pw[i] * qw[3 - i];
+        o[(size_t)(3 * ax + 0) * max_points + vi] = x * t;
+        o[(size_t)(3 * ax + 1) * max_points + vi] = dx;
+        o[(size_t)(3 * ax + 2) * max_points + vi] = ddx / t;
+      }
+    }
+    base += linter;
+  }
+}
+
+}  // namespace btrapz

@@ -1,0 +1,218 @@
+// find_traj.hip -- the reference's C-ABI driver, re-hosted on the HIP path.
+//
+// Replaces src/trp_wrapper.cpp:20-305 (trapezoid) and src/cub_wrapper.cpp:20-283 (cuboid):
+// parse the corridor text file, extract/select the corridor segments on the host, solve the
+// QP on the GPU through the batched entry point (B = 1), sample the trajectory on the GPU,
+// compute the scalar cost the Python harness receives and write the trajectory file.
+// There is no CPU solve: without a HIP device the call returns the failure sentinel 1e11
+// (and says why on stderr), exactly what the harness treats as "optimizer failed".
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "btrapz_device.h"
+#include "corridor.hpp"
+
+using namespace btrapz;
+
+namespace {
+
+// Paths compiled into the reference's libraries (trp_wrapper.cpp:23,288 ; cub_wrapper.cpp:22,268 ;
+// the older libbtrapz.so passes its own pair, see shim_btrapz.c).  Kept as defaults so the harness drops in unchanged.
+const char *kDefaultInput[2] = {"/home/srujan_d/RISS/code/btrapz/src/c_road_s1_2.txt",
+                                "/home/srujan_d/RISS/code/btrapz/src/c_road_s1_3.txt"};
+const char *kDefaultOutputPrefix[2] = {"/home/srujan_d/RISS/code/btrapz/src/s1_slt_3d_",
+                                       "/home/srujan_d/RISS/code/btrapz/src/s1_cub_3d_"};
+
+std::mutex g_ctx_mutex;
+btrapz_ctx *g_ctx = nullptr;
+
+btrapz_ctx *shared_ctx() {
+  std::lock_guard<std::mutex> lk(g_ctx_mutex);
+  if (!g_ctx) {
+    const char *dev = getenv("BTRAPZ_DEVICE");
+    if (btrapz_create(&g_ctx, dev ? atoi(dev) : 0) != BTRAPZ_OK) g_ctx = nullptr;
+  }
+  return g_ctx;
+}
+
+bool verbose() { const char *v = getenv("BTRAPZ_VERBOSE"); return v && *v && *v != '0'; }
+
+int clampi(int i, int hi) { return i < 0 ? 0 : (i > hi ? hi : i); }
+
+struct DeviceBuf {
+  void *p = nullptr;
+  ~DeviceBuf() { if (p) (void)hipFree(p); }
+  bool alloc(size_t bytes) { return hipMalloc(&p, bytes) == hipSuccess; }
+  template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+// a_cost of trp_wrapper.cpp:207-286 / cub_wrapper.cpp:201-262.  Reads of x_ref[i] past N
+// and of l[N-1] past the sampled length (undefined in the reference) are clamped.
+double trajectory_cost(int variant, const Params &p, const TrajInput &in, int np, const double *s, const double *ds,
+                       const double *dds, const double *l, const double *dl, const double *ddl) {
+  const double dt = in.delta;
+  const int N = in.N;
+  double s_cost = 0.0, l_cost = 0.0, max_a = 0.0;
+  for (int i = 0; i < np; ++i) {
+    const double jerk = (i == 0) ? (dds[np > 1 ? 1 : 0] - dds[0]) / dt : (dds[i] - dds[i - 1]) / dt;
+    const double e = s[i] - in.s_ref[clampi(i, N - 1)];
+    if (variant == BTRAPZ_TRAPEZOID) {
+      s_cost += p.weight_s_ref * e * e * dt;
+      s_cost += p.weight_ds_ref * ds[i] * ds[i] * dt;
+      s_cost += p.s_acc_weight * dds[i] * dds[i] * dt;
+      s_cost += p.s_jerk_weight * jerk * jerk * dt;
+    } else {
+      s_cost += e * e * dt;
+      s_cost += ds[i] * ds[i] * dt;
+      s_cost += dds[i] * dds[i] * dds[i] * dds[i] * dt;
+      s_cost += jerk * jerk * jerk * jerk * dt;
+    }
+    max_a = std::fmax(max_a, std::fabs(dds[i]));
+  }
+  if (variant == BTRAPZ_CUBOID) s_cost += max_a * max_a * max_a * max_a;
+  max_a = 0.0;
+  for (int i = 0; i < np; ++i) {
+    const double jerk = (i == 0) ? (ddl[np > 1 ? 1 : 0] - ddl[0]) / dt : (ddl[i] - ddl[i - 1]) / dt;
+    const double e = l[i] - in.l_ref[clampi(i, N - 1)];
+    if (variant == BTRAPZ_TRAPEZOID) {
+      l_cost += p.weight_l_ref * e * e * dt;
+      l_cost += p.weight_dl_ref * dl[i] * dl[i] * dt;
+      l_cost += p.l_acc_weight * ddl[i] * ddl[i] * dt;
+      l_cost += p.l_jerk_weight * jerk * jerk * dt;
+    } else {
+      l_cost += e * e * dt;
+      l_cost += dl[i] * dl[i] * dt;
+      l_cost += ddl[i] * ddl[i] * dt;
+      l_cost += jerk * jerk * dt;
+    }
+    max_a = std::fmax(max_a, std::fabs(ddl[i]));
+  }
+  if (variant == BTRAPZ_TRAPEZOID) {
+    const double e = l[clampi(N - 1, np - 1)] - in.l_ref[N - 1];
+    l_cost += p.weight_end_l * e * e * dt;
+  } else {
+    l_cost += max_a * max_a;
+  }
+  return s_cost + l_cost;
+}
+
+}  // namespace
+
+extern "C" double btrapz_find_traj(int variant, const char *input_path, const char *output_path, const Params *p) {
+  const double FAIL = BTRAPZ_FAIL_SENTINEL;
+  if (!p || variant < 0 || variant > 1) return FAIL;
+  std::string in_path = input_path ? input_path : "";
+  if (in_path.empty()) { const char *e = getenv("BTRAPZ_INPUT"); in_path = e ? e : kDefaultInput[variant]; }
+  std::string out_path = output_path ? output_path : "";
+  if (out_path.empty()) {
+    const char *e = getenv("BTRAPZ_OUTPUT_PREFIX");
+    out_path = std::string(e ? e : kDefaultOutputPrefix[variant]) + std::to_string(p->iteration) + ".txt";
+  }
+
+  TrajInput in;
+  if (!read_traj_input(in_path, in)) {
+    fprintf(stderr, "btrapz: cannot read corridor file '%s'\n", in_path.c_str());
+    return FAIL;
+  }
+  // corridor stage (host): trp_wrapper.cpp:176-188
+  std::vector<std::vector<Segment>> lists;
+  for (int o = 0; o < in.num_obs; o++) lists.push_back(extract_segments(variant, in.N, in.delta, in.s_bounds[o], in.l_bounds[o]));
+  std::vector<Segment> seg;
+  if (!select_segments(variant, in.delta, lists, in.s_ref, in.l_ref, seg)) return FAIL;
+  const int S = (int)seg.size();
+  if (S < 1 || S > BTRAPZ_MAX_SEGMENTS) { fprintf(stderr, "btrapz: %d segments not supported (1..%d)\n", S, BTRAPZ_MAX_SEGMENTS); return FAIL; }
+  for (const Segment &c : seg) if (!(c.t > 0)) return FAIL;
+
+  // batch record, B = 1 (layout: include/btrapz_hip.h)
+  const int N = in.N;
+  std::vector<double> h_seg((size_t)BTRAPZ_NUM_SEG_FIELDS * S), h_init(6), h_ref_end(2), h_dl(10);
+  auto F = [&](int f, int k) -> double & { return h_seg[(size_t)f * S + k]; };
+  for (int k = 0; k < S; k++) {
+    const Segment &c = seg[k];
+    F(BTRAPZ_F_T, k) = c.t;
+    F(BTRAPZ_F_DOWN_BIAS, k) = c.down_bias; F(BTRAPZ_F_DOWN_SKEW, k) = c.down_skew;
+    F(BTRAPZ_F_UPP_BIAS, k) = c.upp_bias; F(BTRAPZ_F_UPP_SKEW, k) = c.upp_skew;
+    F(BTRAPZ_F_L_DOWN_BIAS, k) = c.l_down_bias; F(BTRAPZ_F_L_DOWN_SKEW, k) = c.l_down_skew;
+    F(BTRAPZ_F_L_UPP_BIAS, k) = c.l_upp_bias; F(BTRAPZ_F_L_UPP_SKEW, k) = c.l_upp_skew;
+    F(BTRAPZ_F_BEG_L, k) = c.beg_l; F(BTRAPZ_F_END_L, k) = c.end_l;
+    double lo = 0.0, hi = 1000.0;  // solve_3d.cc:835-841
+    for (int i = c.beg_t; i <= c.end_t; i++) {
+      lo = std::fmax(in.ds_bounds[clampi(i, N - 1)].first, lo);
+      hi = std::fmin(in.ds_bounds[clampi(i, N - 1)].second, hi);
+    }
+    F(BTRAPZ_F_DS_LO, k) = lo; F(BTRAPZ_F_DS_HI, k) = hi;
+    const int i0 = clampi(10 * k, N - 1), i1 = clampi(10 * k + 1, N - 1);  // solve_3d.cc:1161-1165 (clamped)
+    F(BTRAPZ_F_X_SKEW, k) = (in.s_ref[i1] - in.s_ref[i0]) / in.delta; F(BTRAPZ_F_X_BIAS, k) = in.s_ref[i0];
+    F(BTRAPZ_F_Y_SKEW, k) = (in.l_ref[i1] - in.l_ref[i0]) / in.delta; F(BTRAPZ_F_Y_BIAS, k) = in.l_ref[i0];
+  }
+  for (int i = 0; i < 3; i++) { h_init[i] = in.init_s[i]; h_init[3 + i] = in.init_l[i]; }
+  h_ref_end[0] = in.s_ref[N - 1]; h_ref_end[1] = in.l_ref[N - 1];
+  for (int i = 0; i < 5; i++) { h_dl[2 * i] = in.dl_bounds[clampi(i, N - 1)].first; h_dl[2 * i + 1] = in.dl_bounds[clampi(i, N - 1)].second; }
+
+  btrapz_shared sh = {};
+  sh.w_s[0] = p->weight_s_ref; sh.w_s[1] = p->weight_ds_ref; sh.w_s[2] = p->s_acc_weight; sh.w_s[3] = p->s_jerk_weight;
+  sh.w_l[0] = p->weight_l_ref; sh.w_l[1] = p->weight_dl_ref; sh.w_l[2] = p->l_acc_weight; sh.w_l[3] = p->l_jerk_weight;
+  sh.weight_end_s = p->weight_end_s; sh.weight_end_l = p->weight_end_l;
+  sh.ds_ref = in.ds_ref; sh.dl_ref = in.dl_ref;
+  for (int i = 0; i < 2; i++) { sh.dds[i] = in.dds[i]; sh.ddds[i] = in.ddds[i]; sh.ddl[i] = in.ddl[i]; sh.dddl[i] = in.dddl[i]; }
+  sh.delta = in.delta; sh.variant = variant;
+
+  btrapz_ctx *ctx = shared_ctx();
+  if (!ctx) { fprintf(stderr, "btrapz: no HIP device available (this library has no CPU path)\n"); return FAIL; }
+
+  // expected sample count and the reference's CHECK_EQ(var_index, num_of_points_) (solve_3d.cc:1407)
+  int np_expected = 1, var_index = 1;
+  for (const Segment &c : seg) { np_expected = (int)((double)np_expected + c.t / in.delta); var_index += (int)(c.t / in.delta); }
+  if (np_expected != var_index || np_expected < 1) return FAIL;
+  const int max_points = np_expected;
+
+  DeviceBuf d_seg, d_init, d_re, d_dl, d_ctrl, d_cost, d_status, d_sel, d_out, d_np;
+  if (!d_seg.alloc(h_seg.size() * 8) || !d_init.alloc(48) || !d_re.alloc(16) || !d_dl.alloc(80) ||
+      !d_ctrl.alloc((size_t)12 * S * 8) || !d_cost.alloc(8) || !d_status.alloc(8) || !d_sel.alloc(8) ||
+      !d_out.alloc((size_t)6 * max_points * 8) || !d_np.alloc(4)) return FAIL;
+  const long long sel0 = 0;
+  if (hipMemcpy(d_seg.p, h_seg.data(), h_seg.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_init.p, h_init.data(), 48, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_re.p, h_ref_end.data(), 16, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_dl.p, h_dl.data(), 80, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_sel.p, &sel0, 8, hipMemcpyHostToDevice) != hipSuccess) return FAIL;
+  if (btrapz_solve_batch_device(ctx, &sh, nullptr, 1, S, d_seg.as<double>(), d_init.as<double>(), d_re.as<double>(),
+                                d_dl.as<double>(), d_ctrl.as<double>(), d_cost.as<double>(), d_status.as<int>(),
+                                d_status.as<int>() + 1, nullptr) != BTRAPZ_OK ||
+      btrapz_sample_device(ctx, 1, S, in.delta, d_seg.as<double>(), d_init.as<double>(), d_ctrl.as<double>(), 1,
+                           d_sel.as<long long>(), max_points, d_out.as<double>(), d_np.as<int>(), nullptr) != BTRAPZ_OK) {
+    fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
+    return FAIL;
+  }
+  int h_status[2] = {0, 0}, h_np = 0;
+  double h_cost = 0.0;
+  std::vector<double> out((size_t)6 * max_points);
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h_status, d_status.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(&h_cost, d_cost.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(&h_np, d_np.p, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(out.data(), d_out.p, out.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return FAIL;
+  if (verbose()) fprintf(stderr, "btrapz: S=%d status=%d iters=%d obj=%.9g\n", S, h_status[0], h_status[1], h_cost);
+  // acceptance: solve_3d.cc:1251-1277
+  if (h_status[0] != BTRAPZ_SOLVED && h_status[0] != BTRAPZ_SOLVED_INACCURATE) return FAIL;
+  if (h_np != max_points) return FAIL;
+
+  const double *s = &out[0], *ds = &out[(size_t)max_points], *dds = &out[(size_t)2 * max_points];
+  const double *l = &out[(size_t)3 * max_points], *dl = &out[(size_t)4 * max_points], *ddl = &out[(size_t)5 * max_points];
+  const double cost = trajectory_cost(variant, *p, in, max_points, s, ds, dds, l, dl, ddl);
+
+  // trajectory file: trp_wrapper.cpp:288-301 (fixed, 3 decimals)
+  if (FILE *f = fopen(out_path.c_str(), "w")) {
+    for (int i = 0; i < max_points; i++)
+      fprintf(f, "%.3f %.3f %.3f %.3f %.3f %.3f %.3f\n", i * in.delta, s[i], l[i], ds[i], dl[i], dds[i], ddl[i]);
+    fclose(f);
+  } else if (verbose()) {
+    fprintf(stderr, "btrapz: cannot write '%s'\n", out_path.c_str());
+  }
+  return cost;
+}

@@ -1,0 +1,166 @@
+"""ctypes binding of libbtrapz_hip.so (include/btrapz_hip.h).
+
+The library is the product; this module only marshals pointers.  There is no CPU or
+PyTorch fallback: if the HIP library is missing, or no HIP device is visible, every
+solve raises."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import layout as L
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(LIB_DIR, "libbtrapz_hip.so")
+
+
+class BtrapzError(RuntimeError):
+    pass
+
+
+class CShared(C.Structure):
+    _fields_ = [("w_s", C.c_double * 4), ("w_l", C.c_double * 4),
+                ("weight_end_s", C.c_double), ("weight_end_l", C.c_double),
+                ("ds_ref", C.c_double), ("dl_ref", C.c_double),
+                ("dds", C.c_double * 2), ("ddds", C.c_double * 2),
+                ("ddl", C.c_double * 2), ("dddl", C.c_double * 2),
+                ("delta", C.c_double), ("variant", C.c_int), ("reserved", C.c_int)]
+
+    @classmethod
+    def from_shared(cls, sh):
+        s = cls()
+        s.w_s[:] = sh.w_s; s.w_l[:] = sh.w_l
+        s.weight_end_s, s.weight_end_l = sh.weight_end_s, sh.weight_end_l
+        s.ds_ref, s.dl_ref = sh.ds_ref, sh.dl_ref
+        s.dds[:] = sh.dds; s.ddds[:] = sh.ddds; s.ddl[:] = sh.ddl; s.dddl[:] = sh.dddl
+        s.delta, s.variant = sh.delta, sh.variant
+        return s
+
+
+class COptions(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("eps", C.c_double)]
+
+
+class CParams(C.Structure):
+    """include/btrapz/py_cpp_.h:6-21 == trp_wrapper.py:19-32."""
+    _fields_ = [("s_acc_weight", C.c_double), ("s_jerk_weight", C.c_double),
+                ("l_acc_weight", C.c_double), ("l_jerk_weight", C.c_double),
+                ("weight_s_ref", C.c_double), ("weight_ds_ref", C.c_double),
+                ("weight_l_ref", C.c_double), ("weight_dl_ref", C.c_double),
+                ("weight_end_s", C.c_double), ("weight_end_l", C.c_double),
+                ("iteration", C.c_int)]
+
+
+EXPORTS = ("btrapz_find_traj", "btrapz_create", "btrapz_destroy", "btrapz_last_error",
+           "btrapz_device_count", "btrapz_solve_batch_device", "btrapz_argmin_device",
+           "btrapz_sample_device", "btrapz_solve_batch_host")
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC_DIR, "all"], stdout=out)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BtrapzError("HIP library %s is missing: run spectral_amd.native.build() "
+                              "(there is no CPU path)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        vp, dp, ip, llp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+        l.btrapz_find_traj.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.POINTER(CParams)]
+        l.btrapz_find_traj.restype = C.c_double
+        l.btrapz_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        l.btrapz_destroy.argtypes = [C.c_void_p]
+        l.btrapz_last_error.argtypes = [C.c_void_p]; l.btrapz_last_error.restype = C.c_char_p
+        l.btrapz_device_count.restype = C.c_int
+        l.btrapz_solve_batch_device.argtypes = [vp, C.POINTER(CShared), C.POINTER(COptions), C.c_int, C.c_int,
+                                                dp, dp, dp, dp, dp, dp, ip, ip, vp]
+        l.btrapz_argmin_device.argtypes = [vp, C.c_int, C.c_int, C.c_longlong, dp, llp, dp, vp]
+        l.btrapz_sample_device.argtypes = [vp, C.c_int, C.c_int, C.c_double, dp, dp, dp, C.c_int, llp, C.c_int,
+                                           dp, ip, vp]
+        l.btrapz_solve_batch_host.argtypes = [vp, C.POINTER(CShared), C.POINTER(COptions), C.c_int, C.c_int,
+                                              dp, dp, dp, dp, dp, dp, ip, ip]
+        _lib = l
+    return _lib
+
+
+class Context:
+    """Owns a btrapz_ctx on one HIP device."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().btrapz_create(C.byref(self._h), int(device))
+        if rc != 0:
+            raise BtrapzError("btrapz_create(device=%d) failed with %d: no HIP device "
+                              "(this library has no CPU path)" % (device, rc))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().btrapz_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise BtrapzError("%s failed (%d): %s" % (what, rc, lib().btrapz_last_error(self._h).decode()))
+
+    # ---- host-pointer path (numpy in, numpy out) ------------------------------------------
+    def solve_host(self, batch, shared, max_iter=0, eps=0.0):
+        B, S = batch.B, batch.S
+        seg = np.ascontiguousarray(batch.seg, dtype=np.float64)
+        init = np.ascontiguousarray(batch.init, dtype=np.float64)
+        ref_end = np.ascontiguousarray(batch.ref_end, dtype=np.float64)
+        dlb = np.ascontiguousarray(batch.dl_bounds, dtype=np.float64)
+        assert seg.shape == (L.NUM_SEG_FIELDS, B, S)
+        ctrl = np.empty((B, 12 * S)); cost = np.empty(B)
+        status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32)
+        sh = CShared.from_shared(shared); opt = COptions(int(max_iter), float(eps))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(lib().btrapz_solve_batch_host(self._h, C.byref(sh), C.byref(opt), B, S, p(seg), p(init),
+                                                  p(ref_end), p(dlb), p(ctrl), p(cost), p(status), p(iters)),
+                    "btrapz_solve_batch_host")
+        return ctrl, cost, status, iters
+
+    # ---- device-pointer path (torch tensors only carry the memory) --------------------------
+    def solve_device(self, B, S, shared, seg, init, ref_end, dl_bounds, ctrl, cost, status, iters=None,
+                     stream=None, max_iter=0, eps=0.0):
+        sh = CShared.from_shared(shared); opt = COptions(int(max_iter), float(eps))
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self._check(lib().btrapz_solve_batch_device(self._h, C.byref(sh), C.byref(opt), B, S, ptr(seg), ptr(init),
+                                                    ptr(ref_end), ptr(dl_bounds), ptr(ctrl), ptr(cost),
+                                                    ptr(status), ptr(iters), C.c_void_p(stream or 0)),
+                    "btrapz_solve_batch_device")
+
+    def argmin_device(self, B, group, index_base, cost, best_idx, best_cost, stream=None):
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        self._check(lib().btrapz_argmin_device(self._h, B, group, int(index_base), ptr(cost), ptr(best_idx),
+                                               ptr(best_cost), C.c_void_p(stream or 0)), "btrapz_argmin_device")
+
+    def sample_device(self, B, S, delta, seg, init, ctrl, sel, max_points, out, npoints, stream=None):
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        self._check(lib().btrapz_sample_device(self._h, B, S, float(delta), ptr(seg), ptr(init), ptr(ctrl),
+                                               int(sel.numel()), ptr(sel), int(max_points), ptr(out), ptr(npoints),
+                                               C.c_void_p(stream or 0)), "btrapz_sample_device")
+
+
+def find_traj_native(variant, params, input_path=None, output_path=None):
+    """btrapz_find_traj(): the reference's find_traj with explicit paths."""
+    cp = params if isinstance(params, CParams) else CParams(*params)
+    enc = lambda s: os.fsencode(s) if s else None
+    return lib().btrapz_find_traj(int(variant), enc(input_path), enc(output_path), C.byref(cp))
