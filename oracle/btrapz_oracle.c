@@ -1458,3 +1458,61 @@ fin:
   free(iseq); free(rowpos);
   return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Batch-record entry point: the same candidates the product's batched C-ABI  */
+/* takes (layout of include/btrapz_hip.h: seg[f][b][k], init[b][6],           */
+/* ref_end[b][2], dl_bounds[b][10], shared[21]) solved one by one by the       */
+/* reference's algorithm: orc_assemble (general CSC) + orc_osqp_solve.  Used   */
+/* as the CPU baseline of bench.py and by batch parity tests.  shared[] =      */
+/* w_s[4] w_l[4] weight_end_s weight_end_l ds_ref dl_ref dds[2] ddds[2] ddl[2]  */
+/* dddl[2] delta.  exact != 0 -> orc_ipm_solve (x*) instead of the ADMM.       */
+/* ------------------------------------------------------------------------ */
+int orc_batch_solve(int variant, int B, int S, const double *seg, const double *init, const double *ref_end,
+                    const double *dl_bounds, const double *shared, const orc_settings *settings, int exact,
+                    int b0, int b1, double *ctrl, double *obj, int *status, int *iters) {
+  enum { F_T = 0, F_DOWN_BIAS, F_DOWN_SKEW, F_UPP_BIAS, F_UPP_SKEW, F_L_DOWN_BIAS, F_L_DOWN_SKEW, F_L_UPP_BIAS,
+         F_L_UPP_SKEW, F_BEG_L, F_END_L, F_DS_LO, F_DS_HI, F_X_SKEW, F_X_BIAS, F_Y_SKEW, F_Y_BIAS };
+  if (S < 1 || S > 64 || b0 < 0 || b1 > B) return -1;
+  const int N = 10 * S + 1;
+  const size_t BS = (size_t)B * S;
+  const double delta = shared[20];
+  double *x_ref = (double *)calloc(N, sizeof(double)), *y_ref = (double *)calloc(N, sizeof(double));
+  double *dxb = (double *)malloc(sizeof(double) * 2 * N), *dyb = (double *)malloc(sizeof(double) * 2 * N);
+  orc_cube *cubes = (orc_cube *)malloc(sizeof(orc_cube) * S);
+  double *x = (double *)malloc(sizeof(double) * 12 * S);
+  orc_settings sdef; if (!settings) { orc_settings_reference(&sdef); settings = &sdef; }
+  for (int b = b0; b < b1; b++) {
+#define SEG(f, k) seg[(size_t)(f) * BS + (size_t)b * S + (k)]
+    for (int i = 0; i < N; i++) { x_ref[i] = 0; y_ref[i] = 0; dxb[2 * i] = -1e10; dxb[2 * i + 1] = 1e10; dyb[2 * i] = -1e10; dyb[2 * i + 1] = 1e10; }
+    for (int k = 0; k < S; k++) {
+      orc_cube *c = &cubes[k]; cube_default(c);
+      c->beg_t = 10 * k; c->end_t = 10 * k + 10; c->t = SEG(F_T, k);
+      c->beg_l = SEG(F_BEG_L, k); c->end_l = SEG(F_END_L, k);
+      c->upp_skew = SEG(F_UPP_SKEW, k); c->upp_bias = SEG(F_UPP_BIAS, k);
+      c->down_skew = SEG(F_DOWN_SKEW, k); c->down_bias = SEG(F_DOWN_BIAS, k);
+      c->l_upp_skew = SEG(F_L_UPP_SKEW, k); c->l_upp_bias = SEG(F_L_UPP_BIAS, k);
+      c->l_down_skew = SEG(F_L_DOWN_SKEW, k); c->l_down_bias = SEG(F_L_DOWN_BIAS, k);
+      x_ref[10 * k] = SEG(F_X_BIAS, k); x_ref[10 * k + 1] = SEG(F_X_BIAS, k) + SEG(F_X_SKEW, k) * delta;
+      y_ref[10 * k] = SEG(F_Y_BIAS, k); y_ref[10 * k + 1] = SEG(F_Y_BIAS, k) + SEG(F_Y_SKEW, k) * delta;
+      for (int i = 10 * k + 1; i < 10 * k + 10; i++) { dxb[2 * i] = SEG(F_DS_LO, k); dxb[2 * i + 1] = SEG(F_DS_HI, k); }
+    }
+    x_ref[N - 1] = ref_end[2 * b]; y_ref[N - 1] = ref_end[2 * b + 1];
+    for (int i = 0; i < 5 && i < N; i++) { dyb[2 * i] = dl_bounds[10 * b + 2 * i]; dyb[2 * i + 1] = dl_bounds[10 * b + 2 * i + 1]; }
+    orc_qp_params pp; memset(&pp, 0, sizeof(pp));
+    memcpy(pp.w_s, shared, sizeof(double) * 4); memcpy(pp.w_l, shared + 4, sizeof(double) * 4);
+    pp.weight_end_s = shared[8]; pp.weight_end_l = shared[9]; pp.ds_ref = shared[10]; pp.dl_ref = shared[11];
+    memcpy(pp.dds, shared + 12, 16); memcpy(pp.ddds, shared + 14, 16); memcpy(pp.ddl, shared + 16, 16); memcpy(pp.dddl, shared + 18, 16);
+    memcpy(pp.init_s, init + 6 * b, 24); memcpy(pp.init_l, init + 6 * b + 3, 24);
+    pp.N = N; pp.delta = delta; pp.dx_bounds = dxb; pp.dy_bounds = dyb; pp.x_ref = x_ref; pp.y_ref = y_ref;
+    orc_qp qp; orc_info info; memset(&info, 0, sizeof(info));
+    if (orc_assemble(variant, S, cubes, &pp, &qp) != 0) { status[b] = -10; obj[b] = 0; if (iters) iters[b] = 0; orc_qp_free(&qp); continue; }
+    if (exact) orc_ipm_solve(&qp, 1e-9, 80, x, NULL, &info); else orc_osqp_solve(&qp, settings, x, NULL, &info);
+    memcpy(ctrl + (size_t)b * 12 * S, x, sizeof(double) * 12 * S);
+    obj[b] = info.obj_val; status[b] = info.status; if (iters) iters[b] = info.iter;
+    orc_qp_free(&qp);
+#undef SEG
+  }
+  free(x_ref); free(y_ref); free(dxb); free(dyb); free(cubes); free(x);
+  return 0;
+}

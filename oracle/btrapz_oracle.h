@@ -173,6 +173,14 @@ double orc_find_traj(int variant, const char *input_path,
                      const orc_settings *settings, int *S_out, double *ctrl_out,
                      orc_cube *corridor_out, orc_info *info_out);
 
+/* Candidates [b0,b1) of a batch record (layout of include/btrapz_hip.h) solved one by
+ * one: orc_assemble + orc_osqp_solve (exact=0, the reference's algorithm) or
+ * orc_ipm_solve (exact=1, x*).  shared[21]: see btrapz_oracle.c. */
+int orc_batch_solve(int variant, int B, int S, const double *seg, const double *init,
+                    const double *ref_end, const double *dl_bounds, const double *shared,
+                    const orc_settings *settings, int exact, int b0, int b1, double *ctrl,
+                    double *obj, int *status, int *iters);
+
 #ifdef __cplusplus
 }
 #endif

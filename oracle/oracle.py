@@ -139,6 +139,10 @@ def lib():
                                     C.POINTER(Settings), C.POINTER(C.c_int),
                                     C.POINTER(C.c_double), C.POINTER(Cube), C.POINTER(Info)]
         L.orc_find_traj.restype = C.c_double
+        L.orc_batch_solve.argtypes = [C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 5 + \
+            [C.POINTER(Settings), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+             C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_batch_solve.restype = C.c_int
         _lib = L
     return _lib
 
@@ -306,3 +310,28 @@ def find_traj(variant, input_path, output_path, params, settings=None):
                                C.byref(S), _dp(ctrl), cubes, C.byref(info))
     s = S.value
     return cost, s, ctrl[:12 * max(s, 0)].copy(), [cubes[i] for i in range(max(min(s, 64), 0))], info
+
+
+def batch_solve(batch, shared, b0=0, b1=None, exact=False, settings=None, threads=1):
+    """Solve candidates [b0,b1) of a spectral_amd.layout.Batch with the oracle (OSQP port, or
+    x* when exact).  threads>1 partitions the range over Python threads (ctypes drops the GIL)."""
+    B, S = batch.B, batch.S
+    b1 = B if b1 is None else b1
+    seg = np.ascontiguousarray(batch.seg, dtype=np.float64); init = np.ascontiguousarray(batch.init, dtype=np.float64)
+    ref_end = np.ascontiguousarray(batch.ref_end, dtype=np.float64); dlb = np.ascontiguousarray(batch.dl_bounds, dtype=np.float64)
+    sh = np.ascontiguousarray(shared.as_array())
+    ctrl = np.zeros((B, 12 * S)); obj = np.zeros(B); status = np.zeros(B, dtype=np.int32); iters = np.zeros(B, dtype=np.int32)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    sp = C.byref(settings) if settings is not None else None
+
+    def run(lo, hi):
+        return lib().orc_batch_solve(shared.variant, B, S, _dp(seg), _dp(init), _dp(ref_end), _dp(dlb), _dp(sh), sp,
+                                     1 if exact else 0, lo, hi, _dp(ctrl), _dp(obj), ip(status), ip(iters))
+    if threads <= 1:
+        run(b0, b1)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        edges = np.linspace(b0, b1, threads + 1).astype(int)
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda i: run(int(edges[i]), int(edges[i + 1])), range(threads)))
+    return ctrl[b0:b1], obj[b0:b1], status[b0:b1], iters[b0:b1]

@@ -67,6 +67,23 @@ def build(verbose=False):
 
 
 _lib = None
+ROCM_HIP_RUNTIME = "/opt/rocm/lib/libamdhip64.so"
+
+
+def _bind_hip_runtime():
+    """libbtrapz_hip.so is linked without a HIP runtime of its own (csrc/Makefile): a process
+    must hold exactly one libamdhip64.  If PyTorch-ROCm is already imported its bundled runtime
+    is promoted to the global symbol scope and reused; otherwise the system runtime is loaded."""
+    import sys
+    path = ROCM_HIP_RUNTIME
+    if "torch" in sys.modules:
+        bundled = os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib", "libamdhip64.so")
+        if os.path.exists(bundled):
+            path = bundled
+    try:
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        raise BtrapzError("cannot load the HIP runtime %s: %s (there is no CPU path)" % (path, e))
 
 
 def lib():
@@ -75,6 +92,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise BtrapzError("HIP library %s is missing: run spectral_amd.native.build() "
                               "(there is no CPU path)" % LIB_PATH)
+        _bind_hip_runtime()
         l = C.CDLL(LIB_PATH)
         vp, dp, ip, llp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
         l.btrapz_find_traj.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.POINTER(CParams)]
