@@ -33,7 +33,7 @@ struct KernelArgs {
   int max_iter;
 };
 
-__global__ void ipm_solve_kernel(const KernelArgs a);
+__global__ void ipm_solve_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void finalize_kernel(int B, const double *axis_obj, const int *axis_status, const int *axis_iters,
                                 double *cost, int *status, int *iters);
 __global__ void argmin_kernel(int group, long long index_base, const double *cost, long long *best_idx,

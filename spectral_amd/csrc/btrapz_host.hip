@@ -141,10 +141,9 @@ extern "C" int btrapz_solve_batch_device(btrapz_ctx *c, const btrapz_shared *sh,
   a.sh.variant = sh->variant;
   a.eps = (opt && opt->eps > 0) ? opt->eps : 1e-9;
   a.max_iter = (opt && opt->max_iter > 0) ? opt->max_iter : 60;
-  const int gpw = 64 / S;
-  const long long nprob = 2LL * B;
-  const unsigned blocks = (unsigned)((nprob + gpw - 1) / gpw);
-  hipLaunchKernelGGL(ipm_solve_kernel, dim3(blocks), dim3(64), 0, stream, a);
+  const int gpw = 64 / S;  // axis problems per wavefront; wave w: axis w&1 of candidates (w>>1)*gpw + [0,gpw)
+  const unsigned blocks = 2u * (unsigned)((B + gpw - 1) / gpw);
+  hipLaunchKernelGGL(ipm_solve_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, B, c->d_axis_obj, c->d_axis_status,
                      c->d_axis_iters, cost, status, iters);

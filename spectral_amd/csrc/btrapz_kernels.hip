@@ -17,12 +17,16 @@
 //     (solve_3d.cc:896-949): the feasible set of the equalities is parametrised EXACTLY by
 //     the joint states X_j = (p, v, a), j = 1..S (null-space form, no equality multipliers);
 //   * every inequality row touches one segment only -> the Newton matrix of a primal-dual
-//     interior-point method in X is block tridiagonal with 3x3 blocks.
-// Mapping: one lane per segment, floor(64/S) axis problems per wavefront, the whole
-// interior-point state in VGPRs (+LDS for group reductions and the P blocks); neighbour
-// exchange with wavefront shuffles; the block-tridiagonal LDL^T and its sweeps run as S
-// sequential steps in which lane k owns pivot block k.  No HBM traffic inside the solve.
+//     (Mehrotra predictor-corrector) interior-point method in X is block tridiagonal, 3x3 blocks.
+// Mapping: one lane per segment, floor(64/S) axis problems per wavefront.  The interior-point
+// state is split between VGPRs (36 slacks per lane) and LDS columns private to the lane (36
+// multipliers, 36 reciprocal slacks); a wavefront holds problems of ONE axis so the
+// batch-invariant M'QM table comes through scalar loads; neighbour exchange is
+// a DPP wave shift; the block LDL^T and its sweeps run as S sequential steps in which lane k
+// owns pivot block k.  HBM is touched once to load the Cube records and once to store results.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "btrapz_device.h"
 
@@ -31,44 +35,68 @@ namespace btrapz {
 #define UNROLL _Pragma("unroll")
 #define SYM(i, j) ((j) * ((j) + 1) / 2 + (i))  // i <= j, packed upper triangle, column-wise
 
-__device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+// 1/x: v_rcp_f64 seed + two Newton steps (full double accuracy for normal x; no denormal /
+// overflow fix-ups -- every operand here is a positive slack, multiplier or pivot).
+__device__ __forceinline__ double rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// lane i <- lane i-1 / lane i+1 over the whole wavefront (DPP wave_shr:1 / wave_shl:1).
+__device__ __forceinline__ double from_prev(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_next(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 
 // ---- constraint rows of one segment (solve_3d.cc:823-888): 6 pos, 5 vel, 4 acc, 3 jerk ----
-__device__ __forceinline__ void G_apply(const double (&c)[6], double t, double (&o)[18]) {
-  UNROLL for (int i = 0; i < 6; i++) o[i] = t * c[i];
-  UNROLL for (int i = 0; i < 5; i++) o[6 + i] = 5.0 * (c[i + 1] - c[i]);
-  UNROLL for (int i = 0; i < 4; i++) o[11 + i] = 20.0 * ((c[i] - 2.0 * c[i + 1]) + c[i + 2]);
-  UNROLL for (int i = 0; i < 3; i++) o[15 + i] = 60.0 * ((c[i + 3] - c[i]) + 3.0 * (c[i + 1] - c[i + 2]));
+// row r: first column, number of columns, coefficients (position rows carry the runtime t).
+__host__ __device__ constexpr int row_col0(int r) { return r < 6 ? r : r < 11 ? r - 6 : r < 15 ? r - 11 : r - 15; }
+__host__ __device__ constexpr int row_nnz(int r) { return r < 6 ? 1 : r < 11 ? 2 : r < 15 ? 3 : 4; }
+__host__ __device__ constexpr double row_coef(int r, int j) {
+  return r < 6 ? 1.0 : r < 11 ? (j == 0 ? -5.0 : 5.0) : r < 15 ? (j == 1 ? -40.0 : 20.0)
+                                                              : (j == 0 ? -60.0 : j == 1 ? 180.0 : j == 2 ? -180.0 : 60.0);
 }
-__device__ __forceinline__ void GT_apply(const double (&y)[18], double t, double (&o)[6]) {
-  UNROLL for (int i = 0; i < 6; i++) o[i] = t * y[i];
-  UNROLL for (int i = 0; i < 5; i++) { o[i] -= 5.0 * y[6 + i]; o[i + 1] += 5.0 * y[6 + i]; }
-  UNROLL for (int i = 0; i < 4; i++) { o[i] += 20.0 * y[11 + i]; o[i + 1] -= 40.0 * y[11 + i]; o[i + 2] += 20.0 * y[11 + i]; }
-  UNROLL for (int i = 0; i < 3; i++) {
-    o[i] -= 60.0 * y[15 + i]; o[i + 1] += 180.0 * y[15 + i]; o[i + 2] -= 180.0 * y[15 + i]; o[i + 3] += 60.0 * y[15 + i];
-  }
+template <int R> __device__ __forceinline__ double row_dot(const double (&c)[6], double t) {
+  if constexpr (R < 6) return t * c[R];
+  else if constexpr (R < 11) return 5.0 * (c[R - 5] - c[R - 6]);
+  else if constexpr (R < 15) return 20.0 * ((c[R - 11] - 2.0 * c[R - 10]) + c[R - 9]);
+  else return 60.0 * ((c[R - 12] - c[R - 15]) + 3.0 * (c[R - 14] - c[R - 13]));
 }
-// H += G' diag(w) G   (packed symmetric 6x6)
-__device__ __forceinline__ void GWG_accumulate(const double (&w)[18], double t, double (&H)[21]) {
-  const double t2 = t * t;
-  UNROLL for (int i = 0; i < 6; i++) H[SYM(i, i)] += t2 * w[i];
-  UNROLL for (int i = 0; i < 5; i++) {
-    const double a = 25.0 * w[6 + i];
-    H[SYM(i, i)] += a; H[SYM(i + 1, i + 1)] += a; H[SYM(i, i + 1)] -= a;
-  }
-  UNROLL for (int i = 0; i < 4; i++) {
-    const double a = 400.0 * w[11 + i];
-    H[SYM(i, i)] += a; H[SYM(i, i + 1)] -= 2.0 * a; H[SYM(i, i + 2)] += a;
-    H[SYM(i + 1, i + 1)] += 4.0 * a; H[SYM(i + 1, i + 2)] -= 2.0 * a; H[SYM(i + 2, i + 2)] += a;
-  }
-  UNROLL for (int i = 0; i < 3; i++) {
-    const double a = 3600.0 * w[15 + i];
-    H[SYM(i, i)] += a; H[SYM(i, i + 1)] -= 3.0 * a; H[SYM(i, i + 2)] += 3.0 * a; H[SYM(i, i + 3)] -= a;
-    H[SYM(i + 1, i + 1)] += 9.0 * a; H[SYM(i + 1, i + 2)] -= 9.0 * a; H[SYM(i + 1, i + 3)] += 3.0 * a;
-    H[SYM(i + 2, i + 2)] += 9.0 * a; H[SYM(i + 2, i + 3)] -= 3.0 * a; H[SYM(i + 3, i + 3)] += a;
+template <int R> __device__ __forceinline__ void row_scatter(double v, double t, double (&o)[6]) {  // o += G_r' v
+  if constexpr (R < 6) o[R] += t * v;
+  else {
+    UNROLL for (int j = 0; j < row_nnz(R); j++) o[row_col0(R) + j] += row_coef(R, j) * v;
   }
 }
-__device__ __forceinline__ double symget(const double (&H)[21], int i, int j) { return i <= j ? H[SYM(i, j)] : H[SYM(j, i)]; }
+template <int R> __device__ __forceinline__ void row_outer(double w, double t2, double (&H)[21]) {  // H += w G_r' G_r
+  if constexpr (R < 6) H[SYM(R, R)] += t2 * w;
+  else {
+    UNROLL for (int a = 0; a < row_nnz(R); a++)
+      UNROLL for (int b = a; b < row_nnz(R); b++)
+        H[SYM(row_col0(R) + a, row_col0(R) + b)] += (row_coef(R, a) * row_coef(R, b)) * w;
+  }
+}
+// Stops the optimiser from carrying row-sized temporaries (G c, residuals, LDS reloads) from one
+// row loop to the next: recomputing them is cheap, keeping 9 x 18 doubles alive spills to scratch.
+__device__ __forceinline__ void opaque6(double (&v)[6]) {
+  UNROLL for (int i = 0; i < 6; i++) asm volatile("" : "+v"(v[i]));
+}
+#define PHASE_FENCE(...) do { asm volatile("" ::: "memory"); __VA_ARGS__; } while (0)
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+#define FOR_ROWS(r) static_for<18>([&](auto r##_c) { constexpr int r = decltype(r##_c)::value;
+#define END_ROWS });
 
 // Null-space maps.  X = (p, v, a) physical state at a joint; segment duration t.
 //   start of segment:  c0 = p/t, c1 = c0 + v/5, c2 = c0 + 2v/5 + a t/20
@@ -81,7 +109,6 @@ __device__ __forceinline__ void U_apply(const NullMap m, const double (&X)[3], d
 __device__ __forceinline__ void V_apply(const NullMap m, const double (&X)[3], double &c3, double &c4, double &c5) {
   c5 = m.it * X[0]; c4 = c5 - 0.2 * X[1]; c3 = c5 - 0.4 * X[1] + m.t20 * X[2];
 }
-// transposes: (h0,h1,h2) -> U'h ; (h3,h4,h5) -> V'h
 __device__ __forceinline__ void UT_apply(const NullMap m, double h0, double h1, double h2, double (&o)[3]) {
   o[0] = m.it * ((h0 + h1) + h2); o[1] = 0.2 * h1 + 0.4 * h2; o[2] = m.t20 * h2;
 }
@@ -107,27 +134,35 @@ __device__ __forceinline__ void ldl3_solve(const double (&F)[6], double b0, doub
   x0 = z0 * F[3] - F[0] * x1 - F[1] * x2;
 }
 
-// ---- reductions over the S lanes of a group through LDS (block = one wavefront) ----
-struct Red4 { double a, b, c, d; };
-__device__ __forceinline__ Red4 group_reduce(double (*red)[64], int lane, int gbase, int S, double vsum, double vmax0,
+// ---- LDS: one 64-wide row per per-lane scalar; a lane only ever touches its own column ----
+enum { L_LL = 0, L_LU = 18, L_ISL = 36, L_ISU = 54, L_RED = 72, L_ROWS = 76 };
+
+// Reductions over the S lanes of a group: every lane publishes 4 values, then reads its
+// group's S entries in batches of 8 (reads issued back to back, one wait per batch).
+struct Red4 { double sum, max0, max1, min; };
+__device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gbase, int S, double vsum, double vmax0,
                                              double vmax1, double vmin) {
   __syncthreads();
-  red[0][lane] = vsum; red[1][lane] = vmax0; red[2][lane] = vmax1; red[3][lane] = vmin;
+  lds[L_RED + 0][lane] = vsum; lds[L_RED + 1][lane] = vmax0; lds[L_RED + 2][lane] = vmax1; lds[L_RED + 3][lane] = vmin;
   __syncthreads();
   Red4 r = {0.0, 0.0, 0.0, 1e300};
-  for (int j = 0; j < S; j++) {
-    r.a += red[0][gbase + j];
-    r.b = fmax(r.b, red[1][gbase + j]);
-    r.c = fmax(r.c, red[2][gbase + j]);
-    r.d = fmin(r.d, red[3][gbase + j]);
+  for (int j0 = 0; j0 < S; j0 += 8) {
+    double a[8], b[8], c[8], d[8];
+    UNROLL for (int u = 0; u < 8; u++) {
+      const int j = gbase + (j0 + u < S ? j0 + u : S - 1);
+      a[u] = lds[L_RED + 0][j]; b[u] = lds[L_RED + 1][j]; c[u] = lds[L_RED + 2][j]; d[u] = lds[L_RED + 3][j];
+    }
+    UNROLL for (int u = 0; u < 8; u++) {
+      r.sum += (j0 + u < S) ? a[u] : 0.0;  // padded slots repeat entry S-1: harmless for max/min
+      r.max0 = fmax(r.max0, b[u]); r.max1 = fmax(r.max1, c[u]); r.min = fmin(r.min, d[u]);
+    }
   }
   return r;
 }
 
 // -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a) {
-  __shared__ double red[4][64];
-  __shared__ double Psm[21][64];
+__global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  __shared__ double lds[L_ROWS][64];
 
   const int lane = threadIdx.x;
   const int S = a.S;
@@ -137,12 +172,13 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a) {
   const bool lane_in_group = g < gpw;
   const int gl = lane_in_group ? g : gpw - 1;
   const int gbase = gl * S;
-  const long long nprob = 2LL * a.B;
-  long long prob = (long long)blockIdx.x * gpw + gl;
-  const bool valid = lane_in_group && prob < nprob;
-  if (prob >= nprob) prob = nprob - 1;
-  const int b = (int)(prob >> 1);
-  const int axis = (int)(prob & 1);
+  // wave w solves axis (w & 1) of candidates (w >> 1) * gpw + [0, gpw): the axis is wave-uniform
+  const int axis = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 1));
+  long long cand = (long long)(blockIdx.x >> 1) * gpw + gl;
+  const bool valid = lane_in_group && cand < a.B;
+  if (cand >= a.B) cand = a.B - 1;
+  const int b = (int)cand;
+  const long long prob = 2LL * b + axis;
   const bool first = (k == 0), last = (k == S - 1);
 
   // ---------------- load the segment record (coalesced: lanes -> consecutive (b,k)) ----------
@@ -150,7 +186,7 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a) {
   const size_t e = (size_t)b * S + k;
   const double *sg = a.seg;
   const double t = sg[BTRAPZ_F_T * BS + e];
-  const double it = rcp(t);
+  const double it = 1.0 / t;
   const NullMap nm = {it, t * 0.05};
   const Shared &sh = a.sh;
   const int variant = sh.variant;
@@ -193,16 +229,16 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a) {
 #define LO(r) ((r) < 6 ? plo0 + (double)(r) * dplo : (r) < 11 ? vlo[((r) >= 6 && (r) < 11) ? (r) - 6 : 0] : (r) < 15 ? alo : jlo)
 #define UP(r) ((r) < 6 ? phi0 + (double)(r) * dphi : (r) < 11 ? vhi[((r) >= 6 && (r) < 11) ? (r) - 6 : 0] : (r) < 15 ? ahi : jhi)
 
-  // P block (solve_3d.cc:159-171) from the batch-invariant MQM_d = M' pQp_d M (device constant table)
-  double P[21];
-  {
-    const double *mq = a.mqm + axis * 84;
-    const double t3 = t * t * t, it3 = it * it * it;
-    UNROLL for (int i = 0; i < 21; i++)
-      P[i] = 2.0 * (t3 * mq[i] + t * mq[21 + i] + mq[42 + i] * it + mq[63 + i] * it3);
-    if (last) P[SYM(5, 5)] += 2.0 * (axis == 0 ? sh.weight_end_s : sh.weight_end_l) * t * t;  // :164-168
-    UNROLL for (int i = 0; i < 21; i++) Psm[i][lane] = P[i];
-  }
+  // P block (solve_3d.cc:159-171) from the batch-invariant MQM_d = M' pQp_d M: the table is
+  // wave-uniform (one axis per wave) -> scalar loads; P is rebuilt where it is needed.
+  const double *__restrict__ mq = mqm + axis * 84;
+  const double t3 = t * t * t, it3 = it * it * it, t2 = t * t;
+  const double pend = last ? 2.0 * (axis == 0 ? sh.weight_end_s : sh.weight_end_l) * t2 : 0.0;  // :164-168
+#define LOAD_P(H)                                                                                     \
+  UNROLL for (int i_ = 0; i_ < 21; i_++)                                                              \
+    H[i_] = 2.0 * (t3 * mq[i_] + t * mq[21 + i_] + it * mq[42 + i_] + it3 * mq[63 + i_]);             \
+  H[SYM(5, 5)] += pend;
+#define HSYM(H, i, j) ((i) <= (j) ? H[SYM(i, j)] : H[SYM(j, i)])
   // q block (solve_3d.cc:248-268): q_p in the monomial basis, then q_p * M
   double q[6];
   {
@@ -229,36 +265,40 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a) {
 
   // ---------------- consistency of the bounds -------------------------------------------
   double gapmin = 1e300, bnorm = 0.0, qn = 0.0;
-  UNROLL for (int r = 0; r < 18; r++) {
+  FOR_ROWS(r)
     gapmin = fmin(gapmin, UP(r) - LO(r));
     bnorm = fmax(bnorm, fmax(fabs(LO(r)), fabs(UP(r))));
-  }
+  END_ROWS
   UNROLL for (int i = 0; i < 6; i++) qn = fmax(qn, fabs(q[i]));
   // ---------------- starting point: constant-velocity propagation of the initial state -----
   double X[3];
   {
     __syncthreads();
-    red[0][lane] = t;
+    lds[L_RED][lane] = t;
     __syncthreads();
     double tsum = 0.0;
-    for (int j = 0; j < S; j++) tsum += (j <= k) ? red[0][gbase + j] : 0.0;
+    for (int j = 0; j < S; j++) tsum += (j <= k) ? lds[L_RED][gbase + j] : 0.0;
     X[0] = Xinit[0] + Xinit[1] * tsum; X[1] = Xinit[1]; X[2] = 0.0;
   }
-  Red4 r0 = group_reduce(red, lane, gbase, S, 0.0, bnorm, qn, gapmin);
-  bnorm = r0.b; qn = r0.c; gapmin = r0.d;
+  {
+    const Red4 r0 = group_reduce(lds, lane, gbase, S, 0.0, bnorm, qn, gapmin);
+    bnorm = r0.max0; qn = r0.max1; gapmin = r0.min;
+  }
   const bool infeasible_bounds = !(gapmin >= 0.0) || !(t > 0.0);
 
-  double sl[18], su[18], ll[18], lu[18];
+  double sl[18], su[18];
+#define LL(r) lds[L_LL + r][lane]
+#define LU(r) lds[L_LU + r][lane]
   {
-    double Xp[3], c[6], Gc[18];
-    UNROLL for (int i = 0; i < 3; i++) { const double v = __shfl_up(X[i], 1); Xp[i] = first ? Xinit[i] : v; }
+    double Xp[3], c[6];
+    UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(X[i]); Xp[i] = first ? Xinit[i] : v; }
     U_apply(nm, Xp, c[0], c[1], c[2]);
     V_apply(nm, X, c[3], c[4], c[5]);
-    G_apply(c, t, Gc);
-    UNROLL for (int r = 0; r < 18; r++) {
-      sl[r] = fmax(Gc[r] - LO(r), 1.0); su[r] = fmax(UP(r) - Gc[r], 1.0);
-      ll[r] = 1.0; lu[r] = 1.0;
-    }
+    FOR_ROWS(r)
+      const double gc_r = row_dot<r>(c, t);
+      sl[r] = fmax(gc_r - LO(r), 1.0); su[r] = fmax(UP(r) - gc_r, 1.0);
+      LL(r) = 1.0; LU(r) = 1.0;
+    END_ROWS
   }
 
   const double eps = a.eps;
@@ -268,62 +308,67 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a) {
   bool done = !valid || infeasible_bounds;
 
   for (int iter = 0; iter < a.max_iter; ++iter) {
-    // ---- 1. control points of this segment, rows, residuals ----
-    double Xp[3], c[6], Gc[18];
-    UNROLL for (int i = 0; i < 3; i++) { const double v = __shfl_up(X[i], 1); Xp[i] = first ? Xinit[i] : v; }
-    U_apply(nm, Xp, c[0], c[1], c[2]);
-    V_apply(nm, X, c[3], c[4], c[5]);
-    G_apply(c, t, Gc);
-    double mu_part = 0.0, rp_part = 0.0, y[18];
-    UNROLL for (int r = 0; r < 18; r++) {
-      const double rpl = Gc[r] - sl[r] - LO(r), rpu = Gc[r] + su[r] - UP(r);
-      rp_part = fmax(rp_part, fmax(fabs(rpl), fabs(rpu)));
-      mu_part += sl[r] * ll[r] + su[r] * lu[r];
-      y[r] = lu[r] - ll[r];
-    }
-    double gc[6], Pc[6], dscale = 0.0;
-    GT_apply(y, t, gc);
-    UNROLL for (int i = 0; i < 6; i++) dscale = fmax(dscale, fabs(gc[i]));
-    UNROLL for (int i = 0; i < 6; i++) {
-      double s = 0.0;
-      UNROLL for (int j = 0; j < 6; j++) s += (i <= j ? Psm[SYM(i, j)][lane] : Psm[SYM(j, i)][lane]) * c[j];
-      Pc[i] = s;
-      dscale = fmax(dscale, fabs(s));
-      gc[i] += s + q[i];
+    // ---- 1. control points of this segment, rows, residuals, gradient ----
+    double c[6], gc[6];
+    double mu_part = 0.0, rp_part = 0.0, dscale = 0.0;
+    {
+      double Xp[3];
+      UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(X[i]); Xp[i] = first ? Xinit[i] : v; }
+      U_apply(nm, Xp, c[0], c[1], c[2]);
+      V_apply(nm, X, c[3], c[4], c[5]);
+      UNROLL for (int i = 0; i < 6; i++) gc[i] = 0.0;
+      FOR_ROWS(r)
+        const double gcr = row_dot<r>(c, t), ll = LL(r), lu = LU(r);
+        const double rpl = gcr - sl[r] - LO(r), rpu = gcr + su[r] - UP(r);
+        rp_part = fmax(rp_part, fmax(fabs(rpl), fabs(rpu)));
+        mu_part += sl[r] * ll + su[r] * lu;
+        row_scatter<r>(lu - ll, t, gc);
+      END_ROWS
+      UNROLL for (int i = 0; i < 6; i++) dscale = fmax(dscale, fabs(gc[i]));
+      double Pm[21];
+      LOAD_P(Pm)
+      UNROLL for (int i = 0; i < 6; i++) {
+        double s = 0.0;
+        UNROLL for (int j = 0; j < 6; j++) s += HSYM(Pm, i, j) * c[j];
+        dscale = fmax(dscale, fabs(s));
+        gc[i] += s + q[i];
+      }
     }
     // reduced gradient for X_{k+1}: V' gc[3..5] + (lane k+1) U' gc[0..2]
-    double rd[3], un[3];
-    VT_apply(nm, gc[3], gc[4], gc[5], rd);
-    UT_apply(nm, gc[0], gc[1], gc[2], un);
-    UNROLL for (int i = 0; i < 3; i++) { const double v = __shfl_down(un[i], 1); rd[i] += last ? 0.0 : v; }
-    const double rd_part = fmax(fabs(rd[0]), fmax(fabs(rd[1]), fabs(rd[2])));
-    Red4 rr = group_reduce(red, lane, gbase, S, mu_part, rd_part, rp_part, -dscale);
-    const double mu = rr.a * inv_m;
-    const double rdn = rr.b, rpn = rr.c, dsc = -rr.d;
+    double rd_part;
+    {
+      double rd[3], un[3];
+      VT_apply(nm, gc[3], gc[4], gc[5], rd);
+      UT_apply(nm, gc[0], gc[1], gc[2], un);
+      UNROLL for (int i = 0; i < 3; i++) { const double v = from_next(un[i]); rd[i] += last ? 0.0 : v; }
+      rd_part = fmax(fabs(rd[0]), fmax(fabs(rd[1]), fabs(rd[2])));
+    }
+    const Red4 rr = group_reduce(lds, lane, gbase, S, mu_part, rd_part, rp_part, -dscale);
+    const double mu = rr.sum * inv_m;
     // KKT score: dual residual relative to (1+|q|) with a round-off floor, primal residual
     // relative to the bound scale, complementarity absolute.
-    const double rd_eff = fmax(rdn - 2e-13 * dsc, 0.0);
-    const double score = fmax(fmax(rd_eff / (1.0 + qn), rpn / (1.0 + bnorm)), mu);
+    const double rd_eff = fmax(rr.max0 - 2e-13 * (-rr.min), 0.0);
+    const double score = fmax(fmax(rd_eff / (1.0 + qn), rr.max1 / (1.0 + bnorm)), mu);
     if (!done) {
       iters = iter;
       if (score < best_score) { best_score = score; best_it = iter; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
+#ifndef ABL_FIXED
       if (score < eps || (best_score < 1e-5 && iter - best_it >= 3) || !(score == score)) done = true;
+#endif
     }
     if (__all(done)) break;
 
     // ---- 2. Newton matrix: H = P + G'WG ; M = Phi' H Phi ; block tridiagonal T, M01 ----
-    double isl[18], isu[18], H[21];
-    UNROLL for (int i = 0; i < 21; i++) H[i] = Psm[i][lane];
-    {
-      double W[18];
-      UNROLL for (int r = 0; r < 18; r++) {
-        isl[r] = rcp(sl[r]); isu[r] = rcp(su[r]);
-        W[r] = ll[r] * isl[r] + lu[r] * isu[r];
-      }
-      GWG_accumulate(W, t, H);
-    }
     double M01[9], T[6];
     {
+      double H[21];
+      LOAD_P(H)
+      PHASE_FENCE();
+      FOR_ROWS(r)
+        const double isl = rcp(sl[r]), isu = rcp(su[r]);
+        lds[L_ISL + r][lane] = isl; lds[L_ISU + r][lane] = isu;
+        row_outer<r>(LL(r) * isl + LU(r) * isu, t2, H);
+      END_ROWS
       double w0[3], w1[3], w2[3], col[3], M00[6];
       // M00 = U' H00 U
       UT_apply(nm, H[SYM(0, 0)], H[SYM(0, 1)], H[SYM(0, 2)], w0);
@@ -348,14 +393,18 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a) {
       VT_apply(nm, w0[1], w1[1], w2[1], col); T[3] = col[1]; T[4] = col[2];
       VT_apply(nm, w0[2], w1[2], w2[2], col); T[5] = col[2];
       // diagonal block of X_{k+1}: M11_k + M00_{k+1}
-      UNROLL for (int i = 0; i < 6; i++) { const double v = __shfl_down(M00[i], 1); T[i] += last ? 0.0 : v; }
+      UNROLL for (int i = 0; i < 6; i++) { const double v = from_next(M00[i]); T[i] += last ? 0.0 : v; }
     }
     // ---- 3. block LDL^T: S_0 = T_0 ; C_k = S_{k-1}^{-1} M01_k ; S_k = T_k - M01_k' C_k ----
     double F[6] = {0.0, 0.0, 0.0, 1.0, 1.0, 1.0}, C[9];
     UNROLL for (int i = 0; i < 9; i++) C[i] = 0.0;
+#if defined(ABL_NOSEQ) || defined(ABL_NOFACT)
+    for (int step = 0; step < 1; ++step) {
+#else
     for (int step = 0; step < S; ++step) {
+#endif
       double pF[6];
-      UNROLL for (int i = 0; i < 6; i++) pF[i] = __shfl_up(F[i], 1);
+      UNROLL for (int i = 0; i < 6; i++) pF[i] = from_prev(F[i]);
       if (k == step) {
         double Sk[6] = {T[0], T[1], T[2], T[3], T[4], T[5]};
         if (!first) {
@@ -373,33 +422,45 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a) {
     }
 
     // ---- 4. predictor (sigma = 0) and corrector solves ----
-    double Gdc_aff[18];
     double sigma_mu = 0.0;
-    double alpha = 0.0;
+    double dca[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // predictor direction in control-point space
     UNROLL for (int pass = 0; pass < 2; ++pass) {
-      // rhs in c space: h = gc + G' tv ; tv = rcl/sl - rcu/su + (ll/sl) rpl + (lu/su) rpu
-      double tv[18];
-      UNROLL for (int r = 0; r < 18; r++) {
-        const double rpl = Gc[r] - sl[r] - LO(r), rpu = Gc[r] + su[r] - UP(r);
-        double rcl = sl[r] * ll[r], rcu = su[r] * lu[r];
-        if (pass == 1) {
-          const double dsl = Gdc_aff[r] + rpl, dsu = -Gdc_aff[r] - rpu;
-          const double dll = -ll[r] - ll[r] * dsl * isl[r], dlu = -lu[r] - lu[r] * dsu * isu[r];
-          rcl += dsl * dll - sigma_mu; rcu += dsu * dlu - sigma_mu;
-        }
-        tv[r] = (rcl + ll[r] * rpl) * isl[r] - (rcu - lu[r] * rpu) * isu[r];
+      // complementarity target of row r in this pass: rc = s*lambda (+ ds_aff*dl_aff - sigma*mu)
+#define ROW_TERMS(r)                                                                             \
+      const double isl = lds[L_ISL + r][lane], isu = lds[L_ISU + r][lane];                          \
+      const double ll = LL(r), lu = LU(r);                                                          \
+      const double gcr = row_dot<r>(c, t);                                                          \
+      const double rpl = gcr - sl[r] - LO(r), rpu = gcr + su[r] - UP(r);                              \
+      double rcl = sl[r] * ll, rcu = su[r] * lu;                                                    \
+      if (pass == 1) {                                                                              \
+        const double ga = row_dot<r>(dca, t);                                                        \
+        const double dsa = ga + rpl, dua = -ga - rpu;                                                \
+        rcl += dsa * (-ll - ll * dsa * isl) - sigma_mu;                                               \
+        rcu += dua * (-lu - lu * dua * isu) - sigma_mu;                                               \
       }
+      // rhs in c space: h = gc + G' tv ; tv = (rcl + ll rpl)/sl - (rcu - lu rpu)/su
       double h[6];
-      GT_apply(tv, t, h);
-      UNROLL for (int i = 0; i < 6; i++) h[i] += gc[i];
-      double u[3], hn[3];
-      VT_apply(nm, h[3], h[4], h[5], u);
-      UT_apply(nm, h[0], h[1], h[2], hn);
-      UNROLL for (int i = 0; i < 3; i++) { const double v = __shfl_down(hn[i], 1); u[i] = -(u[i] + (last ? 0.0 : v)); }
+      UNROLL for (int i = 0; i < 6; i++) h[i] = gc[i];
+      PHASE_FENCE(opaque6(c); opaque6(dca));
+      FOR_ROWS(r)
+        ROW_TERMS(r)
+        row_scatter<r>((rcl + ll * rpl) * isl - (rcu - lu * rpu) * isu, t, h);
+      END_ROWS
+      double u[3];
+      {
+        double hn[3];
+        VT_apply(nm, h[3], h[4], h[5], u);
+        UT_apply(nm, h[0], h[1], h[2], hn);
+        UNROLL for (int i = 0; i < 3; i++) { const double v = from_next(hn[i]); u[i] = -(u[i] + (last ? 0.0 : v)); }
+      }
       // forward: u_k -= C_k' u_{k-1}
+#if defined(ABL_NOSEQ) || defined(ABL_NOSWEEP)
+      for (int step = 1; step < 2; ++step) {
+#else
       for (int step = 1; step < S; ++step) {
+#endif
         double pu[3];
-        UNROLL for (int i = 0; i < 3; i++) pu[i] = __shfl_up(u[i], 1);
+        UNROLL for (int i = 0; i < 3; i++) pu[i] = from_prev(u[i]);
         if (k == step) {
           u[0] -= C[0] * pu[0] + C[3] * pu[1] + C[6] * pu[2];
           u[1] -= C[1] * pu[0] + C[4] * pu[1] + C[7] * pu[2];
@@ -411,78 +472,87 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a) {
       ldl3_solve(F, u[0], u[1], u[2], v[0], v[1], v[2]);
       UNROLL for (int i = 0; i < 3; i++) dX[i] = v[i];
       UNROLL for (int i = 0; i < 3; i++) w[i] = C[3 * i] * dX[0] + C[3 * i + 1] * dX[1] + C[3 * i + 2] * dX[2];
+#if defined(ABL_NOSEQ) || defined(ABL_NOSWEEP)
+      for (int step = 0; step >= 0; --step) {
+#else
       for (int step = S - 2; step >= 0; --step) {
+#endif
         double pw[3];
-        UNROLL for (int i = 0; i < 3; i++) pw[i] = __shfl_down(w[i], 1);
+        UNROLL for (int i = 0; i < 3; i++) pw[i] = from_next(w[i]);
         if (k == step) {
           UNROLL for (int i = 0; i < 3; i++) dX[i] = v[i] - pw[i];
           UNROLL for (int i = 0; i < 3; i++) w[i] = C[3 * i] * dX[0] + C[3 * i + 1] * dX[1] + C[3 * i + 2] * dX[2];
         }
       }
-      // directions in the rows
-      double dXp[3], dc[6], Gdc[18];
-      UNROLL for (int i = 0; i < 3; i++) { const double vv = __shfl_up(dX[i], 1); dXp[i] = first ? 0.0 : vv; }
-      U_apply(nm, dXp, dc[0], dc[1], dc[2]);
-      V_apply(nm, dX, dc[3], dc[4], dc[5]);
-      G_apply(dc, t, Gdc);
-      // step to the boundary: max over rows of -d/v kept as a fraction (no divisions)
-      double pn = 0.0, pd = 1.0, dn = 0.0, dd = 1.0;  // primal ratio pn/pd, dual ratio dn/dd
-      double mua_part = 0.0;
-      double dsl_[18], dsu_[18], dll_[18], dlu_[18];
-      UNROLL for (int r = 0; r < 18; r++) {
-        const double rpl = Gc[r] - sl[r] - LO(r), rpu = Gc[r] + su[r] - UP(r);
-        double rcl = sl[r] * ll[r], rcu = su[r] * lu[r];
-        if (pass == 1) {
-          const double dsl = Gdc_aff[r] + rpl, dsu = -Gdc_aff[r] - rpu;
-          const double dll = -ll[r] - ll[r] * dsl * isl[r], dlu = -lu[r] - lu[r] * dsu * isu[r];
-          rcl += dsl * dll - sigma_mu; rcu += dsu * dlu - sigma_mu;
-        }
-        const double dsl = Gdc[r] + rpl, dsu = -Gdc[r] - rpu;
-        const double dll = (-rcl - ll[r] * dsl) * isl[r], dlu = (-rcu - lu[r] * dsu) * isu[r];
-        dsl_[r] = dsl; dsu_[r] = dsu; dll_[r] = dll; dlu_[r] = dlu;
-        // ratio = -d/v ; keep the largest (v > 0)
+      // directions in the rows: ds = +-(G dc) + rp ; dlambda = (-rc - lambda ds)/s
+      double dc[6];
+      {
+        double dXp[3];
+        UNROLL for (int i = 0; i < 3; i++) { const double vv = from_prev(dX[i]); dXp[i] = first ? 0.0 : vv; }
+        U_apply(nm, dXp, dc[0], dc[1], dc[2]);
+        V_apply(nm, dX, dc[3], dc[4], dc[5]);
+      }
+#define ROW_DIRS(r)                                                                              \
+      const double gd = row_dot<r>(dc, t);                                                          \
+      const double dsl = gd + rpl, dsu = -gd - rpu;                                                 \
+      const double dll = (-rcl - ll * dsl) * isl, dlu = (-rcu - lu * dsu) * isu;
+      // step to the boundary: largest -d/v over the rows, kept as a fraction (no divisions)
+      double pn = 0.0, pd = 1.0, dn = 0.0, dd = 1.0;
+      PHASE_FENCE(opaque6(c); opaque6(dca); opaque6(dc));
+      FOR_ROWS(r)
+        ROW_TERMS(r)
+        ROW_DIRS(r)
         if (-dsl * pd > pn * sl[r]) { pn = -dsl; pd = sl[r]; }
         if (-dsu * pd > pn * su[r]) { pn = -dsu; pd = su[r]; }
-        if (-dll * dd > dn * ll[r]) { dn = -dll; dd = ll[r]; }
-        if (-dlu * dd > dn * lu[r]) { dn = -dlu; dd = lu[r]; }
-      }
-      const double pr_ratio = pn / pd, du_ratio = dn / dd;  // step = 1/max(ratio,1)
-      Red4 ra = group_reduce(red, lane, gbase, S, 0.0, pr_ratio, du_ratio, 0.0);
-      const double ap = 1.0 / fmax(ra.b, 1.0), ad = 1.0 / fmax(ra.c, 1.0);
+        if (-dll * dd > dn * ll) { dn = -dll; dd = ll; }
+        if (-dlu * dd > dn * lu) { dn = -dlu; dd = lu; }
+      END_ROWS
+      const Red4 ra = group_reduce(lds, lane, gbase, S, 0.0, pn * rcp(pd), dn * rcp(dd), 0.0);
+      const double ap = 1.0 / fmax(ra.max0, 1.0), ad = 1.0 / fmax(ra.max1, 1.0);
       if (pass == 0) {
-        UNROLL for (int r = 0; r < 18; r++) {
-          mua_part += (sl[r] + ap * dsl_[r]) * (ll[r] + ad * dll_[r]) + (su[r] + ap * dsu_[r]) * (lu[r] + ad * dlu_[r]);
-          Gdc_aff[r] = Gdc[r];
-        }
-        Red4 rm = group_reduce(red, lane, gbase, S, mua_part, 0.0, 0.0, 0.0);
-        const double mua = rm.a * inv_m;
-        const double sr = mua / mu;
+        // centering parameter from the predictor: sigma = (mu_aff/mu)^3
+        double mua_part = 0.0;
+        PHASE_FENCE(opaque6(c); opaque6(dc));
+        FOR_ROWS(r)
+          ROW_TERMS(r)
+          ROW_DIRS(r)
+          mua_part += (sl[r] + ap * dsl) * (ll + ad * dll) + (su[r] + ap * dsu) * (lu + ad * dlu);
+        END_ROWS
+        UNROLL for (int i = 0; i < 6; i++) dca[i] = dc[i];
+        const Red4 rm = group_reduce(lds, lane, gbase, S, mua_part, 0.0, 0.0, 0.0);
+        const double sr = rm.sum * inv_m / mu;
         sigma_mu = sr * sr * sr * mu;
       } else {
-        alpha = fmin(1.0, 0.995 * fmin(ap, ad));
-        if (done) alpha = 0.0;
+        const double alpha = done ? 0.0 : fmin(1.0, 0.995 * fmin(ap, ad));
         UNROLL for (int i = 0; i < 3; i++) X[i] += alpha * dX[i];
-        UNROLL for (int r = 0; r < 18; r++) {
-          sl[r] += alpha * dsl_[r]; su[r] += alpha * dsu_[r];
-          ll[r] += alpha * dll_[r]; lu[r] += alpha * dlu_[r];
-        }
+        PHASE_FENCE(opaque6(c); opaque6(dca); opaque6(dc));
+        FOR_ROWS(r)
+          ROW_TERMS(r)
+          ROW_DIRS(r)
+          sl[r] += alpha * dsl; su[r] += alpha * dsu;
+          LL(r) = ll + alpha * dll; LU(r) = lu + alpha * dlu;
+        END_ROWS
       }
+#undef ROW_TERMS
+#undef ROW_DIRS
     }
   }
 
   // ---------------- write back: control points, per-axis objective/status ------------------
   {
     double Xp[3], c[6];
-    UNROLL for (int i = 0; i < 3; i++) { const double v = __shfl_up(Xb[i], 1); Xp[i] = first ? Xinit[i] : v; }
+    UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(Xb[i]); Xp[i] = first ? Xinit[i] : v; }
     U_apply(nm, Xp, c[0], c[1], c[2]);
     V_apply(nm, Xb, c[3], c[4], c[5]);
     double obj = 0.0;
+    double Pm[21];
+    LOAD_P(Pm)
     UNROLL for (int i = 0; i < 6; i++) {
       double s = 0.0;
-      UNROLL for (int j = 0; j < 6; j++) s += (i <= j ? Psm[SYM(i, j)][lane] : Psm[SYM(j, i)][lane]) * c[j];
+      UNROLL for (int j = 0; j < 6; j++) s += HSYM(Pm, i, j) * c[j];
       obj += c[i] * (0.5 * s + q[i]);
     }
-    Red4 ro = group_reduce(red, lane, gbase, S, obj, 0.0, 0.0, 0.0);
+    const Red4 ro = group_reduce(lds, lane, gbase, S, obj, 0.0, 0.0, 0.0);
     if (valid) {
       double *dst = a.ctrl + (size_t)b * 12 * S + (size_t)axis * 6 * S + (size_t)k * 6;
       UNROLL for (int i = 0; i < 6; i++) dst[i] = c[i];
@@ -492,7 +562,7 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a) {
         else if (best_score < 1e-7) st = BTRAPZ_SOLVED;
         else if (best_score < 1e-5) st = BTRAPZ_SOLVED_INACCURATE;
         else st = BTRAPZ_MAX_ITER_REACHED;
-        a.axis_obj[prob] = ro.a;
+        a.axis_obj[prob] = ro.sum;
         a.axis_status[prob] = st;
         a.axis_iters[prob] = iters;
       }
