@@ -57,6 +57,20 @@ enum { BTRAPZ_TRAPEZOID = 0, /* src/solve_3d.cc   */
 double btrapz_find_traj(int variant, const char *input_path, const char *output_path,
                         const Params *p);
 
+/* Host-side corridor stage of find_traj alone (CorridorGeneration + CorridorSplit per obstacle,
+ * then CollisionCheck: src/solve_3d.cc:323-486,729-772,488-714 ; src/cuboid_3d.cc:301-573).
+ * Parses input_path, writes up to cap segments.  Returns the segment count S >= 1, 0 when no
+ * segment survives the selection, or a negative BTRAPZ_E* code.  Needs no GPU. */
+typedef struct btrapz_segment { /* == Cube, include/btrapz/cube_type.h:2-24 */
+  int beg_t, end_t;
+  double t;
+  double beg_l, end_l;
+  double upp_skew, upp_bias, down_skew, down_bias;
+  double l_upp_skew, l_upp_bias, l_down_skew, l_down_bias;
+  int count;
+} btrapz_segment;
+int btrapz_corridor_from_file(int variant, const char *input_path, btrapz_segment *out, int cap);
+
 /* ---- error codes ----------------------------------------------------------------- */
 enum {
   BTRAPZ_OK = 0,

@@ -104,6 +104,26 @@ double trajectory_cost(int variant, const Params &p, const TrajInput &in, int np
 
 }  // namespace
 
+extern "C" int btrapz_corridor_from_file(int variant, const char *input_path, btrapz_segment *out, int cap) {
+  if (!input_path || !out || cap < 1 || variant < 0 || variant > 1) return BTRAPZ_EINVAL;
+  TrajInput in;
+  if (!read_traj_input(input_path, in)) return BTRAPZ_EINVAL;
+  std::vector<std::vector<Segment>> lists;
+  for (int o = 0; o < in.num_obs; o++) lists.push_back(extract_segments(variant, in.N, in.delta, in.s_bounds[o], in.l_bounds[o]));
+  std::vector<Segment> seg;
+  if (!select_segments(variant, in.delta, lists, in.s_ref, in.l_ref, seg)) return 0;
+  const int n = (int)seg.size() < cap ? (int)seg.size() : cap;
+  for (int k = 0; k < n; k++) {
+    const Segment &c = seg[k];
+    btrapz_segment &o = out[k];
+    o.beg_t = c.beg_t; o.end_t = c.end_t; o.t = c.t; o.beg_l = c.beg_l; o.end_l = c.end_l;
+    o.upp_skew = c.upp_skew; o.upp_bias = c.upp_bias; o.down_skew = c.down_skew; o.down_bias = c.down_bias;
+    o.l_upp_skew = c.l_upp_skew; o.l_upp_bias = c.l_upp_bias; o.l_down_skew = c.l_down_skew; o.l_down_bias = c.l_down_bias;
+    o.count = c.count;
+  }
+  return (int)seg.size();
+}
+
 extern "C" double btrapz_find_traj(int variant, const char *input_path, const char *output_path, const Params *p) {
   const double FAIL = BTRAPZ_FAIL_SENTINEL;
   if (!p || variant < 0 || variant > 1) return FAIL;

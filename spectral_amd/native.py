@@ -54,7 +54,18 @@ class CParams(C.Structure):
                 ("iteration", C.c_int)]
 
 
-EXPORTS = ("btrapz_find_traj", "btrapz_create", "btrapz_destroy", "btrapz_last_error",
+class CSegment(C.Structure):
+    """btrapz_segment == Cube (include/btrapz/cube_type.h:2-24)."""
+    _fields_ = [("beg_t", C.c_int), ("end_t", C.c_int), ("t", C.c_double),
+                ("beg_l", C.c_double), ("end_l", C.c_double),
+                ("upp_skew", C.c_double), ("upp_bias", C.c_double),
+                ("down_skew", C.c_double), ("down_bias", C.c_double),
+                ("l_upp_skew", C.c_double), ("l_upp_bias", C.c_double),
+                ("l_down_skew", C.c_double), ("l_down_bias", C.c_double),
+                ("count", C.c_int)]
+
+
+EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "btrapz_destroy", "btrapz_last_error",
            "btrapz_device_count", "btrapz_solve_batch_device", "btrapz_argmin_device",
            "btrapz_sample_device", "btrapz_solve_batch_host")
 
@@ -97,6 +108,8 @@ def lib():
         vp, dp, ip, llp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
         l.btrapz_find_traj.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.POINTER(CParams)]
         l.btrapz_find_traj.restype = C.c_double
+        l.btrapz_corridor_from_file.argtypes = [C.c_int, C.c_char_p, C.POINTER(CSegment), C.c_int]
+        l.btrapz_corridor_from_file.restype = C.c_int
         l.btrapz_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         l.btrapz_destroy.argtypes = [C.c_void_p]
         l.btrapz_last_error.argtypes = [C.c_void_p]; l.btrapz_last_error.restype = C.c_char_p
@@ -182,3 +195,12 @@ def find_traj_native(variant, params, input_path=None, output_path=None):
     cp = params if isinstance(params, CParams) else CParams(*params)
     enc = lambda s: os.fsencode(s) if s else None
     return lib().btrapz_find_traj(int(variant), enc(input_path), enc(output_path), C.byref(cp))
+
+
+def corridor_from_file(variant, input_path, cap=256):
+    """Host-side corridor stage (no GPU): list of CSegment, [] when nothing is selected."""
+    buf = (CSegment * cap)()
+    n = lib().btrapz_corridor_from_file(int(variant), os.fsencode(input_path), buf, cap)
+    if n < 0:
+        raise BtrapzError("btrapz_corridor_from_file(%s) -> %d" % (input_path, n))
+    return [buf[i] for i in range(min(n, cap))]

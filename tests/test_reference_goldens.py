@@ -1,0 +1,108 @@
+"""Vectors the REFERENCE ITSELF produced (tests/golden/ref_outputs/*.txt are trajectory files
+from the reference repo, 7 columns `t s l ds dl dds ddl`, 3 decimals, trp_wrapper.cpp:298-301).
+
+The weights of each saved run were not recorded, but two input/output pairs are reproduced to
+print precision with the s weights of weights.txt (found by searching all_weights.txt):
+  * c4.txt / c5.txt -> s4_slt_3d.txt, s4_cub_3d.txt, s5_slt_3d.txt.  OSQP hits max_iter there
+    (status 2, "solved inaccurate"): the reference wrote OSQP's UNCONVERGED iterate, 0.34 m
+    from the optimum.  The oracle's OSQP port lands on the same 3 decimals after 5000
+    iterations -> this pins parser + corridor pipeline + assembly + ADMM port + sampling.
+  * c2.txt -> s columns of s2_slt_3d_4.txt / s2_slt_3d_5.txt (OSQP converged): both the OSQP
+    port and x* agree with the reference's file to print precision.
+The other pairs only pin the row count 1 + sum floor(t_k/delta) and the first row."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+W = np.loadtxt(os.path.join(GOLD, "inputs", "weights.txt"))
+# all_weights.txt row 47 (0-based, numeric rows only): weights.txt with weight_l_ref = 49.71.  OSQP's
+# stopping point couples the axes (joint termination test, joint adaptive rho), so reproducing its
+# s-axis ITERATE needs the l weights of the saved run too; x* of the s axis does not depend on them.
+W47 = np.array([35.73, 41.61, 25.57, 41.59, 0.12, 10.04, 49.71, 14.3, 7.27, 32.13])
+PRINT = 5.0e-4 + 2e-5  # half a unit of the third decimal + slack for values that sit on a rounding edge
+
+
+def run(name, variant, exact, tmp_path, weights=W47):
+    out = str(tmp_path / "traj.txt")
+    p = O.params_from_weights(weights)
+    if not exact:  # the whole reference driver (parse -> corridors -> assemble -> OSQP port -> sample -> file)
+        path = os.path.join(GOLD, "inputs", name + ".txt")
+        cost, S, ctrl, cubes, info = O.find_traj(variant, path, out, p)
+        inp = O.ParsedInput(path)
+        rc, s = O.sample(cubes, inp.delta, ctrl, inp.init_s, inp.init_l)
+        full = np.stack([np.arange(len(s[0])) * inp.delta, s[0], s[3], s[1], s[4], s[2], s[5]], 1)
+        written = np.loadtxt(out)
+        assert written.shape == full.shape and np.abs(written - full).max() <= PRINT  # file = 3-decimal rounding
+        return cost, full, info
+    inp = O.ParsedInput(os.path.join(GOLD, "inputs", name + ".txt"))
+    n, cubes = O.pipeline(variant, inp)
+    qp = O.AssembledQp(variant, cubes, p, inp)
+    x, _, info = qp.solve_exact()
+    rc, s = O.sample(cubes, inp.delta, x, inp.init_s, inp.init_l)
+    return None, np.stack([np.arange(len(s[0])) * inp.delta, s[0], s[3], s[1], s[4], s[2], s[5]], 1), info
+
+
+@pytest.mark.parametrize("name,variant,ref", [("c4", 0, "s4_slt_3d.txt"), ("c4", 1, "s4_cub_3d.txt"),
+                                              ("c5", 0, "s5_slt_3d.txt")])
+def test_oracle_reproduces_reference_file_c4(name, variant, ref, tmp_path):
+    cost, got, info = run(name, variant, False, tmp_path)
+    want = np.loadtxt(os.path.join(GOLD, "ref_outputs", ref))
+    assert info.status == 2 and info.iter == 5000      # the reference accepted "solved inaccurate"
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= PRINT
+    assert cost < 1e10
+
+
+@pytest.mark.parametrize("ref", ["s2_slt_3d_4.txt", "s2_slt_3d_5.txt"])
+@pytest.mark.parametrize("exact", [False, True])
+def test_s_axis_of_scenario_2_matches_reference_file(ref, exact, tmp_path):
+    _, got, info = run("c2", 0, exact, tmp_path, weights=W if exact else W47)
+    want = np.loadtxt(os.path.join(GOLD, "ref_outputs", ref))
+    assert info.status == 1
+    assert got.shape == want.shape
+    cols = [0, 1, 3, 5]  # t, s, ds, dds
+    assert np.abs(got[:, cols] - want[:, cols]).max() <= PRINT
+
+
+def test_xstar_differs_from_the_unconverged_reference_iterate(tmp_path):
+    """Documents WHY parity is defined against x*: on c4 the reference's own answer is 0.34 m off."""
+    _, got, info = run("c4", 0, True, tmp_path)
+    want = np.loadtxt(os.path.join(GOLD, "ref_outputs", "s4_slt_3d.txt"))
+    assert info.status == 1
+    assert 0.2 < np.abs(got[:, 1] - want[:, 1]).max() < 0.5
+
+
+PAIRS = [("c1", 0, "s1_slt_3d_30.txt"), ("c1", 0, "s1_slt_3d_31.txt"), ("c1", 0, "s1_slt_3d_500.txt"),
+         ("c1", 1, "s1_cub_3d_3.txt"), ("c1", 1, "s1_cub_3d_4.txt"), ("c1", 1, "s1_cub_3d_30.txt"),
+         ("c1", 1, "s1_cub_3d_31.txt"), ("c2", 1, "s2_cub_3d_3.txt"),
+         ("c2", 1, "s2_cub_3d_5.txt"), ("c_road_s1", 0, "s1_slt_3d_200.txt")]
+
+
+@pytest.mark.parametrize("name,variant,ref", PAIRS)
+def test_row_count_and_first_row_of_saved_outputs(name, variant, ref):
+    """Weak anchor for pairs whose weights are unknown: number of samples and the echoed
+    initial state (solve_3d.cc:1279-1282, 1325-1331)."""
+    inp = O.ParsedInput(os.path.join(GOLD, "inputs", name + ".txt"))
+    n, cubes = O.pipeline(variant, inp)
+    want = np.loadtxt(os.path.join(GOLD, "ref_outputs", ref))
+    rows = 1 + sum(int(c.t / inp.delta) for c in cubes)
+    assert rows == want.shape[0]
+    first = [0.0, inp.init_s[0], inp.init_l[0], inp.init_s[1], inp.init_l[1], inp.init_s[2], inp.init_l[2]]
+    assert np.abs(want[0] - first).max() <= PRINT
+
+
+def test_w47_is_a_row_of_all_weights():
+    rows = []
+    for line in open(os.path.join(GOLD, "inputs", "all_weights.txt")):
+        try:
+            v = [float(t) for t in line.split()]
+        except ValueError:
+            continue
+        if len(v) >= 10:
+            rows.append(v[:10])
+    assert np.allclose(rows[47], W47)
+    assert np.allclose(np.delete(W47, 6), np.delete(W, 6))
