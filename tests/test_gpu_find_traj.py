@@ -1,0 +1,99 @@
+"""The drop-in boundary on a GPU: libtrp.so / libcub.so / libbtrapz.so called the way the
+reference harness calls them (ctypes, Params by pointer, text file in, text file out)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from helpers import O
+from spectral_amd import native, trp_wrapper, cub_wrapper
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+W = np.loadtxt(os.path.join(GOLD, "inputs", "weights.txt"))
+PRINT = 5.0e-4 + 2e-5
+FEASIBLE = [("c1", 0), ("c1", 1), ("c2", 0), ("c2", 1), ("c3", 0), ("c3", 1), ("c4", 0), ("c4", 1), ("c6", 0), ("c6", 1),
+            ("c_road_s1", 0), ("c_road_s1", 1), ("c_road_s1_3", 0)]
+FAILING = [("c7", 0), ("c7_7", 1), ("c_road_s1_2", 0), ("c_road_s1_2", 1), ("c_road_s1_3", 1)]
+
+
+def call(lib, params, inp, prefix, monkeypatch):
+    monkeypatch.setenv("BTRAPZ_INPUT", inp)
+    monkeypatch.setenv("BTRAPZ_OUTPUT_PREFIX", prefix)
+    monkeypatch.setenv("BTRAPZ_OUTPUT", prefix + "old.txt")
+    l = C.CDLL(os.path.join(native.LIB_DIR, lib))          # exactly trp_wrapper.py:45-54
+    l.find_traj.argtypes = (C.POINTER(trp_wrapper.Params),)
+    l.find_traj.restype = C.c_double
+    return l.find_traj(params)
+
+
+@pytest.mark.parametrize("name,variant", FEASIBLE)
+def test_trajectory_file_matches_oracle_optimum(name, variant, tmp_path, monkeypatch):
+    g = np.load(os.path.join(GOLD, "scenario_xstar.npz"))
+    inp_path = os.path.join(GOLD, "inputs", name + ".txt")
+    prefix = str(tmp_path / "traj_")
+    cost = call("libtrp.so" if variant == 0 else "libcub.so", trp_wrapper.Params(*W, 7), inp_path, prefix, monkeypatch)
+    assert cost != 100000000000.0 and np.isfinite(cost)
+    got = np.loadtxt(prefix + "7.txt")                       # "<prefix><iteration>.txt", trp_wrapper.cpp:288-289
+    traj = g["%s/%d/traj" % (name, variant)]                 # oracle x*, sampled: s ds dds l dl ddl
+    inp = O.ParsedInput(inp_path)
+    want = np.stack([np.arange(traj.shape[1]) * inp.delta, traj[0], traj[3], traj[1], traj[4], traj[2], traj[5]], 1)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= PRINT                 # 3-decimal file vs full-precision optimum
+    # a_cost (trp_wrapper.cpp:217-286 / cub_wrapper.cpp:201-262) recomputed by the oracle on x*'s samples
+    p = O.params_from_weights(W)
+    ref_cost = O.lib().orc_acost(variant, C.byref(p), C.byref(inp.raw), traj.shape[1],
+                                 *[np.ascontiguousarray(traj[i]).ctypes.data_as(C.POINTER(C.c_double)) for i in range(6)])
+    assert abs(cost - ref_cost) <= 1e-6 * abs(ref_cost)
+
+
+@pytest.mark.parametrize("name,variant", FAILING)
+def test_failure_sentinel(name, variant, tmp_path, monkeypatch):
+    cost = call("libtrp.so" if variant == 0 else "libcub.so", trp_wrapper.Params(*W, 1),
+                os.path.join(GOLD, "inputs", name + ".txt"), str(tmp_path / "t_"), monkeypatch)
+    assert cost == 100000000000.0                             # trp_wrapper.cpp:195-200
+    assert not os.path.exists(str(tmp_path / "t_1.txt"))
+
+
+def test_missing_input_returns_sentinel(tmp_path, monkeypatch):
+    assert call("libtrp.so", trp_wrapper.Params(*W, 1), str(tmp_path / "none.txt"), str(tmp_path / "t_"), monkeypatch) == 1e11
+
+
+def test_reference_generated_vector_scenario_2(tmp_path, monkeypatch):
+    """s columns of the reference's own s2_slt_3d_5.txt (input c2, trapezoid): the HIP path's file
+    agrees to one unit of the third decimal."""
+    prefix = str(tmp_path / "s2_")
+    call("libtrp.so", trp_wrapper.Params(*W, 5), os.path.join(GOLD, "inputs", "c2.txt"), prefix, monkeypatch)
+    got = np.loadtxt(prefix + "5.txt"); want = np.loadtxt(os.path.join(GOLD, "ref_outputs", "s2_slt_3d_5.txt"))
+    assert got.shape == want.shape
+    assert np.abs(got[:, [0, 1, 3, 5]] - want[:, [0, 1, 3, 5]]).max() <= 1.0e-3 + 1e-9
+
+
+def test_old_libbtrapz_build(tmp_path, monkeypatch):
+    prefix = str(tmp_path / "x_")
+    cost = call("libbtrapz.so", trp_wrapper.Params(*W, 1), os.path.join(GOLD, "inputs", "c1.txt"), prefix, monkeypatch)
+    assert cost < 1e10 and os.path.exists(prefix + "old.txt")
+
+
+def test_python_mirrors(tmp_path, monkeypatch):
+    monkeypatch.setenv("BTRAPZ_WEIGHTS", os.path.join(GOLD, "inputs", "weights.txt"))
+    monkeypatch.setenv("BTRAPZ_INPUT", os.path.join(GOLD, "inputs", "c1.txt"))
+    monkeypatch.setenv("BTRAPZ_OUTPUT_PREFIX", str(tmp_path / "m_"))
+    assert trp_wrapper.find_traj() is True and os.path.exists(str(tmp_path / "m_3.txt"))
+    assert cub_wrapper.find_traj() is True
+    monkeypatch.setenv("BTRAPZ_INPUT", os.path.join(GOLD, "inputs", "c7.txt"))
+    assert trp_wrapper.find_traj() is False                   # infeasible corridor -> 1e11 -> False
+
+
+def test_find_traj_is_reentrant(tmp_path, monkeypatch):
+    """Two threads through the same library (shared lazily-created context)."""
+    import threading
+    res = {}
+
+    def work(i):
+        p = native.CParams(*[float(v) for v in W], i)
+        res[i] = native.find_traj_native(0, p, os.path.join(GOLD, "inputs", "c1.txt"), str(tmp_path / ("r%d.txt" % i)))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert len(set(res.values())) == 1 and list(res.values())[0] < 1e10

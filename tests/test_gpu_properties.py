@@ -1,0 +1,81 @@
+"""Size-independent properties at BASELINE.json's full sizes (configs 2-4): every candidate
+solved, returned control points feasible for every constraint row, C2-continuous, and no worse
+than the reference algorithm's own answer."""
+import numpy as np
+import pytest
+
+from helpers import O
+from spectral_amd import layout as L
+from spectral_amd import native, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rows(batch, sh, ctrl, axis):
+    """Constraint-row values and bounds of one axis for every candidate/segment (numpy restatement of
+    the row definitions, solve_3d.cc:823-888)."""
+    B, S = batch.B, batch.S
+    c = ctrl[:, axis * 6 * S:(axis + 1) * 6 * S].reshape(B, S, 6)
+    t = batch.seg[L.F_T][:, :, None]
+    val = np.concatenate([t * c, 5 * np.diff(c, axis=2), 20 * np.diff(c, 2, axis=2), 60 * np.diff(c, 3, axis=2)], axis=2)
+    i5 = (np.arange(6) / 5.0)[None, None, :]
+    g = lambda f: batch.seg[f][:, :, None]
+    if axis == 0:
+        lo = g(L.F_DOWN_BIAS) + g(L.F_DOWN_SKEW) * i5 * t; up = g(L.F_UPP_BIAS) + g(L.F_UPP_SKEW) * i5 * t
+        if sh.variant == 1:
+            lo = np.repeat(np.maximum(0.0, lo.max(2, keepdims=True)), 6, 2); up = np.repeat(np.minimum(100.0, up.min(2, keepdims=True)), 6, 2)
+        vlo = np.repeat(g(L.F_DS_LO), 5, 2); vhi = np.repeat(g(L.F_DS_HI), 5, 2)
+        acc, jerk = sh.dds, sh.ddds
+    else:
+        if sh.variant == 0:
+            lo = g(L.F_L_DOWN_BIAS) + g(L.F_L_DOWN_SKEW) * i5 * t; up = g(L.F_L_UPP_BIAS) + g(L.F_L_UPP_SKEW) * i5 * t
+        else:
+            lo = np.repeat(g(L.F_BEG_L), 6, 2); up = np.repeat(g(L.F_END_L), 6, 2)
+        dl = batch.dl_bounds.reshape(B, 1, 5, 2)
+        vlo = np.repeat(dl[..., 0], S, 1); vhi = np.repeat(dl[..., 1], S, 1)
+        acc, jerk = sh.ddl, sh.dddl
+    one = np.ones((B, S, 1))
+    lo = np.concatenate([lo, vlo, acc[0] * t * np.ones((1, 1, 4)), jerk[0] * t * t * np.ones((1, 1, 3))], 2)
+    up = np.concatenate([up, vhi, acc[1] * t * np.ones((1, 1, 4)), jerk[1] * t * t * np.ones((1, 1, 3))], 2)
+    return c, val, lo, up
+
+
+@pytest.mark.parametrize("cfg,B,S,variant", [(2, 4096, 10, 0), (3, 65536, 20, 0), (4, 65536, 20, 1)])
+def test_full_size_batches(cfg, B, S, variant):
+    ctx = native.Context(0)
+    batch, sh = synth.make_batch(B, S, config=cfg, variant=variant)
+    ctrl, cost, status, iters = ctx.solve_host(batch, sh)
+    assert (status == 1).all(), np.unique(status, return_counts=True)
+    assert np.isfinite(ctrl).all() and np.isfinite(cost).all()
+    for axis in (0, 1):
+        c, val, lo, up = rows(batch, sh, ctrl, axis)
+        scale = 1 + np.maximum(np.abs(lo), np.abs(up))
+        assert ((lo - val) / scale).max() <= 1e-7 and ((val - up) / scale).max() <= 1e-7   # primal feasible
+        t = batch.seg[L.F_T]
+        init = batch.init[:, 3 * axis:3 * axis + 3]
+        # initial state and C2 continuity (solve_3d.cc:896-949)
+        assert np.abs(t[:, 0] * c[:, 0, 0] - init[:, 0]).max() <= 1e-9 * (1 + np.abs(init[:, 0]).max())
+        assert np.abs(5 * (c[:, 0, 1] - c[:, 0, 0]) - init[:, 1]).max() <= 1e-9 * 10
+        assert np.abs(20 * (c[:, 0, 0] - 2 * c[:, 0, 1] + c[:, 0, 2]) - init[:, 2] * t[:, 0]).max() <= 1e-8
+        pe = t[:, :-1] * c[:, :-1, 5]; pb = t[:, 1:] * c[:, 1:, 0]
+        assert np.abs(pe - pb).max() <= 1e-9 * (1 + np.abs(pe).max())
+        assert np.abs((c[:, :-1, 5] - c[:, :-1, 4]) - (c[:, 1:, 1] - c[:, 1:, 0])).max() <= 1e-9 * 10
+        ae = (c[:, :-1, 3] - 2 * c[:, :-1, 4] + c[:, :-1, 5]) / t[:, :-1]; ab = (c[:, 1:, 0] - 2 * c[:, 1:, 1] + c[:, 1:, 2]) / t[:, 1:]
+        assert np.abs(ae - ab).max() <= 1e-8
+    # no worse than the reference's algorithm on a sample: obj(x_hip) <= obj(x_osqp) (+ tolerance),
+    # both feasible -> for this strictly convex QP the HIP point is at least as close to the optimum
+    idx = np.linspace(0, B - 1, 24).astype(int)
+    sub = synth.make_batch(B, S, config=cfg, variant=variant)[0]
+    for b in idx:
+        xo, oo, so, _ = O.batch_solve(sub, sh, int(b), int(b) + 1)
+        if so[0] == 1:
+            assert cost[b] <= oo[0] + 1e-4 * abs(oo[0])
+            assert np.abs(ctrl[b] - xo[0]).max() <= 2e-2 * np.abs(xo[0]).max()    # OSQP's own tolerance band
+    # the arg-min is the arg-min
+    import torch
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    o = solver.solve(solver.upload(batch), sh)
+    bi, bc = solver.argmin(o["cost"])
+    torch.cuda.synchronize()
+    assert int(bi[0]) == int(np.argmin(cost)) and float(bc[0]) == cost.min()
