@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--segments", type=int, default=20)
     ap.add_argument("--variant", type=int, default=0, help="0 trapezoid (config 3), 1 cuboid (config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-reps", type=int, default=200,
+                    help="B=1 launches for the p50 latency (0 skips them, e.g. under rocprofv3 so that the "
+                         "kernel's average duration is the batch launch alone)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -67,6 +70,7 @@ def main():
     import torch
     import torch.distributed as dist
     from spectral_amd import native, synth
+    from spectral_amd.dist import global_argmin
     from spectral_amd.solver import BatchSolver
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,18 +93,12 @@ def main():
     batch, shared = synth.make_batch(B, S, config=config, variant=a.variant, seed=synth.SEED_BASE + config + 1000 * rank)
     db = solver.upload(batch)
     index_base = rank * B
-    gathered = [torch.empty(2, dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
 
     def step():
-        o = solver.solve(db, shared)
-        bi, bc = solver.argmin(o["cost"], index_base=index_base)
-        if world > 1:  # (cost, global index) pairs: 16 B per rank over RCCL, then a local min
-            pair = torch.stack([bc[0], bi[0].to(torch.float64)])
-            dist.all_gather(gathered, pair)
-            allp = torch.stack(gathered)
-            w = torch.argmin(allp[:, 0])
-            return o, allp[w, 1].to(torch.int64), allp[w, 0]
-        return o, bi[0], bc[0]
+        o = solver.solve(db, shared)                                   # assembly + solve: one launch
+        bi, bc = solver.argmin(o["cost"], index_base=index_base)       # winner of this rank's shard
+        wc, wi = global_argmin(bc, bi)                                  # N > 1: 16 B per rank over RCCL
+        return o, wi[0], wc[0]
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -118,14 +116,8 @@ def main():
         o = solver.solve(db, shared)
         ev[i][1].record()
         bi, bc = solver.argmin(o["cost"], index_base=index_base)
-        if world > 1:
-            pair = torch.stack([bc[0], bi[0].to(torch.float64)])
-            dist.all_gather(gathered, pair)
-            allp = torch.stack(gathered)
-            w = torch.argmin(allp[:, 0])
-            win_idx, win_cost = allp[w, 1].to(torch.int64), allp[w, 0]
-        else:
-            win_idx, win_cost = bi[0], bc[0]
+        wc, wi = global_argmin(bc, bi)
+        win_idx, win_cost = wi[0], wc[0]
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -168,22 +160,23 @@ def main():
             "winner": {"index": int(win_idx.item()), "cost": float(win_cost.item())},
         }
         # p50 latency of ONE solve (B = 1), inputs resident, including the sync
-        one = solver.upload(batch.slice(0, 1))
-        lat = []
-        for i in range(220):
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            solver.solve(one, shared)
-            torch.cuda.synchronize(dev)
-            lat.append(time.perf_counter() - t1)
-        lat = np.array(lat[20:]) * 1e3
-        out["p50_solve_latency_ms"] = float(np.percentile(lat, 50))
-        out["p99_solve_latency_ms"] = float(np.percentile(lat, 99))
-        lat_h = []
-        b1 = batch.slice(0, 1)
-        for i in range(60):
-            t1 = time.perf_counter(); solver.ctx.solve_host(b1, shared); lat_h.append(time.perf_counter() - t1)
-        out["p50_solve_latency_with_pcie_ms"] = float(np.percentile(np.array(lat_h[10:]) * 1e3, 50))
+        if a.latency_reps > 0:
+            one = solver.upload(batch.slice(0, 1))
+            lat = []
+            for i in range(a.latency_reps + 20):
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                solver.solve(one, shared)
+                torch.cuda.synchronize(dev)
+                lat.append(time.perf_counter() - t1)
+            lat = np.array(lat[20:]) * 1e3
+            out["p50_solve_latency_ms"] = float(np.percentile(lat, 50))
+            out["p99_solve_latency_ms"] = float(np.percentile(lat, 99))
+            lat_h = []
+            b1 = batch.slice(0, 1)
+            for i in range(max(20, a.latency_reps // 4)):
+                t1 = time.perf_counter(); solver.ctx.solve_host(b1, shared); lat_h.append(time.perf_counter() - t1)
+            out["p50_solve_latency_with_pcie_ms"] = float(np.percentile(np.array(lat_h[5:]) * 1e3, 50))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, shared, a.cpu_seconds)
         else:

@@ -1,6 +1,6 @@
 /*
  * btrapz_oracle.c -- CPU restatement of the reference's trajectory QP path.
- * TEST INFRASTRUCTURE ONLY (see btrapz_oracle.h header: "PARITY UNPINNED").
+ * TEST INFRASTRUCTURE ONLY (see btrapz_oracle.h header: "HOW PARITY IS PINNED").
  *
  * Follows, function by function (paths relative to /root/reference):
  *   corridor pipeline  src/solve_3d.cc:323-486,488-714,729-772

@@ -6,16 +6,25 @@
  * in __graft_entry__.py and bench.py's cpu_baseline leg may load it.  The
  * product path (spectral_amd/) never links, imports or calls anything here.
  *
- * PARITY UNPINNED: the reference has no tests and no golden vectors, its
- * sources need Eigen + OSQP (absent from this image, so oracle/_ref cannot be
- * built) and its prebuilt libraries need libosqp.so (absent).  The arithmetic
- * of the solve lives in OSQP (oxfordcontrol/osqp, version unpinned by the
- * reference: only the comment "osqp-0.4.1, 0.5.0" at src/solve_3d.cc:1246),
- * whose published ADMM algorithm is restated in orc_osqp_solve().  What IS
- * pinned: (1) assembly against the closed forms of solve_3d.cc / cuboid_3d.cc,
- * (2) the optimum x* through KKT residuals and an independent third-party QP
- * solver (HiGHS, shipped inside scipy) in tests/, (3) the reference's saved
- * 3-decimal output trajectories as a weak external anchor (tests/golden).
+ * HOW PARITY IS PINNED.  The reference has no tests; its sources need Eigen + OSQP (absent
+ * from this image, so oracle/_ref cannot be built) and its prebuilt libraries need
+ * libosqp.so (absent).  The arithmetic of the solve lives in OSQP (oxfordcontrol/osqp,
+ * version unpinned by the reference: only the comment "osqp-0.4.1, 0.5.0" at
+ * src/solve_3d.cc:1246), whose published ADMM algorithm is restated in orc_osqp_solve().
+ * Pins (tests/test_reference_goldens.py, tests/test_oracle_*.py):
+ *  (1) REFERENCE-GENERATED VECTORS: trajectory files the reference itself wrote
+ *      (tests/golden/ref_outputs).  orc_find_traj() reproduces s4_slt_3d.txt, s4_cub_3d.txt,
+ *      s5_slt_3d.txt (inputs c4.txt / c5.txt, s weights of weights.txt) to print precision
+ *      in every column -- including OSQP's unconverged iterate after 5000 iterations -- and
+ *      the s columns of s2_slt_3d_{4,5}.txt (input c2.txt) with both the ADMM port and x*.
+ *      This pins parser, corridor pipeline, assembly, the ADMM port, sampling and the file
+ *      format on those paths.
+ *  (2) assembly against closed forms independent of the reference's route (Gauss
+ *      quadrature of squared Bernstein derivatives, Bezier derivative control points);
+ *  (3) the optimum x* through a KKT certificate, tight ADMM and a third-party QP solver
+ *      (HiGHS, shipped inside scipy).
+ * Unpinned remainder: where the weights of a saved run are unknown only its row count and
+ * first row are checked, and OSQP's wall-clock-dependent adaptive-rho interval is fixed (25).
  *
  * All citations are file:line relative to /root/reference.
  */
