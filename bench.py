@@ -47,6 +47,21 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(B, S, variant):
+    """HBM bytes per launch from the committed PMC profile of this workload (FETCH_SIZE + WRITE_SIZE,
+    separate rocprofv3 --pmc passes, profiles/*_pmc_hbm.json); None when no profile matches."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if (w.get("batch"), w.get("segments"), w.get("variant")) == (B, S, variant):
+            return float(d["bytes_per_launch_raw"]), os.path.basename(f)
+    return None, None
+
+
 def cpu_baseline(batch, shared, seconds):
     """The reference's algorithm (oracle OSQP port) on the host cores, bounded sample."""
     from oracle import oracle as O
@@ -137,6 +152,7 @@ def main():
         alg_bytes = batch.algorithmic_bytes() * B
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         flops = 2.0 * B * S * mean_iters * FLOPS_PER_SEGMENT_ITER
+        traffic, traffic_src = measured_traffic(B, S, a.variant)
         out = {
             "metric": "trajectory QP solves/sec (20-seg order-5 corridor)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
@@ -147,7 +163,7 @@ def main():
                        "batch_per_gpu": B, "segments": S, "variant": a.variant, "parallelism": "shard%d" % world,
                        "collective": "none" if world == 1 else "rccl all_gather of (cost,index), 16 B per rank"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "btrapz::ipm_solve_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_solve": batch.algorithmic_bytes(),
                          "note": "on-chip solve: the binding resource is FP64 VALU issue + dependent sweeps, not HBM "
