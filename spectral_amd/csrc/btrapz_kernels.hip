@@ -35,14 +35,14 @@ namespace btrapz {
 #define UNROLL _Pragma("unroll")
 #define SYM(i, j) ((j) * ((j) + 1) / 2 + (i))  // i <= j, packed upper triangle, column-wise
 
-// 1/x: v_rcp_f64 seed + two Newton steps (full double accuracy for normal x; no denormal /
-// overflow fix-ups -- every operand here is a positive slack, multiplier or pivot).
+// 1/x: v_rcp_f64 seed (measured 4.6e-8 relative on gfx950) + one Newton step -> 2.2e-15.  No
+// denormal / overflow fix-ups: every operand here is a positive slack, multiplier or pivot.
 __device__ __forceinline__ double rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  return r;
+  const double r = __builtin_amdgcn_rcp(x);
+  return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
 }
+// seed only: good to 5e-8, enough for step-length ratios (they carry a 0.5 % safety factor).
+__device__ __forceinline__ double rcp_fast(double x) { return __builtin_amdgcn_rcp(x); }
 
 // lane i <- lane i-1 / lane i+1 over the whole wavefront (DPP wave_shr:1 / wave_shl:1).
 __device__ __forceinline__ double from_prev(double x) {
@@ -138,14 +138,22 @@ __device__ __forceinline__ void ldl3_solve(const double (&F)[6], double b0, doub
 enum { L_LL = 0, L_LU = 18, L_ISL = 36, L_ISU = 54, L_RED = 72, L_ROWS = 76 };
 
 // Reductions over the S lanes of a group: every lane publishes 4 values, then reads its
-// group's S entries in batches of 8 (reads issued back to back, one wait per batch).
-struct Red4 { double sum, max0, max1, min; };
-__device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gbase, int S, double vsum, double vmax0,
-                                             double vmax1, double vmin) {
+// group's S entries in batches of 8 (reads issued back to back, one wait per batch; fixed order
+// -> bit-reproducible).  OPn: 0 sum, 1 max, 2 min.
+struct Red4 { double a, b, c, d; };
+template <int OP> __device__ __forceinline__ double red_init() { return OP == 0 ? 0.0 : OP == 1 ? -1e300 : 1e300; }
+template <int OP> __device__ __forceinline__ double red_op(double acc, double v, bool in_range) {
+  if constexpr (OP == 0) return acc + (in_range ? v : 0.0);   // padded slots repeat entry S-1: harmless for max/min
+  else if constexpr (OP == 1) return fmax(acc, v);
+  else return fmin(acc, v);
+}
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gbase, int S, double v0, double v1,
+                                             double v2, double v3) {
   __syncthreads();
-  lds[L_RED + 0][lane] = vsum; lds[L_RED + 1][lane] = vmax0; lds[L_RED + 2][lane] = vmax1; lds[L_RED + 3][lane] = vmin;
+  lds[L_RED + 0][lane] = v0; lds[L_RED + 1][lane] = v1; lds[L_RED + 2][lane] = v2; lds[L_RED + 3][lane] = v3;
   __syncthreads();
-  Red4 r = {0.0, 0.0, 0.0, 1e300};
+  Red4 r = {red_init<O0>(), red_init<O1>(), red_init<O2>(), red_init<O3>()};
   for (int j0 = 0; j0 < S; j0 += 8) {
     double a[8], b[8], c[8], d[8];
     UNROLL for (int u = 0; u < 8; u++) {
@@ -153,8 +161,9 @@ __device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gb
       a[u] = lds[L_RED + 0][j]; b[u] = lds[L_RED + 1][j]; c[u] = lds[L_RED + 2][j]; d[u] = lds[L_RED + 3][j];
     }
     UNROLL for (int u = 0; u < 8; u++) {
-      r.sum += (j0 + u < S) ? a[u] : 0.0;  // padded slots repeat entry S-1: harmless for max/min
-      r.max0 = fmax(r.max0, b[u]); r.max1 = fmax(r.max1, c[u]); r.min = fmin(r.min, d[u]);
+      const bool in = j0 + u < S;
+      r.a = red_op<O0>(r.a, a[u], in); r.b = red_op<O1>(r.b, b[u], in);
+      r.c = red_op<O2>(r.c, c[u], in); r.d = red_op<O3>(r.d, d[u], in);
     }
   }
   return r;
@@ -281,8 +290,8 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
     X[0] = Xinit[0] + Xinit[1] * tsum; X[1] = Xinit[1]; X[2] = 0.0;
   }
   {
-    const Red4 r0 = group_reduce(lds, lane, gbase, S, 0.0, bnorm, qn, gapmin);
-    bnorm = r0.max0; qn = r0.max1; gapmin = r0.min;
+    const Red4 r0 = group_reduce<0, 1, 1, 2>(lds, lane, gbase, S, 0.0, bnorm, qn, gapmin);
+    bnorm = r0.b; qn = r0.c; gapmin = r0.d;
   }
   const bool infeasible_bounds = !(gapmin >= 0.0) || !(t > 0.0);
 
@@ -343,12 +352,12 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
       UNROLL for (int i = 0; i < 3; i++) { const double v = from_next(un[i]); rd[i] += last ? 0.0 : v; }
       rd_part = fmax(fabs(rd[0]), fmax(fabs(rd[1]), fabs(rd[2])));
     }
-    const Red4 rr = group_reduce(lds, lane, gbase, S, mu_part, rd_part, rp_part, -dscale);
-    const double mu = rr.sum * inv_m;
+    const Red4 rr = group_reduce<0, 1, 1, 1>(lds, lane, gbase, S, mu_part, rd_part, rp_part, dscale);
+    const double mu = rr.a * inv_m;
     // KKT score: dual residual relative to (1+|q|) with a round-off floor, primal residual
     // relative to the bound scale, complementarity absolute.
-    const double rd_eff = fmax(rr.max0 - 2e-13 * (-rr.min), 0.0);
-    const double score = fmax(fmax(rd_eff / (1.0 + qn), rr.max1 / (1.0 + bnorm)), mu);
+    const double rd_eff = fmax(rr.b - 2e-13 * rr.d, 0.0);
+    const double score = fmax(fmax(rd_eff / (1.0 + qn), rr.c / (1.0 + bnorm)), mu);
     if (!done) {
       iters = iter;
       if (score < best_score) { best_score = score; best_it = iter; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
@@ -421,31 +430,9 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
       }
     }
 
-    // ---- 4. predictor (sigma = 0) and corrector solves ----
-    double sigma_mu = 0.0;
-    double dca[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // predictor direction in control-point space
-    UNROLL for (int pass = 0; pass < 2; ++pass) {
-      // complementarity target of row r in this pass: rc = s*lambda (+ ds_aff*dl_aff - sigma*mu)
-#define ROW_TERMS(r)                                                                             \
-      const double isl = lds[L_ISL + r][lane], isu = lds[L_ISU + r][lane];                          \
-      const double ll = LL(r), lu = LU(r);                                                          \
-      const double gcr = row_dot<r>(c, t);                                                          \
-      const double rpl = gcr - sl[r] - LO(r), rpu = gcr + su[r] - UP(r);                              \
-      double rcl = sl[r] * ll, rcu = su[r] * lu;                                                    \
-      if (pass == 1) {                                                                              \
-        const double ga = row_dot<r>(dca, t);                                                        \
-        const double dsa = ga + rpl, dua = -ga - rpu;                                                \
-        rcl += dsa * (-ll - ll * dsa * isl) - sigma_mu;                                               \
-        rcu += dua * (-lu - lu * dua * isu) - sigma_mu;                                               \
-      }
-      // rhs in c space: h = gc + G' tv ; tv = (rcl + ll rpl)/sl - (rcu - lu rpu)/su
-      double h[6];
-      UNROLL for (int i = 0; i < 6; i++) h[i] = gc[i];
-      PHASE_FENCE(opaque6(c); opaque6(dca));
-      FOR_ROWS(r)
-        ROW_TERMS(r)
-        row_scatter<r>((rcl + ll * rpl) * isl - (rcu - lu * rpu) * isu, t, h);
-      END_ROWS
+    // ---- 4. predictor (sigma = 0), then corrector ----
+    // One solve: rhs u (already reduced to X space) -> dX by the block LDL^T sweeps -> dc.
+    auto solve_dc = [&](const double (&h)[6], double (&dX)[3], double (&dc)[6]) {
       double u[3];
       {
         double hn[3];
@@ -468,7 +455,7 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
         }
       }
       // backward: dX_{k+1} = S_k^{-1} u_k - C_{k+1} dX_{k+2}
-      double v[3], dX[3], w[3];
+      double v[3], w[3];
       ldl3_solve(F, u[0], u[1], u[2], v[0], v[1], v[2]);
       UNROLL for (int i = 0; i < 3; i++) dX[i] = v[i];
       UNROLL for (int i = 0; i < 3; i++) w[i] = C[3 * i] * dX[0] + C[3 * i + 1] * dX[1] + C[3 * i + 2] * dX[2];
@@ -484,58 +471,95 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
           UNROLL for (int i = 0; i < 3; i++) w[i] = C[3 * i] * dX[0] + C[3 * i + 1] * dX[1] + C[3 * i + 2] * dX[2];
         }
       }
-      // directions in the rows: ds = +-(G dc) + rp ; dlambda = (-rc - lambda ds)/s
-      double dc[6];
-      {
-        double dXp[3];
-        UNROLL for (int i = 0; i < 3; i++) { const double vv = from_prev(dX[i]); dXp[i] = first ? 0.0 : vv; }
-        U_apply(nm, dXp, dc[0], dc[1], dc[2]);
-        V_apply(nm, dX, dc[3], dc[4], dc[5]);
-      }
-#define ROW_DIRS(r)                                                                              \
-      const double gd = row_dot<r>(dc, t);                                                          \
-      const double dsl = gd + rpl, dsu = -gd - rpu;                                                 \
-      const double dll = (-rcl - ll * dsl) * isl, dlu = (-rcu - lu * dsu) * isu;
-      // step to the boundary: largest -d/v over the rows, kept as a fraction (no divisions)
-      double pn = 0.0, pd = 1.0, dn = 0.0, dd = 1.0;
+      double dXp[3];
+      UNROLL for (int i = 0; i < 3; i++) { const double vv = from_prev(dX[i]); dXp[i] = first ? 0.0 : vv; }
+      U_apply(nm, dXp, dc[0], dc[1], dc[2]);
+      V_apply(nm, dX, dc[3], dc[4], dc[5]);
+    };
+    // per row: reciprocal slacks and multipliers from this lane's LDS column, residuals from c
+#define ROW_BASE(r)                                                                               \
+      const double isl = lds[L_ISL + r][lane], isu = lds[L_ISU + r][lane];                          \
+      const double ll = LL(r), lu = LU(r);                                                          \
+      const double gcr = row_dot<r>(c, t);                                                          \
+      const double rpl = gcr - sl[r] - LO(r), rpu = gcr + su[r] - UP(r);
+
+    double dca[6], dX[3];
+    double sigma_mu;
+    {
+      // predictor.  rc = s*lambda  ->  tv = lambda_l (s_l + rp_l)/s_l - lambda_u (s_u - rp_u)/s_u
+      double h[6];
+      UNROLL for (int i = 0; i < 6; i++) h[i] = gc[i];
+      PHASE_FENCE(opaque6(c));
+      FOR_ROWS(r)
+        ROW_BASE(r)
+        row_scatter<r>(ll * (sl[r] + rpl) * isl - lu * (su[r] - rpu) * isu, t, h);
+      END_ROWS
+      solve_dc(h, dX, dca);
+      // With rc = s*lambda:  dlambda/lambda = -(1 + ds/s).  Step lengths come from q = ds/s alone, and
+      //   m*mu_aff = (1-ad) S0 + (ap - ad - ap*ad) S1 - ap*ad S4,   S0 = sum s*lambda (= m*mu),
+      //   S1 = sum lambda*ds,  S4 = sum lambda*ds*q        -- no second pass over the rows.
+      double qmin = 0.0, qmax = -1.0, S1 = 0.0, S4 = 0.0;
+      PHASE_FENCE(opaque6(c); opaque6(dca));
+      FOR_ROWS(r)
+        ROW_BASE(r)
+        const double gd = row_dot<r>(dca, t);
+        const double dsl = gd + rpl, dsu = -gd - rpu;
+        const double ql = dsl * isl, qu = dsu * isu;
+        qmin = fmin(qmin, fmin(ql, qu)); qmax = fmax(qmax, fmax(ql, qu));
+        const double al = ll * dsl, au = lu * dsu;
+        S1 += al + au;
+        S4 += al * ql + au * qu;
+      END_ROWS
+      const Red4 ra = group_reduce<0, 0, 1, 2>(lds, lane, gbase, S, S1, S4, qmax, qmin);
+      const double ap = 1.0 / fmax(-ra.d, 1.0), ad = 1.0 / fmax(1.0 + ra.c, 1.0);
+      const double mua = ((1.0 - ad) * rr.a + (ap - ad - ap * ad) * ra.a - ap * ad * ra.b) * inv_m;
+      const double sr = mua / mu;
+      sigma_mu = sr * sr * sr * mu;
+    }
+    {
+      // corrector.  rc = s*lambda + ds_aff*dlambda_aff - sigma*mu , dlambda_aff = -lambda (1 + ds_aff/s)
+#define ROW_CORR(r)                                                                               \
+      const double ga = row_dot<r>(dca, t);                                                         \
+      const double dsa = ga + rpl, dua = -ga - rpu;                                                 \
+      const double rcl = __builtin_fma(sl[r], ll, -sigma_mu) - (ll * dsa) * (1.0 + dsa * isl);      \
+      const double rcu = __builtin_fma(su[r], lu, -sigma_mu) - (lu * dua) * (1.0 + dua * isu);      \
+      const double el = rcl * isl, eu = rcu * isu, wl = ll * isl, wu = lu * isu;
+      double h[6], dc[6];
+      UNROLL for (int i = 0; i < 6; i++) h[i] = gc[i];
+      PHASE_FENCE(opaque6(c); opaque6(dca));
+      FOR_ROWS(r)
+        ROW_BASE(r)
+        ROW_CORR(r)
+        row_scatter<r>((el - eu) + (wl * rpl + wu * rpu), t, h);
+      END_ROWS
+      solve_dc(h, dX, dc);
+      // step to the boundary: ratios -ds/s and -dlambda/lambda (seed reciprocal is enough here)
+      double pr = 0.0, dr = 0.0;
       PHASE_FENCE(opaque6(c); opaque6(dca); opaque6(dc));
       FOR_ROWS(r)
-        ROW_TERMS(r)
-        ROW_DIRS(r)
-        if (-dsl * pd > pn * sl[r]) { pn = -dsl; pd = sl[r]; }
-        if (-dsu * pd > pn * su[r]) { pn = -dsu; pd = su[r]; }
-        if (-dll * dd > dn * ll) { dn = -dll; dd = ll; }
-        if (-dlu * dd > dn * lu) { dn = -dlu; dd = lu; }
+        ROW_BASE(r)
+        ROW_CORR(r)
+        const double gd = row_dot<r>(dc, t);
+        const double dsl = gd + rpl, dsu = -gd - rpu;
+        const double dll = -el - wl * dsl, dlu = -eu - wu * dsu;
+        pr = fmax(pr, fmax(-dsl * isl, -dsu * isu));
+        dr = fmax(dr, fmax(-dll * rcp_fast(ll), -dlu * rcp_fast(lu)));
       END_ROWS
-      const Red4 ra = group_reduce(lds, lane, gbase, S, 0.0, pn * rcp(pd), dn * rcp(dd), 0.0);
-      const double ap = 1.0 / fmax(ra.max0, 1.0), ad = 1.0 / fmax(ra.max1, 1.0);
-      if (pass == 0) {
-        // centering parameter from the predictor: sigma = (mu_aff/mu)^3
-        double mua_part = 0.0;
-        PHASE_FENCE(opaque6(c); opaque6(dc));
-        FOR_ROWS(r)
-          ROW_TERMS(r)
-          ROW_DIRS(r)
-          mua_part += (sl[r] + ap * dsl) * (ll + ad * dll) + (su[r] + ap * dsu) * (lu + ad * dlu);
-        END_ROWS
-        UNROLL for (int i = 0; i < 6; i++) dca[i] = dc[i];
-        const Red4 rm = group_reduce(lds, lane, gbase, S, mua_part, 0.0, 0.0, 0.0);
-        const double sr = rm.sum * inv_m / mu;
-        sigma_mu = sr * sr * sr * mu;
-      } else {
-        const double alpha = done ? 0.0 : fmin(1.0, 0.995 * fmin(ap, ad));
-        UNROLL for (int i = 0; i < 3; i++) X[i] += alpha * dX[i];
-        PHASE_FENCE(opaque6(c); opaque6(dca); opaque6(dc));
-        FOR_ROWS(r)
-          ROW_TERMS(r)
-          ROW_DIRS(r)
-          sl[r] += alpha * dsl; su[r] += alpha * dsu;
-          LL(r) = ll + alpha * dll; LU(r) = lu + alpha * dlu;
-        END_ROWS
-      }
-#undef ROW_TERMS
-#undef ROW_DIRS
+      const Red4 ra = group_reduce<0, 1, 1, 1>(lds, lane, gbase, S, 0.0, pr, dr, 0.0);
+      const double alpha = done ? 0.0 : fmin(1.0, 0.995 / fmax(fmax(ra.b, ra.c), 0.995));
+      UNROLL for (int i = 0; i < 3; i++) X[i] += alpha * dX[i];
+      PHASE_FENCE(opaque6(c); opaque6(dca); opaque6(dc));
+      FOR_ROWS(r)
+        ROW_BASE(r)
+        ROW_CORR(r)
+        const double gd = row_dot<r>(dc, t);
+        const double dsl = gd + rpl, dsu = -gd - rpu;
+        sl[r] += alpha * dsl; su[r] += alpha * dsu;
+        LL(r) = ll + alpha * (-el - wl * dsl); LU(r) = lu + alpha * (-eu - wu * dsu);
+      END_ROWS
+#undef ROW_CORR
     }
+#undef ROW_BASE
   }
 
   // ---------------- write back: control points, per-axis objective/status ------------------
@@ -552,7 +576,7 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
       UNROLL for (int j = 0; j < 6; j++) s += HSYM(Pm, i, j) * c[j];
       obj += c[i] * (0.5 * s + q[i]);
     }
-    const Red4 ro = group_reduce(lds, lane, gbase, S, obj, 0.0, 0.0, 0.0);
+    const Red4 ro = group_reduce<0, 1, 1, 1>(lds, lane, gbase, S, obj, 0.0, 0.0, 0.0);
     if (valid) {
       double *dst = a.ctrl + (size_t)b * 12 * S + (size_t)axis * 6 * S + (size_t)k * 6;
       UNROLL for (int i = 0; i < 6; i++) dst[i] = c[i];
@@ -562,7 +586,7 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
         else if (best_score < 1e-7) st = BTRAPZ_SOLVED;
         else if (best_score < 1e-5) st = BTRAPZ_SOLVED_INACCURATE;
         else st = BTRAPZ_MAX_ITER_REACHED;
-        a.axis_obj[prob] = ro.sum;
+        a.axis_obj[prob] = ro.a;
         a.axis_status[prob] = st;
         a.axis_iters[prob] = iters;
       }
