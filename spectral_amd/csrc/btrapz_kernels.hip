@@ -525,37 +525,37 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
       const double rcu = __builtin_fma(su[r], lu, -sigma_mu) - (lu * dua) * (1.0 + dua * isu);      \
       const double el = rcl * isl, eu = rcu * isu, wl = ll * isl, wu = lu * isu;
       double h[6], dc[6];
+      double el_[18], eu_[18];   // rc/s of the corrected complementarity targets, reused by the two loops below
       UNROLL for (int i = 0; i < 6; i++) h[i] = gc[i];
       PHASE_FENCE(opaque6(c); opaque6(dca));
       FOR_ROWS(r)
         ROW_BASE(r)
         ROW_CORR(r)
+        el_[r] = el; eu_[r] = eu;
         row_scatter<r>((el - eu) + (wl * rpl + wu * rpu), t, h);
       END_ROWS
       solve_dc(h, dX, dc);
       // step to the boundary: ratios -ds/s and -dlambda/lambda (seed reciprocal is enough here)
       double pr = 0.0, dr = 0.0;
-      PHASE_FENCE(opaque6(c); opaque6(dca); opaque6(dc));
+      PHASE_FENCE(opaque6(c); opaque6(dc));
       FOR_ROWS(r)
         ROW_BASE(r)
-        ROW_CORR(r)
         const double gd = row_dot<r>(dc, t);
         const double dsl = gd + rpl, dsu = -gd - rpu;
-        const double dll = -el - wl * dsl, dlu = -eu - wu * dsu;
+        const double dll = -el_[r] - (ll * isl) * dsl, dlu = -eu_[r] - (lu * isu) * dsu;
         pr = fmax(pr, fmax(-dsl * isl, -dsu * isu));
         dr = fmax(dr, fmax(-dll * rcp_fast(ll), -dlu * rcp_fast(lu)));
       END_ROWS
       const Red4 ra = group_reduce<0, 1, 1, 1>(lds, lane, gbase, S, 0.0, pr, dr, 0.0);
       const double alpha = done ? 0.0 : fmin(1.0, 0.995 / fmax(fmax(ra.b, ra.c), 0.995));
       UNROLL for (int i = 0; i < 3; i++) X[i] += alpha * dX[i];
-      PHASE_FENCE(opaque6(c); opaque6(dca); opaque6(dc));
+      PHASE_FENCE(opaque6(c); opaque6(dc));
       FOR_ROWS(r)
         ROW_BASE(r)
-        ROW_CORR(r)
         const double gd = row_dot<r>(dc, t);
         const double dsl = gd + rpl, dsu = -gd - rpu;
         sl[r] += alpha * dsl; su[r] += alpha * dsu;
-        LL(r) = ll + alpha * (-el - wl * dsl); LU(r) = lu + alpha * (-eu - wu * dsu);
+        LL(r) = ll + alpha * (-el_[r] - (ll * isl) * dsl); LU(r) = lu + alpha * (-eu_[r] - (lu * isu) * dsu);
       END_ROWS
 #undef ROW_CORR
     }

