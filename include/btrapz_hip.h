@@ -85,7 +85,10 @@ enum {
   BTRAPZ_SOLVED = 1,
   BTRAPZ_SOLVED_INACCURATE = 2,
   BTRAPZ_MAX_ITER_REACHED = -2,
-  BTRAPZ_PRIMAL_INFEASIBLE = -3
+  BTRAPZ_PRIMAL_INFEASIBLE = -3,
+  BTRAPZ_NO_CORRIDOR = -5 /* ragged batches: the corridor stage selected no segment, more than
+                             seg_stride / 64 segments, or a segment with t <= 0 (the reference's
+                             find_traj fails or aborts on these: solve_3d.cc:617, :1407) */
 };
 
 /* ---- batch layout ------------------------------------------------------------------
@@ -159,6 +162,37 @@ int btrapz_sample_device(btrapz_ctx *ctx, int B, int S, double delta, const doub
                          const double *init, const double *ctrl, int nsel,
                          const long long *sel, int max_points, double *out, int *npoints,
                          void *stream);
+
+/* ---- ragged batches and the device corridor stage -------------------------
+ * Candidates may have different segment counts: seg[f][b][k] and ctrl[b][12*seg_stride] have
+ * seg_stride slots per candidate, seg_count[b] in 1..min(64, seg_stride) of them are used (control
+ * points of candidate b: s axis at ctrl[b][0 .. 6 S_b), l axis at ctrl[b][6 S_b .. 12 S_b)).  Candidates
+ * are bucketed by segment count on the device and every bucket is solved by the same kernel in one
+ * launch; candidates with an unusable count get status BTRAPZ_NO_CORRIDOR and cost +inf. */
+int btrapz_solve_ragged_device(btrapz_ctx *ctx, const btrapz_shared *shared,
+                               const btrapz_options *opt, int B, int seg_stride,
+                               const double *seg, const int *seg_count, const double *init,
+                               const double *ref_end, const double *dl_bounds, double *ctrl,
+                               double *cost, int *status, int *iters, void *stream);
+
+/* CorridorGeneration + CorridorSplit + CollisionCheck for B candidates on the device, straight into
+ * the batch record above (replaces the host loop trp_wrapper.cpp:176-188 for candidate sets).
+ *   s_bounds, l_bounds [B][num_obs][N][2]  per-knot (lower, upper), the order of the input file
+ *   ds_bounds, dl_bounds_knots [B][N][2]   s_ref, l_ref [B][N]
+ * outputs: seg [NUM_SEG_FIELDS][B][seg_stride], seg_count [B] (0: nothing selected, -1: overflow or a
+ * segment with t <= 0), ref_end [B][2], dl_bounds [B][10].  N <= 512, num_obs <= 64. */
+int btrapz_corridor_batch_device(btrapz_ctx *ctx, int variant, int B, int N, int num_obs,
+                                 double delta, const double *s_bounds, const double *l_bounds,
+                                 const double *ds_bounds, const double *dl_bounds_knots,
+                                 const double *s_ref, const double *l_ref, int seg_stride,
+                                 double *seg, int *seg_count, double *ref_end, double *dl_bounds,
+                                 void *stream);
+
+/* btrapz_sample_device for ragged batches (seg_count may be NULL: every candidate has seg_stride). */
+int btrapz_sample_ragged_device(btrapz_ctx *ctx, int B, int seg_stride, const int *seg_count,
+                                double delta, const double *seg, const double *init,
+                                const double *ctrl, int nsel, const long long *sel, int max_points,
+                                double *out, int *npoints, void *stream);
 
 /* Host-pointer convenience wrapper: H2D, solve, D2H, synchronous. */
 int btrapz_solve_batch_host(btrapz_ctx *ctx, const btrapz_shared *shared,

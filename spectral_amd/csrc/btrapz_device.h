@@ -18,7 +18,13 @@ struct Shared {
 };
 
 struct KernelArgs {
-  int B, S;
+  int B, S;                 // S: segments per candidate (uniform mode) / unused (ragged mode)
+  int seg_stride;           // k-stride owner: seg[f][b][k] has seg_stride slots per candidate (== S when uniform)
+  // ragged mode (order != nullptr): candidates bucketed by segment count s = 1..64
+  const int *order;         // [B] candidate ids, stable counting sort by s
+  const int *seg_count;     // [B] s of every candidate (<= 0 or > seg_stride: skipped, status set by the bucket kernel)
+  const int *cand_prefix;   // [66] candidates with count < s
+  const int *wave_prefix;   // [66] wavefront pairs needed by buckets < s
   const double *seg;        // [NUM_SEG_FIELDS][B][S]
   const double *init;       // [B][6]
   const double *ref_end;    // [B][2]
@@ -33,13 +39,31 @@ struct KernelArgs {
   int max_iter;
 };
 
+struct CorridorArgs {
+  int B, N, num_obs, variant, seg_stride;
+  double delta;
+  const double *s_bounds, *l_bounds;   // [B][num_obs][N][2]
+  const double *ds_bounds, *dl_bounds; // [B][N][2]
+  const double *s_ref, *l_ref;         // [B][N]
+  double *seg;                         // [NUM_SEG_FIELDS][B][seg_stride]
+  int *seg_count;                      // [B]
+  double *ref_end;                     // [B][2]
+  double *dl10;                        // [B][10]
+};
+
+__global__ void corridor_batch_kernel(const CorridorArgs a);
+__global__ void bucket_hist_kernel(int B, int seg_stride, const int *seg_count, int *meta);
+__global__ void bucket_prefix_kernel(int *meta);
+__global__ void bucket_scatter_kernel(int B, int seg_stride, const int *seg_count, int *meta, int *order,
+                                      double *axis_obj, int *axis_status, int *axis_iters);
 __global__ void ipm_solve_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void finalize_kernel(int B, const double *axis_obj, const int *axis_status, const int *axis_iters,
                                 double *cost, int *status, int *iters);
 __global__ void argmin_kernel(int group, long long index_base, const double *cost, long long *best_idx,
                               double *best_cost);
-__global__ void sample_kernel(int B, int S, double delta, const double *seg, const double *init, const double *ctrl,
-                              int nsel, const long long *sel, int max_points, double *out, int *npoints);
+__global__ void sample_kernel(int B, int seg_stride, const int *seg_count, double delta, const double *seg,
+                              const double *init, const double *ctrl, int nsel, const long long *sel, int max_points,
+                              double *out, int *npoints);
 
 }  // namespace btrapz
 #endif

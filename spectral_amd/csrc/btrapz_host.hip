@@ -21,6 +21,9 @@ struct btrapz_ctx {
   size_t axis_cap = 0;
   double *d_mqm = nullptr;          // [2][4][21]
   double h_mqm_w[8] = {NAN, NAN, NAN, NAN, NAN, NAN, NAN, NAN};  // weights the table was built for
+  // ragged batches: candidate order by segment count + bucket tables
+  int *d_order = nullptr; size_t order_cap = 0;
+  int *d_meta = nullptr;            // [198] histogram/cand_prefix, wave_prefix, cursors
   // staging for the host-pointer wrapper
   double *d_stage = nullptr; size_t stage_cap = 0;
   int *d_istage = nullptr; size_t istage_cap = 0;
@@ -87,6 +90,7 @@ extern "C" int btrapz_destroy(btrapz_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters);
   (void)hipFree(c->d_mqm); (void)hipFree(c->d_stage); (void)hipFree(c->d_istage);
+  (void)hipFree(c->d_order); (void)hipFree(c->d_meta);
   delete c;
   return BTRAPZ_OK;
 }
@@ -104,13 +108,13 @@ static int ensure_axis_ws(btrapz_ctx *c, size_t nprob) {
   return BTRAPZ_OK;
 }
 
-extern "C" int btrapz_solve_batch_device(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B,
-                                         int S, const double *seg, const double *init, const double *ref_end,
-                                         const double *dl_bounds, double *ctrl, double *cost, int *status, int *iters,
-                                         void *stream_) {
+// Uniform batches: seg_count == nullptr, S segments each.  Ragged: S is the slot stride, seg_count[b] the use.
+static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B, int S,
+                        const int *seg_count, const double *seg, const double *init, const double *ref_end,
+                        const double *dl_bounds, double *ctrl, double *cost, int *status, int *iters, void *stream_) {
   if (!c) return BTRAPZ_EINVAL;
-  if (!sh || B < 1 || S < 1 || S > BTRAPZ_MAX_SEGMENTS || !seg || !init || !ref_end || !dl_bounds || !ctrl || !cost ||
-      !status) {
+  if (!sh || B < 1 || S < 1 || (!seg_count && S > BTRAPZ_MAX_SEGMENTS) || !seg || !init || !ref_end || !dl_bounds ||
+      !ctrl || !cost || !status) {
     c->err = "invalid argument";
     return BTRAPZ_EINVAL;
   }
@@ -129,7 +133,8 @@ extern "C" int btrapz_solve_batch_device(btrapz_ctx *c, const btrapz_shared *sh,
     memcpy(c->h_mqm_w, wkey, sizeof(wkey));
   }
   KernelArgs a;
-  a.B = B; a.S = S; a.seg = seg; a.init = init; a.ref_end = ref_end; a.dl_bounds = dl_bounds; a.mqm = c->d_mqm;
+  a.B = B; a.S = S; a.seg_stride = S; a.order = nullptr; a.seg_count = nullptr; a.cand_prefix = nullptr; a.wave_prefix = nullptr;
+  a.seg = seg; a.init = init; a.ref_end = ref_end; a.dl_bounds = dl_bounds; a.mqm = c->d_mqm;
   a.ctrl = ctrl; a.axis_obj = c->d_axis_obj; a.axis_status = c->d_axis_status; a.axis_iters = c->d_axis_iters;
   memcpy(a.sh.w_s, sh->w_s, sizeof(a.sh.w_s)); memcpy(a.sh.w_l, sh->w_l, sizeof(a.sh.w_l));
   a.sh.weight_end_s = sh->weight_end_s; a.sh.weight_end_l = sh->weight_end_l;
@@ -141,12 +146,70 @@ extern "C" int btrapz_solve_batch_device(btrapz_ctx *c, const btrapz_shared *sh,
   a.sh.variant = sh->variant;
   a.eps = (opt && opt->eps > 0) ? opt->eps : 1e-9;
   a.max_iter = (opt && opt->max_iter > 0) ? opt->max_iter : 60;
-  const int gpw = 64 / S;  // axis problems per wavefront; wave w: axis w&1 of candidates (w>>1)*gpw + [0,gpw)
-  const unsigned blocks = 2u * (unsigned)((B + gpw - 1) / gpw);
+  unsigned blocks;
+  if (seg_count) {
+    if ((size_t)B > c->order_cap) {
+      (void)hipFree(c->d_order); c->d_order = nullptr; c->order_cap = 0;
+      HIPCHK(c, hipMalloc(&c->d_order, sizeof(int) * (size_t)B));
+      c->order_cap = B;
+    }
+    if (!c->d_meta) HIPCHK(c, hipMalloc(&c->d_meta, sizeof(int) * 198));
+    HIPCHK(c, hipMemsetAsync(c->d_meta, 0, sizeof(int) * 198, stream));
+    const unsigned nb = (unsigned)((B + 255) / 256);
+    hipLaunchKernelGGL(bucket_hist_kernel, dim3(nb), dim3(256), 0, stream, B, S, seg_count, c->d_meta);
+    hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(64), 0, stream, c->d_meta);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nb), dim3(256), 0, stream, B, S, seg_count, c->d_meta, c->d_order,
+                       c->d_axis_obj, c->d_axis_status, c->d_axis_iters);
+    HIPCHK(c, hipGetLastError());
+    a.order = c->d_order; a.seg_count = seg_count; a.cand_prefix = c->d_meta; a.wave_prefix = c->d_meta + 66;
+    // upper bound on wavefront pairs without a host round trip: every bucket wastes less than one pair
+    blocks = 2u * (unsigned)(B + 64);
+  } else {
+    const int gpw = 64 / S;  // axis problems per wavefront; wave w: axis w&1 of candidates (w>>1)*gpw + [0,gpw)
+    blocks = 2u * (unsigned)((B + gpw - 1) / gpw);
+  }
   hipLaunchKernelGGL(ipm_solve_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, B, c->d_axis_obj, c->d_axis_status,
                      c->d_axis_iters, cost, status, iters);
+  HIPCHK(c, hipGetLastError());
+  return BTRAPZ_OK;
+}
+
+extern "C" int btrapz_solve_batch_device(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B,
+                                         int S, const double *seg, const double *init, const double *ref_end,
+                                         const double *dl_bounds, double *ctrl, double *cost, int *status, int *iters,
+                                         void *stream) {
+  return solve_common(c, sh, opt, B, S, nullptr, seg, init, ref_end, dl_bounds, ctrl, cost, status, iters, stream);
+}
+
+extern "C" int btrapz_solve_ragged_device(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B,
+                                          int seg_stride, const double *seg, const int *seg_count, const double *init,
+                                          const double *ref_end, const double *dl_bounds, double *ctrl, double *cost,
+                                          int *status, int *iters, void *stream) {
+  if (c && !seg_count) { c->err = "seg_count is null"; return BTRAPZ_EINVAL; }
+  return solve_common(c, sh, opt, B, seg_stride, seg_count, seg, init, ref_end, dl_bounds, ctrl, cost, status, iters,
+                      stream);
+}
+
+extern "C" int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B, int N, int num_obs, double delta,
+                                            const double *s_bounds, const double *l_bounds, const double *ds_bounds,
+                                            const double *dl_bounds_knots, const double *s_ref, const double *l_ref,
+                                            int seg_stride, double *seg, int *seg_count, double *ref_end,
+                                            double *dl_bounds, void *stream) {
+  if (!c) return BTRAPZ_EINVAL;
+  if (variant < 0 || variant > 1 || B < 1 || N < 3 || N > 512 || num_obs < 1 || num_obs > 64 || !(delta > 0) ||
+      seg_stride < 1 || !s_bounds || !l_bounds || !ds_bounds || !dl_bounds_knots || !s_ref || !l_ref || !seg ||
+      !seg_count || !ref_end || !dl_bounds) {
+    c->err = "invalid argument";
+    return BTRAPZ_EINVAL;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  CorridorArgs a;
+  a.B = B; a.N = N; a.num_obs = num_obs; a.variant = variant; a.seg_stride = seg_stride; a.delta = delta;
+  a.s_bounds = s_bounds; a.l_bounds = l_bounds; a.ds_bounds = ds_bounds; a.dl_bounds = dl_bounds_knots;
+  a.s_ref = s_ref; a.l_ref = l_ref; a.seg = seg; a.seg_count = seg_count; a.ref_end = ref_end; a.dl10 = dl_bounds;
+  hipLaunchKernelGGL(corridor_batch_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
   HIPCHK(c, hipGetLastError());
   return BTRAPZ_OK;
 }
@@ -170,8 +233,24 @@ extern "C" int btrapz_sample_device(btrapz_ctx *c, int B, int S, double delta, c
     c->err = "invalid argument"; return BTRAPZ_EINVAL;
   }
   HIPCHK(c, hipSetDevice(c->device));
-  hipLaunchKernelGGL(sample_kernel, dim3(nsel), dim3(64), 0, (hipStream_t)stream_, B, S, delta, seg, init, ctrl, nsel,
-                     sel, max_points, out, npoints);
+  hipLaunchKernelGGL(sample_kernel, dim3(nsel), dim3(64), 0, (hipStream_t)stream_, B, S, (const int *)nullptr, delta, seg,
+                     init, ctrl, nsel, sel, max_points, out, npoints);
+  HIPCHK(c, hipGetLastError());
+  return BTRAPZ_OK;
+}
+
+extern "C" int btrapz_sample_ragged_device(btrapz_ctx *c, int B, int seg_stride, const int *seg_count, double delta,
+                                           const double *seg, const double *init, const double *ctrl, int nsel,
+                                           const long long *sel, int max_points, double *out, int *npoints,
+                                           void *stream_) {
+  if (!c) return BTRAPZ_EINVAL;
+  if (B < 1 || seg_stride < 1 || nsel < 1 || !(delta > 0) || !seg || !init || !ctrl || !sel || !out || !npoints ||
+      max_points < 1) {
+    c->err = "invalid argument"; return BTRAPZ_EINVAL;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(sample_kernel, dim3(nsel), dim3(64), 0, (hipStream_t)stream_, B, seg_stride, seg_count, delta, seg,
+                     init, ctrl, nsel, sel, max_points, out, npoints);
   HIPCHK(c, hipGetLastError());
   return BTRAPZ_OK;
 }

@@ -174,25 +174,35 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
   __shared__ double lds[L_ROWS][64];
 
   const int lane = threadIdx.x;
-  const int S = a.S;
+  // wave w solves axis (w & 1) of gpw consecutive candidates: the axis is wave-uniform
+  const int axis = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 1));
+  int S, pair = (int)(blockIdx.x >> 1), ncand = a.B, cand0 = 0;
+  if (a.order) {
+    // ragged batch: candidates are bucketed by segment count; find this wave's bucket (wave-uniform)
+    if (pair >= a.wave_prefix[65]) return;
+    int s = 1;
+    while (a.wave_prefix[s + 1] <= pair) ++s;
+    S = s; pair -= a.wave_prefix[s]; cand0 = a.cand_prefix[s]; ncand = a.cand_prefix[s + 1] - cand0;
+  } else {
+    S = a.S;
+  }
+  S = __builtin_amdgcn_readfirstlane(S);
   const int gpw = 64 / S;
   const int g = lane / S;
   const int k = lane - g * S;
   const bool lane_in_group = g < gpw;
   const int gl = lane_in_group ? g : gpw - 1;
   const int gbase = gl * S;
-  // wave w solves axis (w & 1) of candidates (w >> 1) * gpw + [0, gpw): the axis is wave-uniform
-  const int axis = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 1));
-  long long cand = (long long)(blockIdx.x >> 1) * gpw + gl;
-  const bool valid = lane_in_group && cand < a.B;
-  if (cand >= a.B) cand = a.B - 1;
-  const int b = (int)cand;
+  long long cand = (long long)pair * gpw + gl;
+  const bool valid = lane_in_group && cand < ncand;
+  if (cand >= ncand) cand = ncand - 1;
+  const int b = a.order ? a.order[cand0 + (int)cand] : (int)cand;
   const long long prob = 2LL * b + axis;
   const bool first = (k == 0), last = (k == S - 1);
 
   // ---------------- load the segment record (coalesced: lanes -> consecutive (b,k)) ----------
-  const size_t BS = (size_t)a.B * S;
-  const size_t e = (size_t)b * S + k;
+  const size_t BS = (size_t)a.B * a.seg_stride;
+  const size_t e = (size_t)b * a.seg_stride + k;
   const double *sg = a.seg;
   const double t = sg[BTRAPZ_F_T * BS + e];
   const double it = 1.0 / t;
@@ -352,6 +362,11 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
       UNROLL for (int i = 0; i < 3; i++) { const double v = from_next(un[i]); rd[i] += last ? 0.0 : v; }
       rd_part = fmax(fabs(rd[0]), fmax(fabs(rd[1]), fabs(rd[2])));
     }
+    // fmax/fmin ignore NaN: a lane whose residuals are not finite must poison its group's score, or a NaN
+    // iterate would be ranked by mu alone and could be kept as the best one.
+    if (!(mu_part == mu_part) || !(rd_part == rd_part) || !(rp_part == rp_part) || !(dscale == dscale) ||
+        !(fabs(rd_part) < 1e300) || !(fabs(mu_part) < 1e300))
+      rp_part = 1e300;
     const Red4 rr = group_reduce<0, 1, 1, 1>(lds, lane, gbase, S, mu_part, rd_part, rp_part, dscale);
     const double mu = rr.a * inv_m;
     // KKT score: dual residual relative to (1+|q|) with a round-off floor, primal residual
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
       iters = iter;
       if (score < best_score) { best_score = score; best_it = iter; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
 #ifndef ABL_FIXED
-      if (score < eps || (best_score < 1e-5 && iter - best_it >= 3) || !(score == score)) done = true;
+      if (score < eps || (best_score < 1e-5 && iter - best_it >= 3) || !(score < 1e299)) done = true;
 #endif
     }
     if (__all(done)) break;
@@ -547,16 +562,20 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
         dr = fmax(dr, fmax(-dll * rcp_fast(ll), -dlu * rcp_fast(lu)));
       END_ROWS
       const Red4 ra = group_reduce<0, 1, 1, 1>(lds, lane, gbase, S, 0.0, pr, dr, 0.0);
-      const double alpha = done ? 0.0 : fmin(1.0, 0.995 / fmax(fmax(ra.b, ra.c), 0.995));
-      UNROLL for (int i = 0; i < 3; i++) X[i] += alpha * dX[i];
-      PHASE_FENCE(opaque6(c); opaque6(dc));
-      FOR_ROWS(r)
-        ROW_BASE(r)
-        const double gd = row_dot<r>(dc, t);
-        const double dsl = gd + rpl, dsu = -gd - rpu;
-        sl[r] += alpha * dsl; su[r] += alpha * dsu;
-        LL(r) = ll + alpha * (-el_[r] - (ll * isl) * dsl); LU(r) = lu + alpha * (-eu_[r] - (lu * isu) * dsu);
-      END_ROWS
+      const double alpha = fmin(1.0, 0.995 / fmax(fmax(ra.b, ra.c), 0.995));
+      // a finished group keeps its state (a branch, not alpha = 0: 0 * inf would poison it); a step that is
+      // not finite is not taken either -- the score of the unchanged iterate then stalls and the group stops
+      if (!done && alpha == alpha) {
+        UNROLL for (int i = 0; i < 3; i++) X[i] += alpha * dX[i];
+        PHASE_FENCE(opaque6(c); opaque6(dc));
+        FOR_ROWS(r)
+          ROW_BASE(r)
+          const double gd = row_dot<r>(dc, t);
+          const double dsl = gd + rpl, dsu = -gd - rpu;
+          sl[r] += alpha * dsl; su[r] += alpha * dsu;
+          LL(r) = ll + alpha * (-el_[r] - (ll * isl) * dsl); LU(r) = lu + alpha * (-eu_[r] - (lu * isu) * dsu);
+        END_ROWS
+      }
 #undef ROW_CORR
     }
 #undef ROW_BASE
@@ -578,7 +597,8 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
     }
     const Red4 ro = group_reduce<0, 1, 1, 1>(lds, lane, gbase, S, obj, 0.0, 0.0, 0.0);
     if (valid) {
-      double *dst = a.ctrl + (size_t)b * 12 * S + (size_t)axis * 6 * S + (size_t)k * 6;
+      // control points in the reference's order: s axis (6 S), then l axis (6 S); rows are 12*seg_stride apart
+      double *dst = a.ctrl + (size_t)b * 12 * a.seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
       UNROLL for (int i = 0; i < 6; i++) dst[i] = c[i];
       if (first) {
         int st;
@@ -640,17 +660,20 @@ __global__ __launch_bounds__(256) void argmin_kernel(int group, long long index_
 
 // ---- Bernstein sampling of selected candidates (solve_3d.cc:1279-1392) ---------------------
 // one block per selected candidate; thread = sample point.
-__global__ void sample_kernel(int B, int S, double delta, const double *seg, const double *init, const double *ctrl,
-                              int nsel, const long long *sel, int max_points, double *out, int *npoints) {
+__global__ void sample_kernel(int B, int seg_stride, const int *seg_count, double delta, const double *seg,
+                              const double *init, const double *ctrl, int nsel, const long long *sel, int max_points,
+                              double *out, int *npoints) {
   const int j = blockIdx.x;
   if (j >= nsel) return;
   const long long b = sel[j];
   double *o = out + (size_t)j * 6 * max_points;
   if (b < 0 || b >= B) { if (threadIdx.x == 0) npoints[j] = 0; return; }
-  const size_t BS = (size_t)B * S;
+  const int S = seg_count ? seg_count[b] : seg_stride;
+  if (S < 1 || S > seg_stride) { if (threadIdx.x == 0) npoints[j] = 0; return; }
+  const size_t BS = (size_t)B * seg_stride;
   // num_of_points_: int accumulated with += double (solve_3d.cc:1279-1282)
   int np = 1;
-  for (int k = 0; k < S; k++) np = (int)((double)np + seg[BTRAPZ_F_T * BS + b * S + k] / delta);
+  for (int k = 0; k < S; k++) np = (int)((double)np + seg[BTRAPZ_F_T * BS + b * seg_stride + k] / delta);
   if (threadIdx.x == 0) npoints[j] = np;
   if (threadIdx.x == 0 && max_points > 0) {
     UNROLL for (int a = 0; a < 6; a++) o[(size_t)a * max_points] = init[b * 6 + a];
@@ -658,7 +681,7 @@ __global__ void sample_kernel(int B, int S, double delta, const double *seg, con
   const double bc0[6] = {1, 5, 10, 10, 5, 1}, bc1[5] = {1, 4, 6, 4, 1}, bc2[4] = {1, 3, 3, 1};
   int base = 1;
   for (int k = 0; k < S; k++) {
-    const double t = seg[BTRAPZ_F_T * BS + b * S + k];
+    const double t = seg[BTRAPZ_F_T * BS + b * seg_stride + k];
     const int linter = (int)(t / delta);  // :1351
     for (int l = 1 + (int)threadIdx.x; l <= linter; l += blockDim.x) {
       const int vi = base + l - 1;
@@ -668,7 +691,7 @@ __global__ void sample_kernel(int B, int S, double delta, const double *seg, con
       pw[0] = 1.0; qw[0] = 1.0;
       UNROLL for (int i = 1; i < 6; i++) { pw[i] = pw[i - 1] * tau; qw[i] = qw[i - 1] * om; }
       UNROLL for (int ax = 0; ax < 2; ax++) {
-        const double *c = ctrl + (size_t)b * 12 * S + (size_t)ax * 6 * S + (size_t)k * 6;
+        const double *c = ctrl + (size_t)b * 12 * seg_stride + (size_t)ax * 6 * S + (size_t)k * 6;
         double x = 0, dx = 0, ddx = 0;
         UNROLL for (int i = 0; i < 6; i++) x += c[i] * bc0[i] * pw[i] * qw[5 - i];
         UNROLL for (int i = 0; i < 5; i++) dx += 5.0 * (c[i + 1] - c[i]) * bc1[i] * pw[i] * qw[4 - i];

@@ -1,0 +1,190 @@
+// corridor_core.h -- the corridor stage on fixed-capacity arrays, compiled for host AND device.
+//
+// One implementation serves both the C++ find_traj driver (corridor.cpp) and the batched device
+// pipeline (corridor_kernels.hip).  Restates (file:line in /root/reference)
+//   CorridorGeneration  src/solve_3d.cc:323-486   src/cuboid_3d.cc:301-407
+//   CorridorSplit       src/solve_3d.cc:729-772   src/cuboid_3d.cc:588-625
+//   CollisionCheck      src/solve_3d.cc:488-714   src/cuboid_3d.cc:409-573
+// with the reference's arithmetic kept expression by expression (several factors of its edge
+// functions are identically zero; `(k*d + b) - b` is NOT simplified: it is not k*d in floating point).
+#ifndef BTRAPZ_CORRIDOR_CORE_H
+#define BTRAPZ_CORRIDOR_CORE_H
+
+#if defined(__HIPCC__)
+#define BTRAPZ_HD __host__ __device__ inline
+#else
+#define BTRAPZ_HD inline
+#endif
+
+#include <math.h>
+
+namespace btrapz {
+
+// One corridor segment == the reference's Cube (include/btrapz/cube_type.h:2-24).  POD: usable in LDS.
+struct Seg {
+  int beg_t, end_t;
+  double t;
+  double beg_l, end_l;
+  double upp_skew, upp_bias, down_skew, down_bias;
+  double l_upp_skew, l_upp_bias, l_down_skew, l_down_bias;
+  int count;
+};
+
+BTRAPZ_HD Seg seg_default() {  // Cube::Cube(), cube_type.h:12-21
+  Seg s;
+  s.beg_t = 0; s.end_t = 0; s.t = 0.0; s.beg_l = 0.0; s.end_l = 0.0;
+  s.upp_skew = 0.0; s.upp_bias = 1000.0; s.down_skew = 0.0; s.down_bias = 0.0;
+  s.l_upp_skew = 0.0; s.l_upp_bias = 1000.0; s.l_down_skew = 0.0; s.l_down_bias = 0.0;
+  s.count = 0;
+  return s;
+}
+
+// Per-knot bounds as interleaved (lower, upper) pairs with an element stride, so the same code reads
+// a std::vector<pair>, a file-ordered [N][2] block or an LDS staging buffer.
+struct BoundsView {
+  const double *p;
+  BTRAPZ_HD double lo(int i) const { return p[2 * i]; }
+  BTRAPZ_HD double hi(int i) const { return p[2 * i + 1]; }
+};
+
+// ---- CorridorGeneration + CorridorSplit for one obstacle.  Returns the number of segments written,
+// or -1 when `cap` is too small.
+BTRAPZ_HD int extract_segments_core(int variant, int N, double delta, BoundsView sb, BoundsView lb, Seg *v, int cap) {
+  if (cap < 1 || N < 3) return -1;
+  int n = 0;
+  {
+    Seg s = seg_default();
+    s.beg_t = 0;
+    s.down_skew = (sb.lo(1) - sb.lo(0)) / delta; s.down_bias = sb.lo(0);
+    s.upp_skew = (sb.hi(1) - sb.hi(0)) / delta; s.upp_bias = sb.hi(0);
+    if (variant == 0) {  // solve_3d.cc:338-341
+      s.l_down_skew = (lb.lo(1) - lb.lo(0)) / delta; s.l_down_bias = lb.lo(0);
+      s.l_upp_skew = (lb.hi(1) - lb.hi(0)) / delta; s.l_upp_bias = lb.hi(0);
+    }
+    s.beg_l = lb.lo(0); s.end_l = lb.hi(0);
+    v[n++] = s;
+  }
+  const double threshold = 0.2;  // solve_3d.cc:372
+  for (int i = 2; i < N - 1; i++) {
+    const double dskew = (sb.lo(i) - sb.lo(i - 1)) / delta, uskew = (sb.hi(i) - sb.hi(i - 1)) / delta;
+    if (fabs(dskew - v[n - 1].down_skew) > threshold || fabs(uskew - v[n - 1].upp_skew) > threshold) {
+      if (n + 1 > cap) return -1;
+      v[n - 1].end_t = i;
+      Seg s = seg_default();
+      s.beg_t = i;
+      s.down_skew = (sb.lo(i + 1) - sb.lo(i)) / delta; s.down_bias = sb.lo(i);
+      s.upp_skew = (sb.hi(i + 1) - sb.hi(i)) / delta; s.upp_bias = sb.hi(i);
+      s.beg_l = lb.lo(i); s.end_l = lb.hi(i);
+      if (variant == 0) {  // solve_3d.cc:358-367: the l line of a later segment is the backward difference at i
+        s.l_down_bias = lb.lo(i); s.l_upp_bias = lb.hi(i);
+        s.l_down_skew = (lb.lo(i) - lb.lo(i - 1)) / delta; s.l_upp_skew = (lb.hi(i) - lb.hi(i - 1)) / delta;
+      }
+      v[n++] = s;
+    }
+  }
+  v[n - 1].end_t = N - 1;
+  for (int i = 0; i < n; i++) v[i].t = (v[i].end_t - v[i].beg_t) * delta;
+  // CorridorSplit: peel 1.0 s / 10-knot pieces (the reference hard-codes delta = 0.1: solve_3d.cc:735-746)
+  for (int k = 0; k < n; k++) {
+    while (v[k].t > 1) {
+      if (n + 1 > cap) return -1;
+      Seg rest = v[k];
+      rest.t = rest.t - 1;
+      Seg head = seg_default();
+      head.beg_t = rest.beg_t;
+      head.end_t = head.beg_t + 10;
+      head.t = 1.0;
+      head.down_skew = rest.down_skew; head.down_bias = rest.down_bias;
+      head.upp_skew = rest.upp_skew; head.upp_bias = rest.upp_bias;
+      if (variant == 0) {
+        head.l_down_skew = rest.l_down_skew; head.l_down_bias = rest.l_down_bias;
+        head.l_upp_skew = rest.l_upp_skew; head.l_upp_bias = rest.l_upp_bias;
+      }
+      head.beg_l = rest.beg_l; head.end_l = rest.end_l;
+      rest.beg_t = rest.beg_t + 10;
+      rest.down_bias = head.down_bias + 1.0 * head.down_skew;
+      rest.upp_bias = head.upp_bias + 1.0 * head.upp_skew;
+      for (int j = n; j > k + 1; j--) v[j] = v[j - 1];  // insert(head) before position k
+      v[k] = head; v[k + 1] = rest;
+      n++; k++;
+    }
+  }
+  return n;
+}
+
+BTRAPZ_HD bool same_segment(const Seg &a, const Seg &b) {  // solve_3d.cc:621
+  return a.beg_t == b.beg_t && a.end_t == b.end_t && a.down_bias == b.down_bias && a.down_skew == b.down_skew &&
+         a.upp_bias == b.upp_bias && a.upp_skew == b.upp_skew && a.beg_l == b.beg_l && a.end_l == b.end_l;
+}
+
+// Point-in-quadrilateral by the signs of four edge functions (solve_3d.cc:534-581).
+BTRAPZ_HD bool knot_inside(const Seg &c, double s, double l, double knot, double delta) {
+  if (!(l <= c.end_l && l >= c.beg_l)) return false;
+  const double d0 = (s - c.down_bias) * (c.beg_t - c.beg_t) - (knot - c.beg_t) * (c.upp_bias - c.down_bias);
+  const double d1 = (s - c.upp_bias) * (c.end_t - c.beg_t) - (knot - c.beg_t) * (c.upp_skew * delta + c.upp_bias - c.upp_bias);
+  const double d2 = (s - c.upp_bias - c.upp_skew * delta) * (c.end_t - c.end_t) -
+                    (knot - c.end_t) * (c.down_skew * delta + c.down_bias - c.upp_skew * delta - c.upp_bias);
+  const double d3 = (s - c.down_bias - c.down_skew * delta) * (c.beg_t - c.end_t) -
+                    (knot - c.end_t) * (c.down_bias - c.down_skew * delta - c.down_bias);
+  const bool pos = d0 > 0 || d1 > 0 || d2 > 0 || d3 > 0;
+  const bool neg = d0 < 0 || d1 < 0 || d2 < 0 || d3 < 0;
+  return !(pos && neg);
+}
+
+// The reference takes a segment each time a running hit counter reaches 3; the counter is shared by all
+// segments of all obstacles and reset only when a segment is taken (solve_3d.cc:584-596).  Given the
+// number of reference knots inside a segment and the counter carried in, this returns how many copies the
+// reference pushes (>= 1 means the segment is selected; later copies are exact duplicates, removed by its
+// de-dup pass) and updates the counter.
+BTRAPZ_HD int selection_pushes(int hits_inside, int &carry) {
+  const int total = carry + hits_inside;
+  carry = total % 3;
+  return total / 3;
+}
+
+// De-dup (keep first), then ordering and time-overlap resolution: solve_3d.cc:617-703 (trapezoid),
+// cuboid_3d.cc:538-567 (cuboid: no sort, no reorder, every later twin, a third of the span).
+BTRAPZ_HD int order_segments_core(int variant, double delta, Seg *v, int n) {
+  for (int i = 0; i + 1 < n; i++)
+    for (int j = i + 1; j < n;) {
+      if (same_segment(v[i], v[j])) { for (int m = j; m + 1 < n; m++) v[m] = v[m + 1]; n--; } else j++;
+    }
+  if (variant == 0) {
+    for (int i = 1; i < n; i++) {  // stable insertion sort by beg_t (libstdc++'s behaviour for n <= 16)
+      const Seg x = v[i];
+      int j = i - 1;
+      while (j >= 0 && x.beg_t < v[j].beg_t) { v[j + 1] = v[j]; j--; }
+      v[j + 1] = x;
+    }
+    for (int i = 0; i + 1 < n; i++)  // pull a segment that continues segment i's lane next to it
+      for (int j = i + 1; j < n; j++) {
+        if (v[i].beg_l == v[j].beg_l && j - i == 1) break;
+        for (int k = j + 1; k < n; k++)
+          if (v[i].beg_l == v[k].beg_l && v[i].end_t == v[k].beg_t) { const Seg x = v[j]; v[j] = v[k]; v[k] = x; break; }
+      }
+    for (int i = 0; i + 1 < n; i++) {  // overlaps between neighbours
+      Seg &a = v[i], &b = v[i + 1];
+      if (a.beg_t == b.beg_t && a.end_t == b.end_t) {
+        const int half = (a.end_t - a.beg_t) / 2;
+        a.end_t -= half; a.t = (a.end_t - a.beg_t) * delta;
+        b.beg_t += half; b.t = (b.end_t - b.beg_t) * delta;
+      } else if (a.beg_t > b.beg_t && a.end_t <= b.end_t) {
+        const int half = (a.end_t - a.beg_t) / 2;
+        if (half > 1) { a.end_t -= half; a.t = (a.end_t - a.beg_t) * delta; }
+        b.beg_t = a.end_t; b.t = (b.end_t - b.beg_t) * delta;
+      }
+    }
+  } else {
+    for (int i = 0; i + 1 < n; i++)
+      for (int j = i + 1; j < n; j++)
+        if (v[i].beg_t == v[j].beg_t && v[i].end_t == v[j].end_t) {
+          const int third = (v[i].end_t - v[i].beg_t) / 3;
+          v[i].end_t -= third; v[i].t = (v[i].end_t - v[i].beg_t) * delta;
+          v[j].beg_t += third; v[j].t = (v[j].end_t - v[j].beg_t) * delta;
+        }
+  }
+  return n;
+}
+
+}  // namespace btrapz
+#endif

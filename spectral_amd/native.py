@@ -67,7 +67,8 @@ class CSegment(C.Structure):
 
 EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "btrapz_destroy", "btrapz_last_error",
            "btrapz_device_count", "btrapz_solve_batch_device", "btrapz_argmin_device",
-           "btrapz_sample_device", "btrapz_solve_batch_host")
+           "btrapz_sample_device", "btrapz_solve_batch_host", "btrapz_solve_ragged_device",
+           "btrapz_corridor_batch_device", "btrapz_sample_ragged_device")
 
 
 def build(verbose=False):
@@ -121,6 +122,12 @@ def lib():
                                            dp, ip, vp]
         l.btrapz_solve_batch_host.argtypes = [vp, C.POINTER(CShared), C.POINTER(COptions), C.c_int, C.c_int,
                                               dp, dp, dp, dp, dp, dp, ip, ip]
+        l.btrapz_solve_ragged_device.argtypes = [vp, C.POINTER(CShared), C.POINTER(COptions), C.c_int, C.c_int,
+                                                 dp, ip, dp, dp, dp, dp, dp, ip, ip, vp]
+        l.btrapz_corridor_batch_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                                   dp, dp, dp, dp, dp, dp, C.c_int, dp, ip, dp, dp, vp]
+        l.btrapz_sample_ragged_device.argtypes = [vp, C.c_int, C.c_int, ip, C.c_double, dp, dp, dp, C.c_int, llp,
+                                                  C.c_int, dp, ip, vp]
         _lib = l
     return _lib
 
@@ -177,6 +184,32 @@ class Context:
                                                     ptr(ref_end), ptr(dl_bounds), ptr(ctrl), ptr(cost),
                                                     ptr(status), ptr(iters), C.c_void_p(stream or 0)),
                     "btrapz_solve_batch_device")
+
+    def solve_ragged_device(self, B, seg_stride, shared, seg, seg_count, init, ref_end, dl_bounds, ctrl, cost,
+                            status, iters=None, stream=None, max_iter=0, eps=0.0):
+        sh = CShared.from_shared(shared); opt = COptions(int(max_iter), float(eps))
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self._check(lib().btrapz_solve_ragged_device(self._h, C.byref(sh), C.byref(opt), B, seg_stride, ptr(seg),
+                                                     ptr(seg_count), ptr(init), ptr(ref_end), ptr(dl_bounds),
+                                                     ptr(ctrl), ptr(cost), ptr(status), ptr(iters),
+                                                     C.c_void_p(stream or 0)), "btrapz_solve_ragged_device")
+
+    def corridor_batch_device(self, variant, B, N, num_obs, delta, s_bounds, l_bounds, ds_bounds, dl_bounds_knots,
+                              s_ref, l_ref, seg_stride, seg, seg_count, ref_end, dl_bounds, stream=None):
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        self._check(lib().btrapz_corridor_batch_device(self._h, int(variant), B, N, num_obs, float(delta),
+                                                       ptr(s_bounds), ptr(l_bounds), ptr(ds_bounds),
+                                                       ptr(dl_bounds_knots), ptr(s_ref), ptr(l_ref), seg_stride,
+                                                       ptr(seg), ptr(seg_count), ptr(ref_end), ptr(dl_bounds),
+                                                       C.c_void_p(stream or 0)), "btrapz_corridor_batch_device")
+
+    def sample_ragged_device(self, B, seg_stride, seg_count, delta, seg, init, ctrl, sel, max_points, out, npoints,
+                             stream=None):
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self._check(lib().btrapz_sample_ragged_device(self._h, B, seg_stride, ptr(seg_count), float(delta), ptr(seg),
+                                                      ptr(init), ptr(ctrl), int(sel.numel()), ptr(sel),
+                                                      int(max_points), ptr(out), ptr(npoints),
+                                                      C.c_void_p(stream or 0)), "btrapz_sample_ragged_device")
 
     def argmin_device(self, B, group, index_base, cost, best_idx, best_cost, stream=None):
         ptr = lambda t: C.c_void_p(t.data_ptr())

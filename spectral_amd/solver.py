@@ -47,6 +47,37 @@ class BatchSolver:
                               o["ctrl"], o["cost"], o["status"], o["iters"], stream=stream, max_iter=max_iter, eps=eps)
         return o
 
+    def corridor_batch(self, kb, variant, seg_stride=16):
+        """Device corridor stage on a spectral_amd.knots.KnotBatch -> dict of device tensors forming a ragged
+        batch record (seg, seg_count, init, ref_end, dl_bounds)."""
+        d = self.device
+        f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(d)
+        B = kb.B
+        rec = dict(B=B, seg_stride=seg_stride,
+                   seg=torch.zeros((L.NUM_SEG_FIELDS, B, seg_stride), dtype=torch.float64, device=d),
+                   seg_count=torch.zeros(B, dtype=torch.int32, device=d), init=f(kb.init),
+                   ref_end=torch.zeros((B, 2), dtype=torch.float64, device=d),
+                   dl_bounds=torch.zeros((B, 10), dtype=torch.float64, device=d))
+        ins = [f(kb.s_bounds), f(kb.l_bounds), f(kb.ds_bounds), f(kb.dl_bounds), f(kb.s_ref), f(kb.l_ref)]
+        stream = torch.cuda.current_stream(d).cuda_stream
+        self.ctx.corridor_batch_device(variant, B, kb.N, kb.num_obs, kb.delta, *ins, seg_stride, rec["seg"],
+                                       rec["seg_count"], rec["ref_end"], rec["dl_bounds"], stream=stream)
+        rec["_inputs"] = ins  # keep the knot arrays alive until the launch has run
+        return rec
+
+    def solve_ragged(self, rec, shared, max_iter=0, eps=0.0):
+        """Solve a ragged batch record (from corridor_batch); outputs stay on the device."""
+        d = self.device
+        B, st = rec["B"], rec["seg_stride"]
+        o = dict(ctrl=torch.zeros((B, 12 * st), dtype=torch.float64, device=d),
+                 cost=torch.empty(B, dtype=torch.float64, device=d),
+                 status=torch.empty(B, dtype=torch.int32, device=d), iters=torch.empty(B, dtype=torch.int32, device=d))
+        stream = torch.cuda.current_stream(d).cuda_stream
+        self.ctx.solve_ragged_device(B, st, shared, rec["seg"], rec["seg_count"], rec["init"], rec["ref_end"],
+                                     rec["dl_bounds"], o["ctrl"], o["cost"], o["status"], o["iters"], stream=stream,
+                                     max_iter=max_iter, eps=eps)
+        return o
+
     def argmin(self, cost, group=None, index_base=0):
         """Arg-min of cost over contiguous groups (default: the whole batch). Device tensors."""
         B = cost.numel()

@@ -1,0 +1,131 @@
+"""the corridor stage on the device, and ragged batches through the QP kernel.
+Device corridor records must equal the oracle's pipeline field by field; the end-to-end result
+(knot-level input -> corridors -> QP -> control points) must match the oracle's x*."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import O
+from spectral_amd import knots
+from spectral_amd import layout as L
+from spectral_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+W = np.loadtxt(os.path.join(GOLD, "inputs", "weights.txt"))
+FIELDS = [(L.F_T, "t"), (L.F_DOWN_BIAS, "down_bias"), (L.F_DOWN_SKEW, "down_skew"), (L.F_UPP_BIAS, "upp_bias"),
+          (L.F_UPP_SKEW, "upp_skew"), (L.F_L_DOWN_BIAS, "l_down_bias"), (L.F_L_DOWN_SKEW, "l_down_skew"),
+          (L.F_L_UPP_BIAS, "l_upp_bias"), (L.F_L_UPP_SKEW, "l_upp_skew"), (L.F_BEG_L, "beg_l"), (L.F_END_L, "end_l")]
+
+
+def oracle_pipeline(kb, b, variant):
+    lists = [O.corridor_generation(variant, kb.N, kb.delta, kb.s_bounds[b, o], kb.l_bounds[b, o]) for o in range(kb.num_obs)]
+    return O.collision_check(variant, kb.N, kb.delta, lists, kb.s_ref[b], kb.l_ref[b])
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c6", "c7", "c7_7", "c_road_s1", "c_road_s1_2", "c_road_s1_3"])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_device_corridors_equal_oracle_on_bundled_and_jittered_inputs(name, variant):
+    import torch
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    kb = knots.jittered(knots.parse_corridor_file(os.path.join(GOLD, "inputs", name + ".txt")), 24, seed=7)
+    rec = solver.corridor_batch(kb, variant, seg_stride=24)
+    torch.cuda.synchronize()
+    seg = rec["seg"].cpu().numpy(); cnt = rec["seg_count"].cpu().numpy()
+    for b in range(kb.B):
+        n, cubes = oracle_pipeline(kb, b, variant)
+        assert cnt[b] == (n if n > 0 else 0), (name, variant, b, cnt[b], n)
+        for k, c in enumerate(cubes):
+            for f, attr in FIELDS:
+                assert seg[f, b, k] == getattr(c, attr), (name, b, k, attr)
+    # candidate 0 is the unjittered file: the committed corridor list
+    n0, _ = oracle_pipeline(kb, 0, variant)
+    assert cnt[0] == max(n0, 0)
+
+
+@pytest.mark.parametrize("name,variant", [("c1", 0), ("c1", 1), ("c3", 0), ("c_road_s1_3", 0), ("c2", 1)])
+def test_knots_to_control_points_end_to_end(name, variant):
+    import torch
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    kb0 = knots.parse_corridor_file(os.path.join(GOLD, "inputs", name + ".txt"))
+    kb = knots.jittered(kb0, 40, seed=11)
+    sh = synth.shared_params(variant, weights=W)
+    sh.ds_ref, sh.dl_ref = kb.header["ds_ref"], kb.header["dl_ref"]
+    sh.dds, sh.ddds, sh.ddl, sh.dddl = kb.header["dds"], kb.header["ddds"], kb.header["ddl"], kb.header["dddl"]
+    rec = solver.corridor_batch(kb, variant, seg_stride=16)
+    out = solver.solve_ragged(rec, sh)
+    torch.cuda.synchronize()
+    cnt = rec["seg_count"].cpu().numpy(); ctrl = out["ctrl"].cpu().numpy(); status = out["status"].cpu().numpy()
+    cost = out["cost"].cpu().numpy()
+    assert len(set(cnt.tolist())) >= 1
+    p = O.params_from_weights(W)
+    checked = 0
+    for b in range(0, kb.B, 3):
+        n, cubes = oracle_pipeline(kb, b, variant)
+        if n < 1:
+            assert status[b] == -5 and np.isinf(cost[b])
+            continue
+        src = type("S", (), {})()
+        src.N, src.delta = kb.N, kb.delta
+        src.dx_bounds, src.dy_bounds, src.x_ref, src.y_ref = kb.ds_bounds[b], kb.dl_bounds[b], kb.s_ref[b], kb.l_ref[b]
+        src.init_s, src.init_l = kb.init[b, :3], kb.init[b, 3:]
+        for key, v in kb.header.items():
+            setattr(src, key, v)
+        qp = O.AssembledQp(variant, cubes, p, src)
+        xs, ys, info = qp.solve_exact()
+        S = n
+        if info.status == 1:
+            assert status[b] in (1, 2), (b, status[b])
+            got = ctrl[b, :12 * S]
+            assert np.abs(got - xs).max() <= 1e-5 * np.abs(xs).max(), (b, np.abs(got - xs).max() / np.abs(xs).max())
+            assert abs(cost[b] - info.obj_val) <= 1e-6 * abs(info.obj_val)
+            checked += 1
+        else:
+            assert status[b] < 0
+    assert checked >= 5
+
+
+def test_ragged_batch_equals_uniform_batches():
+    """Mixed segment counts in one launch give bit-identical results to per-count uniform launches."""
+    import torch
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    parts = [synth.make_batch(37, S, config=60 + S) for S in (7, 10, 20)]
+    sh = parts[0][1]
+    stride = 20
+    B = sum(p[0].B for p in parts)
+    seg = np.zeros((L.NUM_SEG_FIELDS, B, stride)); cnt = np.zeros(B, dtype=np.int32)
+    init = np.zeros((B, 6)); ref_end = np.zeros((B, 2)); dlb = np.zeros((B, 10))
+    perm = np.random.default_rng(0).permutation(B)
+    src = []
+    for pb, _ in parts:
+        for b in range(pb.B):
+            src.append((pb, b))
+    for dst, i in enumerate(perm):
+        pb, b = src[i]
+        seg[:, dst, :pb.S] = pb.seg[:, b, :]; cnt[dst] = pb.S
+        init[dst], ref_end[dst], dlb[dst] = pb.init[b], pb.ref_end[b], pb.dl_bounds[b]
+    cnt[5] = 0; cnt[9] = 33                                  # unusable: nothing selected / more than the stride
+    d = solver.device
+    t = lambda a: torch.from_numpy(a).to(d)
+    rec = dict(B=B, seg_stride=stride, seg=t(seg), seg_count=t(cnt), init=t(init), ref_end=t(ref_end), dl_bounds=t(dlb))
+    out = solver.solve_ragged(rec, sh)
+    torch.cuda.synchronize()
+    ctrl = out["ctrl"].cpu().numpy(); status = out["status"].cpu().numpy(); cost = out["cost"].cpu().numpy()
+    uni = [solver.ctx.solve_host(pb, sh) for pb, _ in parts]
+    off = np.cumsum([0] + [p[0].B for p in parts])
+    for dst, i in enumerate(perm):
+        if dst in (5, 9):
+            assert status[dst] == -5 and np.isinf(cost[dst])
+            continue
+        j = int(np.searchsorted(off, i, side="right") - 1)
+        b = i - off[j]
+        S = parts[j][0].S
+        assert (ctrl[dst, :12 * S] == uni[j][0][b]).all()
+        assert cost[dst] == uni[j][1][b] and status[dst] == uni[j][2][b]
+    bi, bc = solver.argmin(out["cost"])
+    torch.cuda.synchronize()
+    assert int(bi[0]) == int(np.argmin(cost))
