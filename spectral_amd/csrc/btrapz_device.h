@@ -51,7 +51,7 @@ struct CorridorArgs {
   double *dl10;                        // [B][10]
 };
 
-__global__ void corridor_batch_kernel(const CorridorArgs a);
+__global__ void corridor_batch_kernel(const CorridorArgs a, int staged);
 __global__ void bucket_hist_kernel(int B, int seg_stride, const int *seg_count, int *meta);
 __global__ void bucket_prefix_kernel(int *meta);
 __global__ void bucket_scatter_kernel(int B, int seg_stride, const int *seg_count, int *meta, int *order,

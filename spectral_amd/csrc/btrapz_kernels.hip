@@ -377,7 +377,11 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
       iters = iter;
       if (score < best_score) { best_score = score; best_it = iter; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
 #ifndef ABL_FIXED
-      if (score < eps || (best_score < 1e-5 && iter - best_it >= 3) || !(score < 1e299)) done = true;
+      // stop: converged; at the round-off floor (best < 1e-5, 3 iterations without progress); diverging or
+      // infeasible (8 iterations without progress after the start-up phase); not finite
+      if (score < eps || (best_score < 1e-5 && iter - best_it >= 3) || (iter >= 12 && iter - best_it >= 8) ||
+          !(score < 1e299))
+        done = true;
 #endif
     }
     if (__all(done)) break;

@@ -16,22 +16,37 @@
 
 namespace btrapz {
 
-enum { MAX_ALL = 160, MAX_SEL = 64, MAX_KNOTS = 512 };
+enum { MAX_ALL = 160, MAX_SEL = 64 };
 
-__global__ __launch_bounds__(64) void corridor_batch_kernel(const CorridorArgs a) {
+// Dynamic LDS: [s_ref N][l_ref N][s_bounds O*N*2][l_bounds O*N*2] when `staged` (it fits), else only the refs.
+__global__ __launch_bounds__(64) void corridor_batch_kernel(const CorridorArgs a, int staged) {
   __shared__ Seg all[MAX_ALL];
   __shared__ Seg sel[MAX_SEL];
   __shared__ int ocount[64];
   __shared__ int nsel_sh;
-  __shared__ double sref[MAX_KNOTS], lref[MAX_KNOTS];
+  extern __shared__ double dyn[];
 
   const int b = blockIdx.x, lane = threadIdx.x;
   const int N = a.N, O = a.num_obs;
   const int cap_o = MAX_ALL / (O > 0 ? O : 1);
+  double *sref = dyn, *lref = dyn + N;
   for (int i = lane; i < N; i += 64) { sref[i] = a.s_ref[(size_t)b * N + i]; lref[i] = a.l_ref[(size_t)b * N + i]; }
+  // The per-obstacle scan below is a serial walk over the knots: from HBM that is N dependent round trips
+  // per lane.  Stage the candidate's bounds into LDS with coalesced 16-byte loads first.
+  const double *gs = a.s_bounds + (size_t)b * O * N * 2, *gl = a.l_bounds + (size_t)b * O * N * 2;
+  const double *ss = gs, *sl_ = gl;
+  if (staged) {
+    double *ls = dyn + 2 * N, *ll = ls + (size_t)O * N * 2;
+    const int n2 = O * N;  // pairs
+    const double2 *gs2 = reinterpret_cast<const double2 *>(gs), *gl2 = reinterpret_cast<const double2 *>(gl);
+    double2 *ls2 = reinterpret_cast<double2 *>(ls), *ll2 = reinterpret_cast<double2 *>(ll);
+    for (int i = lane; i < n2; i += 64) { ls2[i] = gs2[i]; ll2[i] = gl2[i]; }
+    ss = ls; sl_ = ll;
+  }
+  __syncthreads();
   // ---- per-obstacle extraction: lane o owns obstacle o ----
   if (lane < O) {
-    const BoundsView sb{a.s_bounds + ((size_t)b * O + lane) * N * 2}, lb{a.l_bounds + ((size_t)b * O + lane) * N * 2};
+    const BoundsView sb{ss + (size_t)lane * N * 2}, lb{sl_ + (size_t)lane * N * 2};
     ocount[lane] = extract_segments_core(a.variant, N, a.delta, sb, lb, all + lane * cap_o, cap_o);
   }
   __syncthreads();
