@@ -44,6 +44,9 @@ def parse():
                     help="B=1 launches for the p50 latency (0 skips them, e.g. under rocprofv3 so that the "
                          "kernel's average duration is the batch launch alone)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="dry run of the N > 1 flow on a 1-GPU box: every rank uses device 0 (use with --backend gloo)")
     return ap.parse_args()
 
 
@@ -97,9 +100,14 @@ def main():
         native.build()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    if a.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend)
     solver = BatchSolver(local_rank)
     dev = solver.device
 
@@ -136,7 +144,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
@@ -161,7 +169,7 @@ def main():
                                    "order 5, %s constraints, arg-min over all candidates" %
                                    (config, B, S, "trapezoid-prism" if a.variant == 0 else "cuboid"),
                        "batch_per_gpu": B, "segments": S, "variant": a.variant, "parallelism": "shard%d" % world,
-                       "collective": "none" if world == 1 else "rccl all_gather of (cost,index), 16 B per rank"},
+                       "collective": "none" if world == 1 else "%s all_gather of (cost,index), 16 B per rank" % ("rccl" if a.backend == "nccl" else a.backend)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "btrapz::ipm_solve_kernel", "kernel_ms": kernel_ms,

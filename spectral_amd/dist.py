@@ -25,9 +25,12 @@ def global_argmin(best_cost, best_idx, group=None):
     if world == 1:
         return best_cost, best_idx
     pair = torch.stack([best_cost.to(torch.float64), best_idx.to(torch.float64)], dim=-1).contiguous()
+    dev = pair.device
+    if dist.get_backend(group) == "gloo" and pair.is_cuda:   # CPU dry runs of the multi-rank flow
+        pair = pair.cpu()
     gathered = [torch.empty_like(pair) for _ in range(world)]
     dist.all_gather(gathered, pair, group=group)
-    allp = torch.stack(gathered)                      # [world, n, 2]
+    allp = torch.stack(gathered).to(dev)             # [world, n, 2]
     cost, idx = allp[..., 0], allp[..., 1]
     idx_key = torch.where(idx < 0, torch.full_like(idx, float("inf")), idx)
     # lexicographic min over ranks: cost first, then global index
