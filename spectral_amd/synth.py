@@ -32,18 +32,28 @@ def _smoothstep5(x):
     return x * x * x * (10.0 + x * (-15.0 + 6.0 * x))
 
 
-def make_batch(B, S, config=2, variant=0, seed=None, dtype=np.float64):
-    """Returns (Batch, Shared).  All t_k = 1.0 s (10 knots of 0.1 s), N = 10*S+1."""
+def make_batch(B, S, config=2, variant=0, seed=None, dtype=np.float64, agents=None):
+    """Returns (Batch, Shared).  All t_k = 1.0 s (10 knots of 0.1 s), N = 10*S+1.
+
+    agents=G (config 5): the batch is G ego agents x B/G candidate corridors each.  Candidates of one agent
+    are alternatives for the SAME ego: they share the initial state and the longitudinal reference and differ
+    in corridor margins, obstacle ramps and lane-change target/timing."""
     rng = np.random.default_rng(SEED_BASE + config if seed is None else seed)
+    if agents:
+        assert B % agents == 0
+        per = B // agents
+        share = lambda draw: np.repeat(draw(agents), per, axis=0)   # one draw per agent, repeated for its candidates
+    else:
+        share = lambda draw: draw(B)
     sh = shared_params(variant)
     T = float(S)  # horizon in seconds
     N = 10 * S + 1
     tt = np.arange(N) * sh.delta  # knots
     cub = variant == 1
     # longitudinal reference s*(t): v0 + smooth zero-mean acceleration, |a| <= ~1.2
-    v0 = rng.uniform(2.0, 4.5, B) if cub else rng.uniform(4.0, 10.0, B)
-    amp = rng.uniform(0.0, 0.6, (B, 2)) * (0.4 if cub else 1.0)
-    ph = rng.uniform(0, 2 * np.pi, (B, 2))
+    v0 = share(lambda n: rng.uniform(2.0, 4.5, n) if cub else rng.uniform(4.0, 10.0, n))
+    amp = share(lambda n: rng.uniform(0.0, 0.6, (n, 2))) * (0.4 if cub else 1.0)
+    ph = share(lambda n: rng.uniform(0, 2 * np.pi, (n, 2)))
     om = 2 * np.pi * np.array([1.0, 2.0]) / max(T, 10.0)
     # v(t) = v0 + sum amp/om * (cos(ph) - cos(om t + ph))
     v = v0[:, None] + ((amp / om)[:, :, None] * (np.cos(ph)[:, :, None] - np.cos(om[None, :, None] * tt[None, None, :] + ph[:, :, None]))).sum(1)
@@ -51,7 +61,7 @@ def make_batch(B, S, config=2, variant=0, seed=None, dtype=np.float64):
     s_star = np.concatenate([np.zeros((B, 1)), np.cumsum(0.5 * (v[:, 1:] + v[:, :-1]) * sh.delta, axis=1)], axis=1)
     # lateral reference: smoothstep between two lanes
     lanes = np.array([1.2, 2.0, 3.5])
-    la = rng.integers(0, 3, B); lb = rng.integers(0, 3, B)
+    la = share(lambda n: rng.integers(0, 3, n)); lb = rng.integers(0, 3, B)
     l0, l1 = lanes[la], lanes[lb]
     dl = np.abs(l1 - l0)
     dur = np.maximum(3.0, np.sqrt(5.8 * dl / 0.45))
