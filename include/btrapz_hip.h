@@ -125,6 +125,8 @@ typedef struct btrapz_options {
   double eps;    /* KKT score target; 0 -> default (1e-9) */
 } btrapz_options;
 
+/* A context owns the per-launch workspace of one device: it is NOT thread-safe (one context per calling
+ * thread; launches of one context must be issued in stream order). */
 typedef struct btrapz_ctx btrapz_ctx;
 
 int btrapz_create(btrapz_ctx **ctx, int device);

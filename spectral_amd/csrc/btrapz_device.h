@@ -4,6 +4,9 @@
 
 #include "../../include/btrapz_hip.h"
 
+// The library is built with -fvisibility=hidden: only the C-ABI of include/btrapz_hip.h is exported.
+#define BTRAPZ_EXPORT extern "C" __attribute__((visibility("default")))
+
 namespace btrapz {
 
 // Device view of btrapz_shared: limits already in the form the rows use them.

@@ -66,13 +66,13 @@ static void build_mqm(const double w[4], double out[4][21]) {
   }
 }
 
-extern "C" int btrapz_device_count(void) {
+BTRAPZ_EXPORT int btrapz_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
 
-extern "C" int btrapz_create(btrapz_ctx **out, int device) {
+BTRAPZ_EXPORT int btrapz_create(btrapz_ctx **out, int device) {
   if (!out) return BTRAPZ_EINVAL;
   *out = nullptr;
   int n = 0;
@@ -85,7 +85,7 @@ extern "C" int btrapz_create(btrapz_ctx **out, int device) {
   return BTRAPZ_OK;
 }
 
-extern "C" int btrapz_destroy(btrapz_ctx *c) {
+BTRAPZ_EXPORT int btrapz_destroy(btrapz_ctx *c) {
   if (!c) return BTRAPZ_EINVAL;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters);
@@ -95,7 +95,7 @@ extern "C" int btrapz_destroy(btrapz_ctx *c) {
   return BTRAPZ_OK;
 }
 
-extern "C" const char *btrapz_last_error(const btrapz_ctx *c) { return c ? c->err.c_str() : "null context"; }
+BTRAPZ_EXPORT const char *btrapz_last_error(const btrapz_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 static int ensure_axis_ws(btrapz_ctx *c, size_t nprob) {
   if (nprob <= c->axis_cap) return BTRAPZ_OK;
@@ -176,14 +176,14 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   return BTRAPZ_OK;
 }
 
-extern "C" int btrapz_solve_batch_device(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B,
+BTRAPZ_EXPORT int btrapz_solve_batch_device(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B,
                                          int S, const double *seg, const double *init, const double *ref_end,
                                          const double *dl_bounds, double *ctrl, double *cost, int *status, int *iters,
                                          void *stream) {
   return solve_common(c, sh, opt, B, S, nullptr, seg, init, ref_end, dl_bounds, ctrl, cost, status, iters, stream);
 }
 
-extern "C" int btrapz_solve_ragged_device(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B,
+BTRAPZ_EXPORT int btrapz_solve_ragged_device(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B,
                                           int seg_stride, const double *seg, const int *seg_count, const double *init,
                                           const double *ref_end, const double *dl_bounds, double *ctrl, double *cost,
                                           int *status, int *iters, void *stream) {
@@ -192,7 +192,7 @@ extern "C" int btrapz_solve_ragged_device(btrapz_ctx *c, const btrapz_shared *sh
                       stream);
 }
 
-extern "C" int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B, int N, int num_obs, double delta,
+BTRAPZ_EXPORT int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B, int N, int num_obs, double delta,
                                             const double *s_bounds, const double *l_bounds, const double *ds_bounds,
                                             const double *dl_bounds_knots, const double *s_ref, const double *l_ref,
                                             int seg_stride, double *seg, int *seg_count, double *ref_end,
@@ -218,7 +218,7 @@ extern "C" int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B, i
   return BTRAPZ_OK;
 }
 
-extern "C" int btrapz_argmin_device(btrapz_ctx *c, int B, int group, long long index_base, const double *cost,
+BTRAPZ_EXPORT int btrapz_argmin_device(btrapz_ctx *c, int B, int group, long long index_base, const double *cost,
                                     long long *best_idx, double *best_cost, void *stream_) {
   if (!c) return BTRAPZ_EINVAL;
   if (B < 1 || group < 1 || B % group != 0 || !cost || !best_idx || !best_cost) { c->err = "invalid argument"; return BTRAPZ_EINVAL; }
@@ -229,7 +229,7 @@ extern "C" int btrapz_argmin_device(btrapz_ctx *c, int B, int group, long long i
   return BTRAPZ_OK;
 }
 
-extern "C" int btrapz_sample_device(btrapz_ctx *c, int B, int S, double delta, const double *seg, const double *init,
+BTRAPZ_EXPORT int btrapz_sample_device(btrapz_ctx *c, int B, int S, double delta, const double *seg, const double *init,
                                     const double *ctrl, int nsel, const long long *sel, int max_points, double *out,
                                     int *npoints, void *stream_) {
   if (!c) return BTRAPZ_EINVAL;
@@ -243,7 +243,7 @@ extern "C" int btrapz_sample_device(btrapz_ctx *c, int B, int S, double delta, c
   return BTRAPZ_OK;
 }
 
-extern "C" int btrapz_sample_ragged_device(btrapz_ctx *c, int B, int seg_stride, const int *seg_count, double delta,
+BTRAPZ_EXPORT int btrapz_sample_ragged_device(btrapz_ctx *c, int B, int seg_stride, const int *seg_count, double delta,
                                            const double *seg, const double *init, const double *ctrl, int nsel,
                                            const long long *sel, int max_points, double *out, int *npoints,
                                            void *stream_) {
@@ -259,7 +259,7 @@ extern "C" int btrapz_sample_ragged_device(btrapz_ctx *c, int B, int seg_stride,
   return BTRAPZ_OK;
 }
 
-extern "C" int btrapz_solve_batch_host(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B, int S,
+BTRAPZ_EXPORT int btrapz_solve_batch_host(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B, int S,
                                        const double *seg, const double *init, const double *ref_end,
                                        const double *dl_bounds, double *ctrl, double *cost, int *status, int *iters) {
   if (!c) return BTRAPZ_EINVAL;

@@ -30,6 +30,7 @@ const char *kDefaultOutputPrefix[2] = {"/home/srujan_d/RISS/code/btrapz/src/s1_s
                                        "/home/srujan_d/RISS/code/btrapz/src/s1_cub_3d_"};
 
 std::mutex g_ctx_mutex;
+std::mutex g_run_mutex;  // the shared context's workspace serves one find_traj at a time
 btrapz_ctx *g_ctx = nullptr;
 
 btrapz_ctx *shared_ctx() {
@@ -104,7 +105,7 @@ double trajectory_cost(int variant, const Params &p, const TrajInput &in, int np
 
 }  // namespace
 
-extern "C" int btrapz_corridor_from_file(int variant, const char *input_path, btrapz_segment *out, int cap) {
+BTRAPZ_EXPORT int btrapz_corridor_from_file(int variant, const char *input_path, btrapz_segment *out, int cap) {
   if (!input_path || !out || cap < 1 || variant < 0 || variant > 1) return BTRAPZ_EINVAL;
   TrajInput in;
   if (!read_traj_input(input_path, in)) return BTRAPZ_EINVAL;
@@ -124,7 +125,7 @@ extern "C" int btrapz_corridor_from_file(int variant, const char *input_path, bt
   return (int)seg.size();
 }
 
-extern "C" double btrapz_find_traj(int variant, const char *input_path, const char *output_path, const Params *p) {
+BTRAPZ_EXPORT double btrapz_find_traj(int variant, const char *input_path, const char *output_path, const Params *p) {
   const double FAIL = BTRAPZ_FAIL_SENTINEL;
   if (!p || variant < 0 || variant > 1) return FAIL;
   std::string in_path = input_path ? input_path : "";
@@ -192,6 +193,9 @@ extern "C" double btrapz_find_traj(int variant, const char *input_path, const ch
   if (np_expected != var_index || np_expected < 1) return FAIL;
   const int max_points = np_expected;
 
+  // A btrapz_ctx is not thread-safe (its per-axis workspace is shared by every launch): concurrent callers of
+  // find_traj queue here.  The reference's own calls only ever race on the output file.
+  std::lock_guard<std::mutex> run_lock(g_run_mutex);
   DeviceBuf d_seg, d_init, d_re, d_dl, d_ctrl, d_cost, d_status, d_sel, d_out, d_np;
   if (!d_seg.alloc(h_seg.size() * 8) || !d_init.alloc(48) || !d_re.alloc(16) || !d_dl.alloc(80) ||
       !d_ctrl.alloc((size_t)12 * S * 8) || !d_cost.alloc(8) || !d_status.alloc(8) || !d_sel.alloc(8) ||
