@@ -22,8 +22,8 @@
 // state is split between VGPRs (36 slacks per lane) and LDS columns private to the lane (36
 // multipliers, 36 reciprocal slacks); a wavefront holds problems of ONE axis so the
 // batch-invariant M'QM table comes through scalar loads; neighbour exchange is
-// a DPP wave shift; the block LDL^T and its sweeps run as S sequential steps in which lane k
-// owns pivot block k.  HBM is touched once to load the Cube records and once to store results.
+// a DPP wave shift; the block LDL^T and its sweeps run two-sided (upper and lower half towards the
+// middle block) in S/2+1 sequential steps in which lanes s and S-1-s own the pivots.  HBM is touched once to load the Cube records and once to store results.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -199,6 +199,11 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
   const int b = a.order ? a.order[cand0 + (int)cand] : (int)cand;
   const long long prob = 2LL * b + axis;
   const bool first = (k == 0), last = (k == S - 1);
+  const int m = S >> 1;                               // root block of the two-sided elimination
+  const bool top = k < m, bot = k > m, mid = k == m;
+  const int my_step = top ? k : (bot ? S - 1 - k : m);  // the step at which this lane owns a pivot
+  const bool take_p = k <= m && !first;              // my update comes from lane k-1 (upper half) ...
+  const bool take_n = k >= m && !last;               // ... and/or from lane k+1 (lower half)
 
   // ---------------- load the segment record (coalesced: lanes -> consecutive (b,k)) ----------
   const size_t BS = (size_t)a.B * a.seg_stride;
@@ -423,29 +428,40 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
       // diagonal block of X_{k+1}: M11_k + M00_{k+1}
       UNROLL for (int i = 0; i < 6; i++) { const double v = from_next(M00[i]); T[i] += last ? 0.0 : v; }
     }
-    // ---- 3. block LDL^T: S_0 = T_0 ; C_k = S_{k-1}^{-1} M01_k ; S_k = T_k - M01_k' C_k ----
-    double F[6] = {0.0, 0.0, 0.0, 1.0, 1.0, 1.0}, C[9];
-    UNROLL for (int i = 0; i < 9; i++) C[i] = 0.0;
-#if defined(ABL_NOSEQ) || defined(ABL_NOFACT)
-    for (int step = 0; step < 1; ++step) {
-#else
-    for (int step = 0; step < S; ++step) {
-#endif
-      double pF[6];
-      UNROLL for (int i = 0; i < 6; i++) pF[i] = from_prev(F[i]);
-      if (k == step) {
-        double Sk[6] = {T[0], T[1], T[2], T[3], T[4], T[5]};
-        if (!first) {
-          UNROLL for (int j = 0; j < 3; j++) ldl3_solve(pF, M01[j], M01[3 + j], M01[6 + j], C[j], C[3 + j], C[6 + j]);
-          // Sk(a,b) -= sum_r M01(r,a) C(r,b)
-          Sk[0] -= M01[0] * C[0] + M01[3] * C[3] + M01[6] * C[6];
-          Sk[1] -= M01[0] * C[1] + M01[3] * C[4] + M01[6] * C[7];
-          Sk[2] -= M01[0] * C[2] + M01[3] * C[5] + M01[6] * C[8];
-          Sk[3] -= M01[1] * C[1] + M01[4] * C[4] + M01[7] * C[7];
-          Sk[4] -= M01[1] * C[2] + M01[4] * C[5] + M01[7] * C[8];
-          Sk[5] -= M01[2] * C[2] + M01[5] * C[5] + M01[8] * C[8];
+    // ---- 3. two-sided block LDL^T.  Blocks 0..m-1 are eliminated downwards, blocks S-1..m+1 upwards, in the
+    // same instruction stream (step s: lanes s and S-1-s); block m = S/2 is the root and takes both Schur
+    // updates.  A lane that has factored its pivot S_k = T_k - Z_in forms K = S_k^{-1} Mc and Z_out = Mc' K for
+    // its neighbour towards the middle (Mc = M01_{k+1} for the upper half, M01_k' for the lower half).
+    double F[6] = {0.0, 0.0, 0.0, 1.0, 1.0, 1.0}, K[9], Z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    {
+      double Mc[9];
+      UNROLL for (int i = 0; i < 3; i++)
+        UNROLL for (int j = 0; j < 3; j++) {
+          const double nM = from_next(M01[i * 3 + j]);
+          Mc[i * 3 + j] = top ? nM : M01[j * 3 + i];
+          K[i * 3 + j] = 0.0;
         }
-        ldl3(Sk, F);
+#if defined(ABL_NOSEQ) || defined(ABL_NOFACT)
+      for (int step = m; step <= m; ++step) {
+#else
+      for (int step = 0; step <= m; ++step) {
+#endif
+        double pZ[6], nZ[6];
+        UNROLL for (int i = 0; i < 6; i++) { pZ[i] = from_prev(Z[i]); nZ[i] = from_next(Z[i]); }
+        if (step == my_step) {
+          double Sk[6];
+          UNROLL for (int i = 0; i < 6; i++) Sk[i] = T[i] - (take_p ? pZ[i] : 0.0) - (take_n ? nZ[i] : 0.0);
+          ldl3(Sk, F);
+          if (!mid) {
+            UNROLL for (int j = 0; j < 3; j++) ldl3_solve(F, Mc[j], Mc[3 + j], Mc[6 + j], K[j], K[3 + j], K[6 + j]);
+            Z[0] = Mc[0] * K[0] + Mc[3] * K[3] + Mc[6] * K[6];
+            Z[1] = Mc[0] * K[1] + Mc[3] * K[4] + Mc[6] * K[7];
+            Z[2] = Mc[0] * K[2] + Mc[3] * K[5] + Mc[6] * K[8];
+            Z[3] = Mc[1] * K[1] + Mc[4] * K[4] + Mc[7] * K[7];
+            Z[4] = Mc[1] * K[2] + Mc[4] * K[5] + Mc[7] * K[8];
+            Z[5] = Mc[2] * K[2] + Mc[5] * K[5] + Mc[8] * K[8];
+          }
+        }
       }
     }
 
@@ -459,35 +475,37 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
         UT_apply(nm, h[0], h[1], h[2], hn);
         UNROLL for (int i = 0; i < 3; i++) { const double v = from_next(hn[i]); u[i] = -(u[i] + (last ? 0.0 : v)); }
       }
-      // forward: u_k -= C_k' u_{k-1}
+      // forward, both halves towards the root: a lane whose u is final sends w = K' u inwards
+      double w[3] = {0.0, 0.0, 0.0};
 #if defined(ABL_NOSEQ) || defined(ABL_NOSWEEP)
-      for (int step = 1; step < 2; ++step) {
+      for (int step = m; step <= m; ++step) {
 #else
-      for (int step = 1; step < S; ++step) {
+      for (int step = 0; step <= m; ++step) {
 #endif
-        double pu[3];
-        UNROLL for (int i = 0; i < 3; i++) pu[i] = from_prev(u[i]);
-        if (k == step) {
-          u[0] -= C[0] * pu[0] + C[3] * pu[1] + C[6] * pu[2];
-          u[1] -= C[1] * pu[0] + C[4] * pu[1] + C[7] * pu[2];
-          u[2] -= C[2] * pu[0] + C[5] * pu[1] + C[8] * pu[2];
+        double pw[3], nw[3];
+        UNROLL for (int i = 0; i < 3; i++) { pw[i] = from_prev(w[i]); nw[i] = from_next(w[i]); }
+        if (step == my_step) {
+          UNROLL for (int i = 0; i < 3; i++) u[i] -= (take_p ? pw[i] : 0.0) + (take_n ? nw[i] : 0.0);
+          if (!mid) {
+            w[0] = K[0] * u[0] + K[3] * u[1] + K[6] * u[2];
+            w[1] = K[1] * u[0] + K[4] * u[1] + K[7] * u[2];
+            w[2] = K[2] * u[0] + K[5] * u[1] + K[8] * u[2];
+          }
         }
       }
-      // backward: dX_{k+1} = S_k^{-1} u_k - C_{k+1} dX_{k+2}
-      double v[3], w[3];
+      // backward, from the root outwards: dX_k = S_k^{-1} u_k - K_k dX_(neighbour towards the root)
+      double v[3];
       ldl3_solve(F, u[0], u[1], u[2], v[0], v[1], v[2]);
       UNROLL for (int i = 0; i < 3; i++) dX[i] = v[i];
-      UNROLL for (int i = 0; i < 3; i++) w[i] = C[3 * i] * dX[0] + C[3 * i + 1] * dX[1] + C[3 * i + 2] * dX[2];
 #if defined(ABL_NOSEQ) || defined(ABL_NOSWEEP)
-      for (int step = 0; step >= 0; --step) {
+      for (int step = 0; step >= 0 && m > 0; --step) {
 #else
-      for (int step = S - 2; step >= 0; --step) {
+      for (int step = m - 1; step >= 0; --step) {
 #endif
-        double pw[3];
-        UNROLL for (int i = 0; i < 3; i++) pw[i] = from_next(w[i]);
-        if (k == step) {
-          UNROLL for (int i = 0; i < 3; i++) dX[i] = v[i] - pw[i];
-          UNROLL for (int i = 0; i < 3; i++) w[i] = C[3 * i] * dX[0] + C[3 * i + 1] * dX[1] + C[3 * i + 2] * dX[2];
+        double xin[3];
+        UNROLL for (int i = 0; i < 3; i++) { const double px = from_prev(dX[i]), nx = from_next(dX[i]); xin[i] = top ? nx : px; }
+        if (step == my_step) {  // the root (my_step == m) is final already
+          UNROLL for (int i = 0; i < 3; i++) dX[i] = v[i] - (K[3 * i] * xin[0] + K[3 * i + 1] * xin[1] + K[3 * i + 2] * xin[2]);
         }
       }
       double dXp[3];
