@@ -65,6 +65,22 @@ def measured_traffic(B, S, variant):
     return None, None
 
 
+def measured_sq(B, S, variant):
+    """Executed FP64 flops per launch and VALU-busy share from the committed SQ counter profile of this
+    workload (profiles/*_pmc_sq.json, tools/collect_profiles.sh); None when no profile matches."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if (w.get("batch_per_gpu"), w.get("segments"), w.get("variant")) == (B, S, variant):
+            dv = d.get("derived", {})
+            return dv.get("fp64_flops_per_launch_all_lanes"), dv.get("frac_of_wave_cycles:SQ_ACTIVE_INST_VALU"), os.path.basename(f)
+    return None, None, None
+
+
 def cpu_baseline(batch, shared, seconds):
     """The reference's algorithm (oracle OSQP port) on the host cores, bounded sample."""
     from oracle import oracle as O
@@ -161,6 +177,7 @@ def main():
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         flops = 2.0 * B * S * mean_iters * FLOPS_PER_SEGMENT_ITER
         traffic, traffic_src = measured_traffic(B, S, a.variant)
+        sq_flops, valu_busy, sq_src = measured_sq(B, S, a.variant)
         out = {
             "metric": "trajectory QP solves/sec (20-seg order-5 corridor)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
@@ -179,7 +196,12 @@ def main():
                          "fp64_valu": {"achieved_tflops": flops / (kernel_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                                        "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                        "model": "%.0f useful flops per segment per iteration x %.2f mean iterations" %
-                                                (FLOPS_PER_SEGMENT_ITER, mean_iters)}},
+                                                (FLOPS_PER_SEGMENT_ITER, mean_iters),
+                                       # what the SIMDs actually executed (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 x 64
+                                       # lanes, FMA = 2), from the committed counter profile of this workload
+                                       "executed_tflops": None if sq_flops is None else sq_flops / (kernel_ms * 1e-3) / 1e12,
+                                       "executed_frac": None if sq_flops is None else sq_flops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                       "valu_busy_frac_of_wave_cycles": valu_busy, "counter_source": sq_src}},
             "solved_fraction": solved, "mean_ipm_iterations": mean_iters,
             "winner": {"index": int(win_idx.item()), "cost": float(win_cost.item())},
         }

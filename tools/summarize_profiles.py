@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<tag>/ (written by tools/collect_profiles.sh) into the committed files under profiles/.
+
+  python tools/summarize_profiles.py r01
+
+Writes profiles/<tag>_bench.json, <tag>_bench_under_rocprof.json, <tag>_bench_kernel_stats.csv,
+<tag>_pmc_hbm.json (FETCH_SIZE / WRITE_SIZE, per launch of the dominant kernel) and <tag>_pmc_sq.json
+(SQ counters per launch and per wavefront)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+KERNEL = "ipm_solve_kernel"
+
+
+def counter_means(root):
+    """{counter: (mean over launches of KERNEL, launches, resource columns)} over every pmc_* directory."""
+    out = {}
+    for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        acc = {}
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if KERNEL not in row["Kernel_Name"]:
+                    continue
+                acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
+                acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+                res = dict(vgpr=row["VGPR_Count"], agpr=row["Accum_VGPR_Count"], sgpr=row["SGPR_Count"],
+                           lds=row["LDS_Block_Size"], scratch=row["Scratch_Size"], grid=row["Grid_Size"])
+        for name, per in acc.items():
+            vals = list(per.values())
+            out[name] = dict(mean=sum(vals) / len(vals), min=min(vals), max=max(vals), launches=len(vals), **res)
+    return out
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src, dst = os.path.join(here, "gpurun_out", tag), os.path.join(here, "profiles")
+    shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+    shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
+    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+    bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+    wl = bench["config"]
+    c = counter_means(src)
+
+    hbm = {}
+    for k in ("FETCH_SIZE", "WRITE_SIZE"):
+        if k in c:
+            hbm[k] = dict(launches=c[k]["launches"], mean_KB=c[k]["mean"], min_KB=c[k]["min"], max_KB=c[k]["max"],
+                          **{r: c[k][r] for r in ("vgpr", "agpr", "sgpr", "lds", "scratch", "grid")})
+    if len(hbm) == 2:
+        hbm["workload"] = wl
+        hbm["bytes_per_launch_raw"] = (hbm["FETCH_SIZE"]["mean_KB"] + hbm["WRITE_SIZE"]["mean_KB"]) * 1024.0
+        hbm["note"] = ("FETCH_SIZE/WRITE_SIZE in KB, separate --pmc passes (TCC slot limit).  WRITE_SIZE matches the "
+                       "stored bytes.  FETCH_SIZE is uncalibrated for this access width (8 B/lane loads; the guide "
+                       "calibrates only 16 B/lane streams, where it reads 1/2): the raw figure is reported; the true "
+                       "read traffic lies between it and twice it.")
+        json.dump(hbm, open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
+
+    sq = {k: v["mean"] for k, v in c.items() if k.startswith("SQ_") or k.startswith("GRBM")}
+    if "SQ_WAVES" in sq:
+        w = sq["SQ_WAVES"]
+        per_wave = {k: v / w for k, v in sq.items() if k.startswith("SQ_INSTS")}
+        derived = dict(per_wave_instructions=per_wave)
+        if "SQ_WAVE_CYCLES" in sq:
+            wc = sq["SQ_WAVE_CYCLES"]  # in units of 4 cycles, like the SQ_ACTIVE_* / SQ_WAIT_* counters
+            derived["wave_lifetime_cycles"] = 4.0 * wc / w
+            for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA",
+                      "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS"):
+                if k in sq:
+                    derived["frac_of_wave_cycles:" + k] = sq[k] / wc
+            if "SQ_ACTIVE_INST_VALU" in sq and "SQ_INSTS_VALU" in sq:
+                derived["cycles_per_valu_instruction"] = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_INSTS_VALU"]
+        f64 = {k: sq[k] for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64",
+                                  "SQ_INSTS_VALU_TRANS_F64") if k in sq}
+        if f64:
+            # wave-level instruction counts; one instruction = 64 lanes; FMA = 2 flops
+            flops = 64.0 * (2 * f64.get("SQ_INSTS_VALU_FMA_F64", 0) + f64.get("SQ_INSTS_VALU_MUL_F64", 0) +
+                            f64.get("SQ_INSTS_VALU_ADD_F64", 0) + f64.get("SQ_INSTS_VALU_TRANS_F64", 0))
+            derived["fp64_flops_per_launch_all_lanes"] = flops
+            derived["fp64_share_of_valu_instructions"] = sum(f64.values()) / sq["SQ_INSTS_VALU"]
+        json.dump(dict(kernel=KERNEL, workload=wl, per_launch=sq, derived=derived,
+                       note="rocprofv3 --pmc passes (tools/collect_profiles.sh), means over the launches of one "
+                            "bench.py --steps 3 --warmup 1 run; SQ cycle counters are in units of 4 clock cycles."),
+                  open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)
+    print("wrote profiles for", tag, "counters:", sorted(c))
+
+
+if __name__ == "__main__":
+    main()
