@@ -196,6 +196,45 @@ int btrapz_sample_ragged_device(btrapz_ctx *ctx, int B, int seg_stride, const in
                                 const double *ctrl, int nsel, const long long *sel, int max_points,
                                 double *out, int *npoints, void *stream);
 
+/* ---- receding-horizon warm start ----------------------------------------------
+ * The reference re-solves cold at every replanning step: a fresh OSQP workspace per call
+ * (solve_3d.cc:1246, osqp_cleanup :1256,1410) inside the replan loop cart_frenet.py:1516-1571.  Here a
+ * solve may start from the joint states and multipliers of an earlier solve of a nearby problem.  The
+ * optimum does not depend on the start (the QP is strictly convex); only the iteration count does.
+ *   x0      [B][2][seg_stride][3]  (p, v, a) at the END of every segment, s axis then l axis; entries that
+ *           are not finite fall back to the cold start of that segment.  NULL: cold primal start.
+ *   lam0    [2][36][B][seg_stride] multipliers (rows 0-17: lower bounds of the 6 position, 5 velocity,
+ *           4 acceleration, 3 jerk rows; 18-35: upper bounds), as written to lam_out by an earlier solve;
+ *           negative / non-finite entries count as 0.  NULL: none.
+ *   lam_out same layout, multipliers at the end of this solve.  NULL: not stored.
+ *   smin, mu0: slacks start at max(gap, smin), multipliers at lam0 + mu0 / slack (0 -> 1e-2 and 1e-4).
+ * A warm-started candidate that stalls, or is still far from converged after 12 iterations, is restarted
+ * once from the cold start inside the kernel: a bad guess costs iterations, never the result.
+ * With warm == NULL, or x0 == lam0 == NULL, the start is the cold one of btrapz_solve_*_device. */
+typedef struct btrapz_warm {
+  const double *x0;
+  const double *lam0;
+  double *lam_out;
+  double mu0;
+  double smin;
+} btrapz_warm;
+
+/* btrapz_solve_ragged_device with a warm start (seg_count == NULL: uniform batch of seg_stride segments). */
+int btrapz_solve_warm_device(btrapz_ctx *ctx, const btrapz_shared *shared, const btrapz_options *opt,
+                             const btrapz_warm *warm, int B, int seg_stride, const double *seg,
+                             const int *seg_count, const double *init, const double *ref_end,
+                             const double *dl_bounds, double *ctrl, double *cost, int *status,
+                             int *iters, void *stream);
+
+/* State (p, v, a) of solved candidates at arbitrary times: x[b][axis][j] at times[b][j] seconds from the
+ * start of candidate b's horizon (Bezier evaluation of solve_3d.cc:1366-1388; beyond the last segment the
+ * end state is extrapolated at constant velocity).  With times = shift + the cumulative durations of the
+ * NEXT step's segments this is x0 of btrapz_warm.  times [B][n_times], x [B][2][n_times][3]; seg_count may
+ * be NULL. */
+int btrapz_eval_states_device(btrapz_ctx *ctx, int B, int seg_stride, const int *seg_count,
+                              const double *seg, const double *ctrl, int n_times, const double *times,
+                              double *x, void *stream);
+
 /* Host-pointer convenience wrapper: H2D, solve, D2H, synchronous. */
 int btrapz_solve_batch_host(btrapz_ctx *ctx, const btrapz_shared *shared,
                             const btrapz_options *opt, int B, int S, const double *seg,

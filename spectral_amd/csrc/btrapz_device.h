@@ -40,6 +40,11 @@ struct KernelArgs {
   Shared sh;
   double eps;
   int max_iter;
+  // warm start (btrapz_warm): all optional
+  const double *x0;         // [B][2][seg_stride][3] joint states at the end of every segment
+  const double *lam0;       // [2][36][B][seg_stride] multipliers of an earlier solve
+  double *lam_out;          // same layout, multipliers at the end of this solve
+  double mu0, smin;         // lambda = lam0 + mu0 / s , s = max(gap, smin)
 };
 
 struct CorridorArgs {
@@ -60,10 +65,13 @@ __global__ void bucket_prefix_kernel(int *meta);
 __global__ void bucket_scatter_kernel(int B, int seg_stride, const int *seg_count, int *meta, int *order,
                                       double *axis_obj, int *axis_status, int *axis_iters);
 __global__ void ipm_solve_kernel(const KernelArgs a, const double *__restrict__ mqm);
+__global__ void ipm_solve_warm_kernel(const KernelArgs a, const double *__restrict__ mqm);  // + btrapz_warm
 __global__ void finalize_kernel(int B, const double *axis_obj, const int *axis_status, const int *axis_iters,
                                 double *cost, int *status, int *iters);
 __global__ void argmin_kernel(int group, long long index_base, const double *cost, long long *best_idx,
                               double *best_cost);
+__global__ void eval_states_kernel(int B, int seg_stride, const int *seg_count, const double *seg, const double *ctrl,
+                                   int n_times, const double *times, double *x);
 __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, double delta, const double *seg,
                               const double *init, const double *ctrl, int nsel, const long long *sel, int max_points,
                               double *out, int *npoints);

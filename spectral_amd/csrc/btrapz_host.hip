@@ -109,8 +109,8 @@ static int ensure_axis_ws(btrapz_ctx *c, size_t nprob) {
 }
 
 // Uniform batches: seg_count == nullptr, S segments each.  Ragged: S is the slot stride, seg_count[b] the use.
-static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B, int S,
-                        const int *seg_count, const double *seg, const double *init, const double *ref_end,
+static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, const btrapz_warm *warm,
+                        int B, int S, const int *seg_count, const double *seg, const double *init, const double *ref_end,
                         const double *dl_bounds, double *ctrl, double *cost, int *status, int *iters, void *stream_) {
   if (!c) return BTRAPZ_EINVAL;
   if (!sh || B < 1 || S < 1 || (!seg_count && S > BTRAPZ_MAX_SEGMENTS) || !seg || !init || !ref_end || !dl_bounds ||
@@ -146,6 +146,9 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   a.sh.variant = sh->variant;
   a.eps = (opt && opt->eps > 0) ? opt->eps : 1e-9;
   a.max_iter = (opt && opt->max_iter > 0) ? opt->max_iter : 60;
+  a.x0 = warm ? warm->x0 : nullptr; a.lam0 = warm ? warm->lam0 : nullptr; a.lam_out = warm ? warm->lam_out : nullptr;
+  a.mu0 = (warm && warm->mu0 > 0) ? warm->mu0 : 1e-4;
+  a.smin = (warm && warm->smin > 0) ? warm->smin : 1e-2;
   unsigned blocks;
   if (seg_count) {
     if ((size_t)B > c->order_cap) {
@@ -168,7 +171,10 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     const int gpw = 64 / S;  // axis problems per wavefront; wave w: axis w&1 of candidates (w>>1)*gpw + [0,gpw)
     blocks = 2u * (unsigned)((B + gpw - 1) / gpw);
   }
-  hipLaunchKernelGGL(ipm_solve_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
+  if (a.x0 || a.lam0 || a.lam_out)
+    hipLaunchKernelGGL(ipm_solve_warm_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
+  else
+    hipLaunchKernelGGL(ipm_solve_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, B, c->d_axis_obj, c->d_axis_status,
                      c->d_axis_iters, cost, status, iters);
@@ -180,7 +186,7 @@ BTRAPZ_EXPORT int btrapz_solve_batch_device(btrapz_ctx *c, const btrapz_shared *
                                          int S, const double *seg, const double *init, const double *ref_end,
                                          const double *dl_bounds, double *ctrl, double *cost, int *status, int *iters,
                                          void *stream) {
-  return solve_common(c, sh, opt, B, S, nullptr, seg, init, ref_end, dl_bounds, ctrl, cost, status, iters, stream);
+  return solve_common(c, sh, opt, nullptr, B, S, nullptr, seg, init, ref_end, dl_bounds, ctrl, cost, status, iters, stream);
 }
 
 BTRAPZ_EXPORT int btrapz_solve_ragged_device(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int B,
@@ -188,8 +194,30 @@ BTRAPZ_EXPORT int btrapz_solve_ragged_device(btrapz_ctx *c, const btrapz_shared 
                                           const double *ref_end, const double *dl_bounds, double *ctrl, double *cost,
                                           int *status, int *iters, void *stream) {
   if (c && !seg_count) { c->err = "seg_count is null"; return BTRAPZ_EINVAL; }
-  return solve_common(c, sh, opt, B, seg_stride, seg_count, seg, init, ref_end, dl_bounds, ctrl, cost, status, iters,
-                      stream);
+  return solve_common(c, sh, opt, nullptr, B, seg_stride, seg_count, seg, init, ref_end, dl_bounds, ctrl, cost, status,
+                      iters, stream);
+}
+
+BTRAPZ_EXPORT int btrapz_solve_warm_device(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt,
+                                        const btrapz_warm *warm, int B, int seg_stride, const double *seg,
+                                        const int *seg_count, const double *init, const double *ref_end,
+                                        const double *dl_bounds, double *ctrl, double *cost, int *status, int *iters,
+                                        void *stream) {
+  return solve_common(c, sh, opt, warm, B, seg_stride, seg_count, seg, init, ref_end, dl_bounds, ctrl, cost, status,
+                      iters, stream);
+}
+
+BTRAPZ_EXPORT int btrapz_eval_states_device(btrapz_ctx *c, int B, int seg_stride, const int *seg_count, const double *seg,
+                                         const double *ctrl, int n_times, const double *times, double *x,
+                                         void *stream_) {
+  if (!c) return BTRAPZ_EINVAL;
+  if (B < 1 || seg_stride < 1 || n_times < 1 || !seg || !ctrl || !times || !x) { c->err = "invalid argument"; return BTRAPZ_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const long long n = (long long)B * n_times;
+  hipLaunchKernelGGL(eval_states_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, B,
+                     seg_stride, seg_count, seg, ctrl, n_times, times, x);
+  HIPCHK(c, hipGetLastError());
+  return BTRAPZ_OK;
 }
 
 BTRAPZ_EXPORT int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B, int N, int num_obs, double delta,

@@ -170,7 +170,10 @@ __device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gb
 }
 
 // -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+// WARM = false: the cold-start kernel (bench path).  WARM = true adds the warm start and the cold restart of a
+// group whose guess did not pay off; a separate instantiation, so the cold kernel keeps its register footprint.
+template <bool WARM>
+__device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double *__restrict__ mqm) {
   __shared__ double lds[L_ROWS][64];
 
   const int lane = threadIdx.x;
@@ -294,15 +297,16 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
     bnorm = fmax(bnorm, fmax(fabs(LO(r)), fabs(UP(r))));
   END_ROWS
   UNROLL for (int i = 0; i < 6; i++) qn = fmax(qn, fabs(q[i]));
-  // ---------------- starting point: constant-velocity propagation of the initial state -----
-  double X[3];
+  // ---------------- starting point: constant-velocity propagation of the initial state, or the caller's
+  // joint states (warm start; a lane whose values are not finite keeps the cold start) -----
+  double X[3], Xcold0;
   {
     __syncthreads();
     lds[L_RED][lane] = t;
     __syncthreads();
     double tsum = 0.0;
     for (int j = 0; j < S; j++) tsum += (j <= k) ? lds[L_RED][gbase + j] : 0.0;
-    X[0] = Xinit[0] + Xinit[1] * tsum; X[1] = Xinit[1]; X[2] = 0.0;
+    Xcold0 = Xinit[0] + Xinit[1] * tsum;
   }
   {
     const Red4 r0 = group_reduce<0, 1, 1, 2>(lds, lane, gbase, S, 0.0, bnorm, qn, gapmin);
@@ -313,7 +317,9 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
   double sl[18], su[18];
 #define LL(r) lds[L_LL + r][lane]
 #define LU(r) lds[L_LU + r][lane]
-  {
+  // cold start of this lane: slacks max(gap, 1), multipliers 1
+  auto cold_start = [&]() {
+    X[0] = Xcold0; X[1] = Xinit[1]; X[2] = 0.0;
     double Xp[3], c[6];
     UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(X[i]); Xp[i] = first ? Xinit[i] : v; }
     U_apply(nm, Xp, c[0], c[1], c[2]);
@@ -323,7 +329,40 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
       sl[r] = fmax(gc_r - LO(r), 1.0); su[r] = fmax(UP(r) - gc_r, 1.0);
       LL(r) = 1.0; LU(r) = 1.0;
     END_ROWS
+  };
+  // multipliers of this lane in the warm-start arrays: [axis][row 0..35][b][k]
+  const size_t lam_row = (size_t)a.B * a.seg_stride, lam_e = (size_t)axis * 36 * lam_row + (size_t)b * a.seg_stride + k;
+  const bool warm_started = WARM && (a.x0 || a.lam0);
+  if (WARM && warm_started) {
+    // warm: slacks floored at smin, multipliers = earlier multipliers (sanitised) + mu0 / s so that every
+    // complementarity product is at least mu0
+    X[0] = Xcold0; X[1] = Xinit[1]; X[2] = 0.0;
+    if (a.x0) {
+      const double *xw = a.x0 + (((size_t)b * 2 + axis) * a.seg_stride + k) * 3;
+      const double w0 = xw[0], w1 = xw[1], w2 = xw[2];
+      if (fabs(w0) < 1e300 && fabs(w1) < 1e300 && fabs(w2) < 1e300) { X[0] = w0; X[1] = w1; X[2] = w2; }
+    }
+    double Xp[3], c[6];
+    UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(X[i]); Xp[i] = first ? Xinit[i] : v; }
+    U_apply(nm, Xp, c[0], c[1], c[2]);
+    V_apply(nm, X, c[3], c[4], c[5]);
+    const double smin = a.smin, mu0 = a.mu0;
+    FOR_ROWS(r)
+      const double gc_r = row_dot<r>(c, t);
+      const double s_l = fmax(gc_r - LO(r), smin), s_u = fmax(UP(r) - gc_r, smin);
+      double l_l = 0.0, l_u = 0.0;
+      if (a.lam0) {
+        const double p_l = a.lam0[lam_e + (size_t)r * lam_row], p_u = a.lam0[lam_e + (size_t)(18 + r) * lam_row];
+        l_l = (p_l >= 0.0 && p_l < 1e300) ? p_l : 0.0; l_u = (p_u >= 0.0 && p_u < 1e300) ? p_u : 0.0;
+      }
+      sl[r] = s_l; su[r] = s_u;
+      LL(r) = l_l + mu0 * rcp(s_l); LU(r) = l_u + mu0 * rcp(s_u);
+    END_ROWS
+  } else {
+    cold_start();
   }
+  bool restarted = !warm_started;   // a warm-started group that stalls gets ONE cold restart
+  int it0 = 0;                      // iteration at which the current start was made
 
   const double eps = a.eps;
   const double inv_m = 1.0 / (36.0 * (double)S);
@@ -378,18 +417,34 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
     // relative to the bound scale, complementarity absolute.
     const double rd_eff = fmax(rr.b - 2e-13 * rr.d, 0.0);
     const double score = fmax(fmax(rd_eff / (1.0 + qn), rr.c / (1.0 + bnorm)), mu);
+    bool restart_now = false;
     if (!done) {
       iters = iter;
       if (score < best_score) { best_score = score; best_it = iter; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
 #ifndef ABL_FIXED
       // stop: converged; at the round-off floor (best < 1e-5, 3 iterations without progress); diverging or
-      // infeasible (8 iterations without progress after the start-up phase); not finite
-      if (score < eps || (best_score < 1e-5 && iter - best_it >= 3) || (iter >= 12 && iter - best_it >= 8) ||
-          !(score < 1e299))
-        done = true;
+      // infeasible (8 iterations without progress after the start-up phase); not finite.  A warm-started group
+      // that ends in the last two ways, or is still far from converged after 12 iterations (a useful guess
+      // needs about 5, a cold start 8-14; below 1e-4 the method is in its fast final phase), or is still running
+      // after 24, is restarted once from the cold start: a bad guess must neither turn a solvable candidate
+      // into a failure nor cost more than a bounded number of iterations.
+      const bool stalled = (iter - it0 >= 12 && iter - best_it >= 8) || !(score < 1e299);
+      if (score < eps || (best_score < 1e-5 && iter - best_it >= 3)) done = true;
+      else if (WARM && !restarted && (stalled || (iter - it0 >= 12 && best_score > 1e-4) || iter - it0 >= 24)) restart_now = true;
+      else if (stalled) done = true;
 #endif
     }
     if (__all(done)) break;
+    if (WARM && __any(restart_now)) {
+      // wave-uniform branch; the other groups of the wavefront only lose this iteration's Newton step.  A group
+      // restarts as a whole (the score is group-uniform), so the DPP reads inside cold_start stay in the group.
+      if (restart_now) {
+        cold_start();
+        best_score = 1e300; best_it = iter + 1; it0 = iter + 1; restarted = true;
+        Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2];
+      }
+      continue;
+    }
 
     // ---- 2. Newton matrix: H = P + G'WG ; M = Phi' H Phi ; block tridiagonal T, M01 ----
     double M01[9], T[6];
@@ -603,7 +658,12 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
 #undef ROW_BASE
   }
 
-  // ---------------- write back: control points, per-axis objective/status ------------------
+  // ---------------- write back: multipliers (warm start of a later solve), control points, objective/status ----
+  if (WARM && a.lam_out && valid) {
+    FOR_ROWS(r)
+      a.lam_out[lam_e + (size_t)r * lam_row] = LL(r); a.lam_out[lam_e + (size_t)(18 + r) * lam_row] = LU(r);
+    END_ROWS
+  }
   {
     double Xp[3], c[6];
     UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(Xb[i]); Xp[i] = first ? Xinit[i] : v; }
@@ -634,6 +694,13 @@ __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const
       }
     }
   }
+}
+
+__global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  ipm_solve_body<false>(a, mqm);
+}
+__global__ __launch_bounds__(64) void ipm_solve_warm_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  ipm_solve_body<true>(a, mqm);
 }
 
 // ---- per-candidate cost/status from the two axis problems (acceptance: solve_3d.cc:1251-1277)
@@ -677,6 +744,44 @@ __global__ __launch_bounds__(256) void argmin_kernel(int group, long long index_
   if (threadIdx.x == 0) {
     best_idx[g] = si[0] >= 0 ? si[0] + index_base : -1;
     best_cost[g] = sc[0];
+  }
+}
+
+// ---- state of solved trajectories at arbitrary times (warm start of the next replanning step) ----------
+// thread = (candidate, time index).  x[b][axis][j] = (p, v, a) at times[b][j] seconds from the start of the
+// candidate's horizon; the Bezier evaluation is the one of solve_3d.cc:1366-1388.  Past the last segment the end
+// state is extrapolated at constant velocity (a = 0); before 0 the start of the first segment is used.
+__global__ void eval_states_kernel(int B, int seg_stride, const int *seg_count, const double *seg, const double *ctrl,
+                                   int n_times, const double *times, double *x) {
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long long)B * n_times) return;
+  const int b = (int)(id / n_times), j = (int)(id - (long long)b * n_times);
+  const int S = seg_count ? seg_count[b] : seg_stride;
+  double *xs = x + (((size_t)b * 2 + 0) * n_times + j) * 3, *xl = x + (((size_t)b * 2 + 1) * n_times + j) * 3;
+  if (S < 1 || S > seg_stride) {
+    UNROLL for (int i = 0; i < 3; i++) { xs[i] = __longlong_as_double(0x7ff8000000000000LL); xl[i] = xs[i]; }
+    return;
+  }
+  const double *tt = seg + (size_t)BTRAPZ_F_T * B * seg_stride + (size_t)b * seg_stride;
+  double rem = times[(size_t)b * n_times + j];
+  if (!(rem > 0.0)) rem = 0.0;
+  int k = 0;
+  while (k < S - 1 && rem > tt[k]) { rem -= tt[k]; ++k; }
+  const double t = tt[k];
+  const double over = rem > t ? rem - t : 0.0;     // beyond the horizon
+  const double tau = over > 0.0 ? 1.0 : rem / t, om = 1.0 - tau;
+  const double bc0[6] = {1, 5, 10, 10, 5, 1}, bc1[5] = {1, 4, 6, 4, 1}, bc2[4] = {1, 3, 3, 1};
+  double pw[6], qw[6];
+  pw[0] = 1.0; qw[0] = 1.0;
+  UNROLL for (int i = 1; i < 6; i++) { pw[i] = pw[i - 1] * tau; qw[i] = qw[i - 1] * om; }
+  UNROLL for (int ax = 0; ax < 2; ax++) {
+    const double *c = ctrl + (size_t)b * 12 * seg_stride + (size_t)ax * 6 * S + (size_t)k * 6;
+    double p = 0, v = 0, acc = 0;
+    UNROLL for (int i = 0; i < 6; i++) p += c[i] * bc0[i] * pw[i] * qw[5 - i];
+    UNROLL for (int i = 0; i < 5; i++) v += 5.0 * (c[i + 1] - c[i]) * bc1[i] * pw[i] * qw[4 - i];
+    UNROLL for (int i = 0; i < 4; i++) acc += 20.0 * (c[i + 2] - 2.0 * c[i + 1] + c[i]) * bc2[i] * pw[i] * qw[3 - i];
+    double *o = ax == 0 ? xs : xl;
+    o[0] = p * t + v * over; o[1] = v; o[2] = over > 0.0 ? 0.0 : acc / t;
   }
 }
 

@@ -44,6 +44,12 @@ class COptions(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("eps", C.c_double)]
 
 
+class CWarm(C.Structure):
+    """btrapz_warm (include/btrapz_hip.h): optional warm start of a solve."""
+    _fields_ = [("x0", C.c_void_p), ("lam0", C.c_void_p), ("lam_out", C.c_void_p),
+                ("mu0", C.c_double), ("smin", C.c_double)]
+
+
 class CParams(C.Structure):
     """include/btrapz/py_cpp_.h:6-21 == trp_wrapper.py:19-32."""
     _fields_ = [("s_acc_weight", C.c_double), ("s_jerk_weight", C.c_double),
@@ -68,7 +74,8 @@ class CSegment(C.Structure):
 EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "btrapz_destroy", "btrapz_last_error",
            "btrapz_device_count", "btrapz_solve_batch_device", "btrapz_argmin_device",
            "btrapz_sample_device", "btrapz_solve_batch_host", "btrapz_solve_ragged_device",
-           "btrapz_corridor_batch_device", "btrapz_sample_ragged_device")
+           "btrapz_corridor_batch_device", "btrapz_sample_ragged_device", "btrapz_solve_warm_device",
+           "btrapz_eval_states_device")
 
 
 def build(verbose=False):
@@ -128,6 +135,9 @@ def lib():
                                                    dp, dp, dp, dp, dp, dp, C.c_int, dp, ip, dp, dp, vp]
         l.btrapz_sample_ragged_device.argtypes = [vp, C.c_int, C.c_int, ip, C.c_double, dp, dp, dp, C.c_int, llp,
                                                   C.c_int, dp, ip, vp]
+        l.btrapz_solve_warm_device.argtypes = [vp, C.POINTER(CShared), C.POINTER(COptions), C.POINTER(CWarm), C.c_int,
+                                               C.c_int, dp, ip, dp, dp, dp, dp, dp, ip, ip, vp]
+        l.btrapz_eval_states_device.argtypes = [vp, C.c_int, C.c_int, ip, dp, dp, C.c_int, dp, dp, vp]
         _lib = l
     return _lib
 
@@ -193,6 +203,25 @@ class Context:
                                                      ptr(seg_count), ptr(init), ptr(ref_end), ptr(dl_bounds),
                                                      ptr(ctrl), ptr(cost), ptr(status), ptr(iters),
                                                      C.c_void_p(stream or 0)), "btrapz_solve_ragged_device")
+
+    def solve_warm_device(self, B, seg_stride, shared, seg, seg_count, init, ref_end, dl_bounds, ctrl, cost, status,
+                          iters=None, x0=None, lam0=None, lam_out=None, mu0=0.0, smin=0.0, stream=None, max_iter=0,
+                          eps=0.0):
+        """btrapz_solve_warm_device: seg_count None = uniform batch; x0 / lam0 / lam_out optional."""
+        sh = CShared.from_shared(shared); opt = COptions(int(max_iter), float(eps))
+        raw = lambda t: t.data_ptr() if t is not None else None
+        warm = CWarm(raw(x0), raw(lam0), raw(lam_out), float(mu0), float(smin))
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self._check(lib().btrapz_solve_warm_device(self._h, C.byref(sh), C.byref(opt), C.byref(warm), B, seg_stride,
+                                                   ptr(seg), ptr(seg_count), ptr(init), ptr(ref_end), ptr(dl_bounds),
+                                                   ptr(ctrl), ptr(cost), ptr(status), ptr(iters),
+                                                   C.c_void_p(stream or 0)), "btrapz_solve_warm_device")
+
+    def eval_states_device(self, B, seg_stride, seg_count, seg, ctrl, n_times, times, x, stream=None):
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self._check(lib().btrapz_eval_states_device(self._h, B, seg_stride, ptr(seg_count), ptr(seg), ptr(ctrl),
+                                                    int(n_times), ptr(times), ptr(x), C.c_void_p(stream or 0)),
+                    "btrapz_eval_states_device")
 
     def corridor_batch_device(self, variant, B, N, num_obs, delta, s_bounds, l_bounds, ds_bounds, dl_bounds_knots,
                               s_ref, l_ref, seg_stride, seg, seg_count, ref_end, dl_bounds, stream=None):

@@ -39,13 +39,46 @@ class BatchSolver:
                                   iters=torch.empty(B, dtype=torch.int32, device=d))
         return self._out[key]
 
-    def solve(self, dbatch, shared, max_iter=0, eps=0.0, out=None):
-        """Launches the solve on torch's current stream; returns dict of device tensors."""
+    def solve(self, dbatch, shared, max_iter=0, eps=0.0, out=None, warm=None, keep_multipliers=False):
+        """Launches the solve on torch's current stream; returns dict of device tensors.
+
+        warm: dict with optional "x0" ([B,2,S,3] joint states, e.g. from eval_states) and "lam" ([2,36,B,S]
+        multipliers kept by an earlier solve) plus optional "mu0", "smin" -- btrapz_warm.  keep_multipliers
+        adds this solve's multipliers to the result as "lam"."""
         o = out if out is not None else self._buffers(dbatch.B, dbatch.S)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.ctx.solve_device(dbatch.B, dbatch.S, shared, dbatch.seg, dbatch.init, dbatch.ref_end, dbatch.dl_bounds,
-                              o["ctrl"], o["cost"], o["status"], o["iters"], stream=stream, max_iter=max_iter, eps=eps)
+        if warm is None and not keep_multipliers:
+            self.ctx.solve_device(dbatch.B, dbatch.S, shared, dbatch.seg, dbatch.init, dbatch.ref_end,
+                                  dbatch.dl_bounds, o["ctrl"], o["cost"], o["status"], o["iters"], stream=stream,
+                                  max_iter=max_iter, eps=eps)
+            return o
+        warm = warm or {}
+        x0, lam0 = warm.get("x0"), warm.get("lam")
+        if x0 is not None:
+            assert x0.dtype == torch.float64 and x0.is_contiguous() and tuple(x0.shape) == (dbatch.B, 2, dbatch.S, 3)
+        if lam0 is not None:
+            assert lam0.dtype == torch.float64 and lam0.is_contiguous() and tuple(lam0.shape) == (2, 36, dbatch.B, dbatch.S)
+        lam_out = None
+        if keep_multipliers:
+            lam_out = o.get("lam_buf")
+            if lam_out is None or lam_out is lam0:   # never write the array that is being read
+                lam_out = torch.empty((2, 36, dbatch.B, dbatch.S), dtype=torch.float64, device=self.device)
+            o = dict(o); o["lam"] = lam_out
+        self.ctx.solve_warm_device(dbatch.B, dbatch.S, shared, dbatch.seg, None, dbatch.init, dbatch.ref_end,
+                                   dbatch.dl_bounds, o["ctrl"], o["cost"], o["status"], o["iters"], x0=x0, lam0=lam0,
+                                   lam_out=lam_out, mu0=warm.get("mu0", 0.0), smin=warm.get("smin", 0.0),
+                                   stream=stream, max_iter=max_iter, eps=eps)
         return o
+
+    def eval_states(self, dbatch, ctrl, times):
+        """(p, v, a) of every candidate's solved trajectory at times[b][j] (seconds from the start of its
+        horizon) -> [B, 2, n_times, 3]; the x0 of a warm start."""
+        times = times.to(self.device, dtype=torch.float64).contiguous()
+        n = times.shape[1]
+        x = torch.empty((dbatch.B, 2, n, 3), dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.ctx.eval_states_device(dbatch.B, dbatch.S, None, dbatch.seg, ctrl, n, times, x, stream=stream)
+        return x
 
     def corridor_batch(self, kb, variant, seg_stride=16):
         """Device corridor stage on a spectral_amd.knots.KnotBatch -> dict of device tensors forming a ragged

@@ -32,12 +32,14 @@ def _smoothstep5(x):
     return x * x * x * (10.0 + x * (-15.0 + 6.0 * x))
 
 
-def make_batch(B, S, config=2, variant=0, seed=None, dtype=np.float64, agents=None):
+def make_batch(B, S, config=2, variant=0, seed=None, dtype=np.float64, agents=None, lateral_per_agent=False):
     """Returns (Batch, Shared).  All t_k = 1.0 s (10 knots of 0.1 s), N = 10*S+1.
 
     agents=G (config 5): the batch is G ego agents x B/G candidate corridors each.  Candidates of one agent
     are alternatives for the SAME ego: they share the initial state and the longitudinal reference and differ
-    in corridor margins, obstacle ramps and lane-change target/timing."""
+    in corridor margins, obstacle ramps and lane-change target/timing (lateral_per_agent=True: the lane-change
+    plan is the agent's too, so that an ego that follows one candidate stays inside the others' corridors --
+    the receding-horizon tool tools/mpc_bench.py needs that)."""
     rng = np.random.default_rng(SEED_BASE + config if seed is None else seed)
     if agents:
         assert B % agents == 0
@@ -61,11 +63,13 @@ def make_batch(B, S, config=2, variant=0, seed=None, dtype=np.float64, agents=No
     s_star = np.concatenate([np.zeros((B, 1)), np.cumsum(0.5 * (v[:, 1:] + v[:, :-1]) * sh.delta, axis=1)], axis=1)
     # lateral reference: smoothstep between two lanes
     lanes = np.array([1.2, 2.0, 3.5])
-    la = share(lambda n: rng.integers(0, 3, n)); lb = rng.integers(0, 3, B)
+    la = share(lambda n: rng.integers(0, 3, n))
+    lb = share(lambda n: rng.integers(0, 3, n)) if (agents and lateral_per_agent) else rng.integers(0, 3, B)
     l0, l1 = lanes[la], lanes[lb]
     dl = np.abs(l1 - l0)
     dur = np.maximum(3.0, np.sqrt(5.8 * dl / 0.45))
-    t_start = rng.integers(1, max(2, int(T - dur.max()) - 1), B).astype(float)
+    t_hi = max(2, int(T - dur.max()) - 1)
+    t_start = (share(lambda n: rng.integers(1, t_hi, n)) if (agents and lateral_per_agent) else rng.integers(1, t_hi, B)).astype(float)
     l_star = l0[:, None] + (l1 - l0)[:, None] * _smoothstep5((tt[None, :] - t_start[:, None]) / dur[:, None])
 
     seg = np.zeros((NUM_SEG_FIELDS, B, S), dtype=dtype)

@@ -54,6 +54,8 @@ def test_params_layout_is_the_reference_abi():
         assert P.iteration.offset == 80
     assert C.sizeof(native.CShared) == 21 * 8 + 8
     assert C.sizeof(native.CSegment) == 104
+    assert C.sizeof(native.CWarm) == 3 * 8 + 2 * 8      # btrapz_warm: three pointers, two doubles
+    assert [f[0] for f in native.CWarm._fields_] == ["x0", "lam0", "lam_out", "mu0", "smin"]
 
 
 def test_no_gpu_means_loud_failure_not_cpu_fallback(built, tmp_path):

@@ -52,3 +52,22 @@ def test_receding_horizon_per_agent_argmin():
             ps, vs, as_ = bezier_state(ctrl[w, 0:6], t0, dt / t0)
             pl, vl, al = bezier_state(ctrl[w, 6 * S:6 * S + 6], t0, dt / t0)
             batch.init[a * CAND:(a + 1) * CAND] = [ps, vs, as_, pl, vl, al]
+
+
+def test_mpc_tool_warm_start_beats_cold_and_matches_oracle():
+    """tools/mpc_bench.py (config 5 loop with window roll, eval_states, warm start) on a small fleet: winners agree
+    with the oracle's x* at the checked steps, everything stays solved, warm start needs fewer iterations."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = lambda *extra: json.loads(subprocess.run(
+        [sys.executable, os.path.join(root, "tools", "mpc_bench.py"), "--agents", "8", "--cand", "64", "--steps", "56",
+         "--check", "3", *extra], check=True, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1])
+    warm, cold = run(), run("--cold")
+    for r in (warm, cold):
+        assert r["solved_fraction_min"] >= 0.98, r
+        assert len(r["oracle_checks"]) == 3
+        assert max(c["worst_rel_err_vs_oracle"] for c in r["oracle_checks"]) <= 1e-5, r["oracle_checks"]
+    assert warm["mean_ipm_iterations"] <= cold["mean_ipm_iterations"] - 2.0, (warm, cold)

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 5: receding-horizon replanning, 128 ego agents x 512 candidate corridors of 20 segments,
+per-agent arg-min, cold vs warm-started solves.
+
+    python tools/mpc_bench.py [--steps 250] [--dt 0.02] [--agents 128] [--cand 512] [--cold] [--check 3]
+
+World: every candidate has a fixed corridor timeline of 1-s pieces (spectral_amd.synth, agents mode).  At step n
+the horizon starts at now = n*dt: the first segment is the rest of the piece containing `now` (its lines
+re-based to `now`; when less than one knot of it is left the window rolls and the next piece is extended
+backwards instead, so min_first <= t_0 <= 1 + min_first, --min-first 0.1 = one knot), followed by 19 whole pieces.  Every agent's initial state is its
+previous winner's state dt later (btrapz_eval_states_device); the warm start is the candidate's own previous
+trajectory at the new joint times plus its previous multipliers (rolled by one segment when the window rolls).
+
+What is timed per step (HIP events around the whole step, inputs resident): window assembly (torch slicing --
+workload generation, not part of the library), btrapz_eval_states_device x2, btrapz_solve_warm_device,
+btrapz_argmin_device(group = candidates per agent).  One JSON line on stdout."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=250)
+    ap.add_argument("--dt", type=float, default=0.02, help="replanning period in seconds (50 Hz)")
+    ap.add_argument("--agents", type=int, default=128)
+    ap.add_argument("--cand", type=int, default=512)
+    ap.add_argument("--segments", type=int, default=20)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--cold", action="store_true", help="cold start at every step (the reference's behaviour)")
+    ap.add_argument("--check", type=int, default=3, help="steps whose winners are checked against the oracle's x*")
+    ap.add_argument("--min-first", type=float, default=0.1,
+                    help="shortest first segment in seconds before the window rolls (0.1 = one knot)")
+    ap.add_argument("--mu0", type=float, default=0.0, help="btrapz_warm.mu0 (0 = library default)")
+    ap.add_argument("--smin", type=float, default=0.0, help="btrapz_warm.smin (0 = library default)")
+    ap.add_argument("--trace", action="store_true", help="per-step latency / iterations on stderr")
+    a = ap.parse_args()
+
+    import torch
+    from spectral_amd import layout as L
+    from spectral_amd import synth
+    from spectral_amd.solver import BatchSolver, DeviceBatch
+
+    S, G, C = a.segments, a.agents, a.cand
+    B = G * C
+    horizon_pieces = S + int(np.ceil(a.steps * a.dt)) + 2
+    assert horizon_pieces <= 64
+    world, sh = synth.make_batch(B, horizon_pieces, config=5, variant=a.variant, agents=G, lateral_per_agent=True)
+    solver = BatchSolver(0)
+    dev = solver.device
+    wseg = torch.from_numpy(world.seg).to(dev)                       # [F][B][pieces]
+    dl_bounds = torch.from_numpy(world.dl_bounds).to(dev)
+    init = torch.from_numpy(world.init).to(dev).clone()
+    pairs = ((L.F_DOWN_BIAS, L.F_DOWN_SKEW), (L.F_UPP_BIAS, L.F_UPP_SKEW), (L.F_L_DOWN_BIAS, L.F_L_DOWN_SKEW),
+             (L.F_L_UPP_BIAS, L.F_L_UPP_SKEW), (L.F_X_BIAS, L.F_X_SKEW), (L.F_Y_BIAS, L.F_Y_SKEW))
+
+    def window(now):
+        j0 = int(np.floor(now + 1e-12))
+        if j0 + 1 - now < a.min_first - 1e-12:
+            j0 += 1
+        off = now - j0                                               # in [-min_first, 1 - min_first]
+        seg = wseg[:, :, j0:j0 + S].contiguous()
+        seg[L.F_T, :, 0] = 1.0 - off
+        for bias, skew in pairs:
+            seg[bias, :, 0] += seg[skew, :, 0] * off
+        ref_end = torch.stack([wseg[L.F_X_BIAS, :, j0 + S], wseg[L.F_Y_BIAS, :, j0 + S]], dim=1).contiguous()
+        return j0, seg, ref_end
+
+    class Win:                                                       # the DeviceBatch interface BatchSolver uses
+        pass
+
+    prev = None
+    lat, iters_mean, solved = [], [], []
+    checks = []
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    check_steps = set(np.linspace(0, a.steps - 1, a.check).astype(int).tolist()) if a.check > 0 else set()
+    torch.cuda.synchronize()
+    wall0 = time.perf_counter()
+    for n in range(a.steps):
+        now = n * a.dt
+        ev0.record()
+        j0, seg, ref_end = window(now)
+        db = Win(); db.B, db.S, db.seg, db.init, db.ref_end, db.dl_bounds = B, S, seg, init, ref_end, dl_bounds
+        warm = None
+        if prev is not None and not a.cold:
+            times = (torch.cumsum(seg[L.F_T], dim=1) + a.dt).contiguous()
+            x0 = solver.eval_states(prev["db"], prev["ctrl"], times)
+            lam = prev["lam"]
+            if j0 != prev["j0"]:                                     # the window rolled: segment k was k+1
+                lam = torch.roll(lam, shifts=-1, dims=3); lam[:, :, :, -1] = 0.0
+            warm = dict(x0=x0, lam=lam, mu0=a.mu0, smin=a.smin)
+        out = solver.solve(db, sh, warm=warm, keep_multipliers=not a.cold,
+                           out=dict(ctrl=torch.empty((B, 12 * S), dtype=torch.float64, device=dev),
+                                    cost=torch.empty(B, dtype=torch.float64, device=dev),
+                                    status=torch.empty(B, dtype=torch.int32, device=dev),
+                                    iters=torch.empty(B, dtype=torch.int32, device=dev)))
+        bi, bc = solver.argmin(out["cost"], group=C)
+        # next initial state of every agent: its winner's state dt later
+        nxt = solver.eval_states(db, out["ctrl"], torch.full((B, 1), a.dt, dtype=torch.float64, device=dev))
+        w = bi.clamp(min=0)
+        st6 = torch.cat([nxt[w, 0, 0], nxt[w, 1, 0]], dim=1)          # [G][6]
+        has = (bi >= 0)[:, None]
+        keep = init.view(G, C, 6)[:, 0]
+        init = torch.where(has, st6, keep).repeat_interleave(C, dim=0).contiguous()
+        ev1.record()
+        torch.cuda.synchronize()
+        lat.append(ev0.elapsed_time(ev1))
+        stt = out["status"]
+        solved.append(float(((stt == 1) | (stt == 2)).double().mean().item()))
+        iters_mean.append(float(out["iters"].double().mean().item()) + 1.0)
+        if a.trace:
+            it = out["iters"].cpu().numpy() + 1
+            print("step %3d j0 %2d t0 %.2f ms %.2f iters mean %.2f p50 %d p99 %d max %d" %
+                  (n, j0, float(seg[L.F_T, 0, 0].item()), lat[-1], it.mean(), np.percentile(it, 50), np.percentile(it, 99), it.max()),
+                  file=sys.stderr)
+        if n in check_steps:
+            from oracle import oracle as O
+            from spectral_amd.layout import Batch
+            hb = Batch(B=B, S=S, seg=seg.cpu().numpy(), init=db.init.cpu().numpy(), ref_end=ref_end.cpu().numpy(),
+                       dl_bounds=world.dl_bounds)
+            ctrl = out["ctrl"].cpu().numpy()
+            worst = 0.0
+            for g in (0, G // 2, G - 1):
+                wi = int(bi[g].item())
+                if wi < 0:
+                    continue
+                xs, obj, st, _ = O.batch_solve(hb, sh, wi, wi + 1, exact=True)
+                if st[0] == 1:
+                    worst = max(worst, float(np.abs(ctrl[wi] - xs[0]).max() / np.abs(xs[0]).max()))
+            checks.append(dict(step=n, worst_rel_err_vs_oracle=worst))
+        prev = dict(db=db, ctrl=out["ctrl"], lam=out.get("lam"), j0=j0)
+    wall = time.perf_counter() - wall0
+    lat = np.array(lat)
+    steady = lat[1:] if len(lat) > 1 else lat
+    print(json.dumps({
+        "workload": "BASELINE.json config 5: %d agents x %d candidates, %d segments, replanned every %.0f ms, %d steps, %s"
+                    % (G, C, S, 1e3 * a.dt, a.steps, "cold start every step" if a.cold else "warm start"),
+        "mode": "cold" if a.cold else "warm", "min_first_segment_s": a.min_first,
+        "achieved_hz": 1e3 / float(steady.mean()), "target_hz": 1.0 / a.dt,
+        "p50_step_ms": float(np.percentile(steady, 50)), "p99_step_ms": float(np.percentile(steady, 99)),
+        "first_step_ms": float(lat[0]), "wall_s_incl_checks": wall,
+        "mean_ipm_iterations": float(np.mean(iters_mean[1:] if len(iters_mean) > 1 else iters_mean)),
+        "mean_ipm_iterations_first_step": iters_mean[0],
+        "solved_fraction_mean": float(np.mean(solved)), "solved_fraction_min": float(np.min(solved)),
+        "candidates_per_s": B * 1e3 / float(steady.mean()),
+        "oracle_checks": checks,
+    }))
+
+
+if __name__ == "__main__":
+    main()
