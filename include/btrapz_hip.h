@@ -57,6 +57,30 @@ enum { BTRAPZ_TRAPEZOID = 0, /* src/solve_3d.cc   */
 double btrapz_find_traj(int variant, const char *input_path, const char *output_path,
                         const Params *p);
 
+/* find_traj without the file side channel.  The reference hands its input over as a text
+ * file whose path is compiled into the library (trp_wrapper.cpp:23, written by cart_frenet.py:384-453) and
+ * returns the trajectory as a 3-decimal text file (trp_wrapper.cpp:288-301).  Here the same content comes in
+ * as arrays -- the grammar of trp_wrapper.cpp:39-144, field for field -- and the trajectory goes out in full
+ * precision.  Same computation, same return value (a_cost or 1e11) as btrapz_find_traj.
+ *   traj [7][cap]: rows t, s, l, ds, dl, dds, ddl (the columns of the reference's output file); at most cap
+ *                  samples are written, *n_points receives the trajectory's sample count.
+ *   ctrl [12*64] (may be NULL): control points, s axis then l axis; *n_segments receives S. */
+typedef struct btrapz_traj_input {
+  int N, num_obs;
+  double delta;
+  double init_s[3], init_l[3];
+  double ds_ref, dl_ref;
+  double dds[2], ddds[2], ddl[2], dddl[2];
+  const double *s_bounds;  /* [num_obs][N][2] (lower, upper) per knot */
+  const double *l_bounds;  /* [num_obs][N][2] */
+  const double *ds_bounds; /* [N][2] */
+  const double *dl_bounds; /* [N][2] */
+  const double *s_ref;     /* [N] */
+  const double *l_ref;     /* [N] */
+} btrapz_traj_input;
+double btrapz_find_traj_mem(int variant, const btrapz_traj_input *in, const Params *p, int cap,
+                            double *traj, int *n_points, double *ctrl, int *n_segments);
+
 /* Host-side corridor stage of find_traj alone (CorridorGeneration + CorridorSplit per obstacle,
  * then CollisionCheck: src/solve_3d.cc:323-486,729-772,488-714 ; src/cuboid_3d.cc:301-573).
  * Parses input_path, writes up to cap segments.  Returns the segment count S >= 1, 0 when no

@@ -125,22 +125,17 @@ BTRAPZ_EXPORT int btrapz_corridor_from_file(int variant, const char *input_path,
   return (int)seg.size();
 }
 
-BTRAPZ_EXPORT double btrapz_find_traj(int variant, const char *input_path, const char *output_path, const Params *p) {
-  const double FAIL = BTRAPZ_FAIL_SENTINEL;
-  if (!p || variant < 0 || variant > 1) return FAIL;
-  std::string in_path = input_path ? input_path : "";
-  if (in_path.empty()) { const char *e = getenv("BTRAPZ_INPUT"); in_path = e ? e : kDefaultInput[variant]; }
-  std::string out_path = output_path ? output_path : "";
-  if (out_path.empty()) {
-    const char *e = getenv("BTRAPZ_OUTPUT_PREFIX");
-    out_path = std::string(e ? e : kDefaultOutputPrefix[variant]) + std::to_string(p->iteration) + ".txt";
-  }
+namespace {
 
-  TrajInput in;
-  if (!read_traj_input(in_path, in)) {
-    fprintf(stderr, "btrapz: cannot read corridor file '%s'\n", in_path.c_str());
-    return FAIL;
-  }
+struct TrajResult {
+  int S = 0, np = 0;
+  std::vector<double> out;    // [6][np]: s, ds, dds, l, dl, ddl
+  std::vector<double> ctrl;   // [12 S]
+};
+
+// Everything of find_traj between the parser and the output file.  Returns a_cost or the failure sentinel.
+double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResult &res) {
+  const double FAIL = BTRAPZ_FAIL_SENTINEL;
   // corridor stage (host): trp_wrapper.cpp:176-188
   std::vector<std::vector<Segment>> lists;
   for (int o = 0; o < in.num_obs; o++) lists.push_back(extract_segments(variant, in.N, in.delta, in.s_bounds[o], in.l_bounds[o]));
@@ -230,6 +225,37 @@ BTRAPZ_EXPORT double btrapz_find_traj(int variant, const char *input_path, const
   const double *l = &out[(size_t)3 * max_points], *dl = &out[(size_t)4 * max_points], *ddl = &out[(size_t)5 * max_points];
   const double cost = trajectory_cost(variant, *p, in, max_points, s, ds, dds, l, dl, ddl);
 
+  res.S = S; res.np = max_points; res.out = std::move(out);
+  res.ctrl.resize((size_t)12 * S);
+  if (hipMemcpy(res.ctrl.data(), d_ctrl.p, res.ctrl.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return FAIL;
+  return cost;
+}
+
+}  // namespace
+
+BTRAPZ_EXPORT double btrapz_find_traj(int variant, const char *input_path, const char *output_path, const Params *p) {
+  const double FAIL = BTRAPZ_FAIL_SENTINEL;
+  if (!p || variant < 0 || variant > 1) return FAIL;
+  std::string in_path = input_path ? input_path : "";
+  if (in_path.empty()) { const char *e = getenv("BTRAPZ_INPUT"); in_path = e ? e : kDefaultInput[variant]; }
+  std::string out_path = output_path ? output_path : "";
+  if (out_path.empty()) {
+    const char *e = getenv("BTRAPZ_OUTPUT_PREFIX");
+    out_path = std::string(e ? e : kDefaultOutputPrefix[variant]) + std::to_string(p->iteration) + ".txt";
+  }
+
+  TrajInput in;
+  if (!read_traj_input(in_path, in)) {
+    fprintf(stderr, "btrapz: cannot read corridor file '%s'\n", in_path.c_str());
+    return FAIL;
+  }
+  TrajResult res;
+  const double cost = run_find_traj(variant, in, p, res);
+  if (cost == FAIL) return FAIL;
+  const int max_points = res.np;
+  const double *s = &res.out[0], *ds = &res.out[(size_t)max_points], *dds = &res.out[(size_t)2 * max_points];
+  const double *l = &res.out[(size_t)3 * max_points], *dl = &res.out[(size_t)4 * max_points], *ddl = &res.out[(size_t)5 * max_points];
+
   // trajectory file: trp_wrapper.cpp:288-301 (fixed, 3 decimals)
   if (FILE *f = fopen(out_path.c_str(), "w")) {
     for (int i = 0; i < max_points; i++)
@@ -238,5 +264,45 @@ BTRAPZ_EXPORT double btrapz_find_traj(int variant, const char *input_path, const
   } else if (verbose()) {
     fprintf(stderr, "btrapz: cannot write '%s'\n", out_path.c_str());
   }
+  return cost;
+}
+
+// find_traj without the file side channel: the parsed content of the corridor file comes in as
+// arrays, the trajectory goes out in full precision.
+BTRAPZ_EXPORT double btrapz_find_traj_mem(int variant, const btrapz_traj_input *ti, const Params *p, int cap, double *traj,
+                                       int *n_points, double *ctrl, int *n_segments) {
+  const double FAIL = BTRAPZ_FAIL_SENTINEL;
+  if (n_points) *n_points = 0;
+  if (n_segments) *n_segments = 0;
+  if (!ti || !p || variant < 0 || variant > 1 || ti->N < 3 || ti->N > 100000 || ti->num_obs < 0 || ti->num_obs > 1000 ||
+      !(ti->delta > 0) || (ti->num_obs > 0 && (!ti->s_bounds || !ti->l_bounds)) || !ti->ds_bounds || !ti->dl_bounds ||
+      !ti->s_ref || !ti->l_ref || cap < 0 || (cap > 0 && !traj))
+    return FAIL;
+  TrajInput in;
+  in.N = ti->N; in.delta = ti->delta; in.num_obs = ti->num_obs;
+  for (int i = 0; i < 3; i++) { in.init_s[i] = ti->init_s[i]; in.init_l[i] = ti->init_l[i]; }
+  in.ds_ref = ti->ds_ref; in.dl_ref = ti->dl_ref;
+  for (int i = 0; i < 2; i++) { in.dds[i] = ti->dds[i]; in.ddds[i] = ti->ddds[i]; in.ddl[i] = ti->ddl[i]; in.dddl[i] = ti->dddl[i]; }
+  const int N = in.N;
+  auto pairs = [N](const double *src, Bounds &b) { b.resize(N); for (int i = 0; i < N; i++) b[i] = {src[2 * i], src[2 * i + 1]}; };
+  in.s_bounds.resize(in.num_obs); in.l_bounds.resize(in.num_obs);
+  for (int o = 0; o < in.num_obs; o++) {
+    pairs(ti->s_bounds + (size_t)o * N * 2, in.s_bounds[o]);
+    pairs(ti->l_bounds + (size_t)o * N * 2, in.l_bounds[o]);
+  }
+  pairs(ti->ds_bounds, in.ds_bounds); pairs(ti->dl_bounds, in.dl_bounds);
+  in.s_ref.assign(ti->s_ref, ti->s_ref + N); in.l_ref.assign(ti->l_ref, ti->l_ref + N);
+  TrajResult res;
+  const double cost = run_find_traj(variant, in, p, res);
+  if (cost == FAIL) return FAIL;
+  if (n_points) *n_points = res.np;
+  if (n_segments) *n_segments = res.S;
+  const int n = res.np < cap ? res.np : cap;
+  static const int src_row[6] = {0, 3, 1, 4, 2, 5};   // file columns s l ds dl dds ddl <- rows s ds dds l dl ddl
+  for (int i = 0; i < n; i++) {
+    traj[i] = i * in.delta;
+    for (int c = 0; c < 6; c++) traj[(size_t)(c + 1) * cap + i] = res.out[(size_t)src_row[c] * res.np + i];
+  }
+  if (ctrl) for (size_t i = 0; i < res.ctrl.size(); i++) ctrl[i] = res.ctrl[i];
   return cost;
 }

@@ -50,6 +50,16 @@ class CWarm(C.Structure):
                 ("mu0", C.c_double), ("smin", C.c_double)]
 
 
+class CTrajInput(C.Structure):
+    """btrapz_traj_input: the content of the corridor text file (trp_wrapper.cpp:39-144) as arrays."""
+    _fields_ = [("N", C.c_int), ("num_obs", C.c_int), ("delta", C.c_double),
+                ("init_s", C.c_double * 3), ("init_l", C.c_double * 3),
+                ("ds_ref", C.c_double), ("dl_ref", C.c_double),
+                ("dds", C.c_double * 2), ("ddds", C.c_double * 2), ("ddl", C.c_double * 2), ("dddl", C.c_double * 2),
+                ("s_bounds", C.c_void_p), ("l_bounds", C.c_void_p), ("ds_bounds", C.c_void_p),
+                ("dl_bounds", C.c_void_p), ("s_ref", C.c_void_p), ("l_ref", C.c_void_p)]
+
+
 class CParams(C.Structure):
     """include/btrapz/py_cpp_.h:6-21 == trp_wrapper.py:19-32."""
     _fields_ = [("s_acc_weight", C.c_double), ("s_jerk_weight", C.c_double),
@@ -75,7 +85,7 @@ EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "bt
            "btrapz_device_count", "btrapz_solve_batch_device", "btrapz_argmin_device",
            "btrapz_sample_device", "btrapz_solve_batch_host", "btrapz_solve_ragged_device",
            "btrapz_corridor_batch_device", "btrapz_sample_ragged_device", "btrapz_solve_warm_device",
-           "btrapz_eval_states_device")
+           "btrapz_eval_states_device", "btrapz_find_traj_mem")
 
 
 def build(verbose=False):
@@ -116,6 +126,9 @@ def lib():
         vp, dp, ip, llp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
         l.btrapz_find_traj.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.POINTER(CParams)]
         l.btrapz_find_traj.restype = C.c_double
+        l.btrapz_find_traj_mem.argtypes = [C.c_int, C.POINTER(CTrajInput), C.POINTER(CParams), C.c_int, C.c_void_p,
+                                           C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int)]
+        l.btrapz_find_traj_mem.restype = C.c_double
         l.btrapz_corridor_from_file.argtypes = [C.c_int, C.c_char_p, C.POINTER(CSegment), C.c_int]
         l.btrapz_corridor_from_file.restype = C.c_int
         l.btrapz_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
@@ -221,7 +234,7 @@ class Context:
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self._check(lib().btrapz_eval_states_device(self._h, B, seg_stride, ptr(seg_count), ptr(seg), ptr(ctrl),
                                                     int(n_times), ptr(times), ptr(x), C.c_void_p(stream or 0)),
-                    "btrapz_eval_states_device")
+                    "btrapz_eval_states_device", "btrapz_find_traj_mem")
 
     def corridor_batch_device(self, variant, B, N, num_obs, delta, s_bounds, l_bounds, ds_bounds, dl_bounds_knots,
                               s_ref, l_ref, seg_stride, seg, seg_count, ref_end, dl_bounds, stream=None):
@@ -257,6 +270,27 @@ def find_traj_native(variant, params, input_path=None, output_path=None):
     cp = params if isinstance(params, CParams) else CParams(*params)
     enc = lambda s: os.fsencode(s) if s else None
     return lib().btrapz_find_traj(int(variant), enc(input_path), enc(output_path), C.byref(cp))
+
+
+def find_traj_mem(variant, params, kb, b=0, cap=None):
+    """btrapz_find_traj_mem(): find_traj on candidate b of a spectral_amd.knots.KnotBatch (arrays in, arrays out).
+    Returns (cost, traj [7][n] rows t s l ds dl dds ddl, ctrl [12 S]); cost == 1e11 on failure (traj, ctrl None)."""
+    cp = params if isinstance(params, CParams) else CParams(*params)
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    arrs = [f(kb.s_bounds[b]), f(kb.l_bounds[b]), f(kb.ds_bounds[b]), f(kb.dl_bounds[b]), f(kb.s_ref[b]), f(kb.l_ref[b])]
+    h = kb.header
+    ti = CTrajInput(int(kb.N), int(kb.num_obs), float(kb.delta), (C.c_double * 3)(*kb.init[b, :3]),
+                    (C.c_double * 3)(*kb.init[b, 3:]), float(h["ds_ref"]), float(h["dl_ref"]),
+                    (C.c_double * 2)(*h["dds"]), (C.c_double * 2)(*h["ddds"]), (C.c_double * 2)(*h["ddl"]),
+                    (C.c_double * 2)(*h["dddl"]), *[a.ctypes.data for a in arrs])
+    cap = int(cap if cap is not None else 4 * kb.N + 16)
+    traj = np.zeros((7, cap)); ctrl = np.zeros(12 * 64)
+    n, S = C.c_int(0), C.c_int(0)
+    cost = lib().btrapz_find_traj_mem(int(variant), C.byref(ti), C.byref(cp), cap, traj.ctypes.data, C.byref(n),
+                                      ctrl.ctypes.data, C.byref(S))
+    if cost == 100000000000.0:
+        return cost, None, None
+    return cost, traj[:, :min(n.value, cap)].copy(), ctrl[:12 * S.value].copy()
 
 
 def corridor_from_file(variant, input_path, cap=256):

@@ -56,6 +56,8 @@ def test_params_layout_is_the_reference_abi():
     assert C.sizeof(native.CSegment) == 104
     assert C.sizeof(native.CWarm) == 3 * 8 + 2 * 8      # btrapz_warm: three pointers, two doubles
     assert [f[0] for f in native.CWarm._fields_] == ["x0", "lam0", "lam_out", "mu0", "smin"]
+    assert C.sizeof(native.CTrajInput) == 2 * 4 + 8 + 6 * 8 + 2 * 8 + 8 * 8 + 6 * 8     # btrapz_traj_input
+    assert native.CTrajInput.s_bounds.offset == 144
 
 
 def test_no_gpu_means_loud_failure_not_cpu_fallback(built, tmp_path):
@@ -70,6 +72,10 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback(built, tmp_path):
                                    str(tmp_path / "o.txt"))
     assert cost == 100000000000.0
     assert not os.path.exists(str(tmp_path / "o.txt"))
+    from spectral_amd import knots
+    cost, traj, ctrl = native.find_traj_mem(0, native.CParams(*[float(v) for v in w], 3),
+                                            knots.parse_corridor_file(os.path.join(gold, "c1.txt")))
+    assert cost == 100000000000.0 and traj is None
 
 
 def test_python_mirror_follows_reference_call_shapes(built, tmp_path, monkeypatch):

@@ -97,3 +97,41 @@ def test_find_traj_is_reentrant(tmp_path, monkeypatch):
     th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
     [t.start() for t in th]; [t.join() for t in th]
     assert len(set(res.values())) == 1 and list(res.values())[0] < 1e10
+
+
+@pytest.mark.parametrize("name,variant", FEASIBLE)
+def test_find_traj_mem_equals_file_path_at_full_precision(name, variant, tmp_path):
+    """btrapz_find_traj_mem (arrays in, arrays out: SURVEY 8f rank 2) is the same computation as the file-based
+    find_traj: same cost bit for bit, the text file is its 3-decimal rounding, and the full-precision samples
+    agree with the oracle's x* to solver accuracy instead of print accuracy."""
+    from spectral_amd import knots
+    g = np.load(os.path.join(GOLD, "scenario_xstar.npz"))
+    inp_path = os.path.join(GOLD, "inputs", name + ".txt")
+    out_path = str(tmp_path / "o.txt")
+    params = native.CParams(*[float(v) for v in W], 7)
+    cost_file = native.find_traj_native(variant, params, inp_path, out_path)
+    kb = knots.parse_corridor_file(inp_path)
+    cost, traj, ctrl = native.find_traj_mem(variant, params, kb)
+    assert cost == cost_file
+    got = np.loadtxt(out_path)
+    assert traj.shape == (7, got.shape[0])
+    assert np.abs(np.round(traj.T, 3) - got).max() <= 1.0e-3 + 1e-12      # the file is the rounded array
+    want = g["%s/%d/traj" % (name, variant)]                              # oracle x*, sampled: s ds dds l dl ddl
+    full = np.stack([traj[1], traj[3], traj[5], traj[2], traj[4], traj[6]])
+    scale = np.abs(want).max(axis=1, keepdims=True) + 1.0
+    assert (np.abs(full - want) / scale).max() <= 1e-5
+    xs = g["%s/%d/xstar" % (name, variant)]
+    assert ctrl.shape == xs.shape and np.abs(ctrl - xs).max() <= 1e-5 * np.abs(xs).max()
+    # a short output buffer truncates the copy, not the count
+    c2, t2, _ = native.find_traj_mem(variant, params, kb, cap=5)
+    assert c2 == cost and t2.shape == (7, 5) and np.array_equal(t2, traj[:, :5])
+
+
+def test_find_traj_mem_failures():
+    from spectral_amd import knots
+    params = native.CParams(*[float(v) for v in W], 1)
+    for name, variant in FAILING:
+        kb = knots.parse_corridor_file(os.path.join(GOLD, "inputs", name + ".txt"))
+        cost, traj, ctrl = native.find_traj_mem(variant, params, kb)
+        assert cost == 100000000000.0 and traj is None
+    assert native.lib().btrapz_find_traj_mem(0, None, C.byref(params), 0, None, None, None, None) == 100000000000.0
