@@ -44,17 +44,18 @@ __device__ __forceinline__ double rcp(double x) {
 // seed only: good to 5e-8, enough for step-length ratios (they carry a 0.5 % safety factor).
 __device__ __forceinline__ double rcp_fast(double x) { return __builtin_amdgcn_rcp(x); }
 
-// lane i <- lane i-1 / lane i+1 over the whole wavefront (DPP wave_shr:1 / wave_shl:1).
+// lane i <- lane i-1 / lane i+1 over the whole wavefront (DPP wave_shr:1 / wave_shl:1, bound_ctrl: the lane
+// without a source reads 0, so the destination needs no initialisation).
 __device__ __forceinline__ double from_prev(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double from_next(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 
@@ -205,8 +206,6 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   const int m = S >> 1;                               // root block of the two-sided elimination
   const bool top = k < m, bot = k > m, mid = k == m;
   const int my_step = top ? k : (bot ? S - 1 - k : m);  // the step at which this lane owns a pivot
-  const bool take_p = k <= m && !first;              // my update comes from lane k-1 (upper half) ...
-  const bool take_n = k >= m && !last;               // ... and/or from lane k+1 (lower half)
 
   // ---------------- load the segment record (coalesced: lanes -> consecutive (b,k)) ----------
   const size_t BS = (size_t)a.B * a.seg_stride;
@@ -501,11 +500,16 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 #else
       for (int step = 0; step <= m; ++step) {
 #endif
+        // No selects: a lane's Z is written at its own step and read (here, at the top of a step) only by the
+        // neighbour towards the root one step later; the neighbour on the other side -- and, across a group
+        // boundary, the neighbouring group's end lane, whose step is 0 -- still holds 0 when this lane's step
+        // comes.  Only S <= 2 breaks that (the root is an end lane): a wave-uniform fix-up.
         double pZ[6], nZ[6];
         UNROLL for (int i = 0; i < 6; i++) { pZ[i] = from_prev(Z[i]); nZ[i] = from_next(Z[i]); }
+        if (S <= 2) { UNROLL for (int i = 0; i < 6; i++) { pZ[i] = first ? 0.0 : pZ[i]; nZ[i] = last ? 0.0 : nZ[i]; } }
         if (step == my_step) {
           double Sk[6];
-          UNROLL for (int i = 0; i < 6; i++) Sk[i] = T[i] - (take_p ? pZ[i] : 0.0) - (take_n ? nZ[i] : 0.0);
+          UNROLL for (int i = 0; i < 6; i++) Sk[i] = T[i] - (pZ[i] + nZ[i]);
           ldl3(Sk, F);
           if (!mid) {
             UNROLL for (int j = 0; j < 3; j++) ldl3_solve(F, Mc[j], Mc[3 + j], Mc[6 + j], K[j], K[3 + j], K[6 + j]);
@@ -539,8 +543,9 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 #endif
         double pw[3], nw[3];
         UNROLL for (int i = 0; i < 3; i++) { pw[i] = from_prev(w[i]); nw[i] = from_next(w[i]); }
-        if (step == my_step) {
-          UNROLL for (int i = 0; i < 3; i++) u[i] -= (take_p ? pw[i] : 0.0) + (take_n ? nw[i] : 0.0);
+        if (S <= 2) { UNROLL for (int i = 0; i < 3; i++) { pw[i] = first ? 0.0 : pw[i]; nw[i] = last ? 0.0 : nw[i]; } }
+        if (step == my_step) {   // (same argument as in the factorisation: the unwanted neighbour still holds 0)
+          UNROLL for (int i = 0; i < 3; i++) u[i] -= pw[i] + nw[i];
           if (!mid) {
             w[0] = K[0] * u[0] + K[3] * u[1] + K[6] * u[2];
             w[1] = K[1] * u[0] + K[4] * u[1] + K[7] * u[2];
@@ -548,19 +553,27 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
           }
         }
       }
-      // backward, from the root outwards: dX_k = S_k^{-1} u_k - K_k dX_(neighbour towards the root)
-      double v[3];
-      ldl3_solve(F, u[0], u[1], u[2], v[0], v[1], v[2]);
-      UNROLL for (int i = 0; i < 3; i++) dX[i] = v[i];
+      // backward, from the root outwards: dX_k = S_k^{-1} u_k - K_k dX_(neighbour towards the root).  y carries
+      // the FINAL dX of a lane (0 until then), so the neighbour away from the root contributes 0: an add, no select.
+      ldl3_solve(F, u[0], u[1], u[2], dX[0], dX[1], dX[2]);
+      double y[3];
+      UNROLL for (int i = 0; i < 3; i++) y[i] = mid ? dX[i] : 0.0;
 #if defined(ABL_NOSEQ) || defined(ABL_NOSWEEP)
       for (int step = 0; step >= 0 && m > 0; --step) {
 #else
       for (int step = m - 1; step >= 0; --step) {
 #endif
         double xin[3];
-        UNROLL for (int i = 0; i < 3; i++) { const double px = from_prev(dX[i]), nx = from_next(dX[i]); xin[i] = top ? nx : px; }
+        UNROLL for (int i = 0; i < 3; i++) {
+          double py = from_prev(y[i]), ny = from_next(y[i]);
+          if (S <= 2) { py = first ? 0.0 : py; ny = last ? 0.0 : ny; }
+          xin[i] = py + ny;
+        }
         if (step == my_step) {  // the root (my_step == m) is final already
-          UNROLL for (int i = 0; i < 3; i++) dX[i] = v[i] - (K[3 * i] * xin[0] + K[3 * i + 1] * xin[1] + K[3 * i + 2] * xin[2]);
+          UNROLL for (int i = 0; i < 3; i++) {
+            dX[i] -= K[3 * i] * xin[0] + K[3 * i + 1] * xin[1] + K[3 * i + 2] * xin[2];
+            y[i] = dX[i];
+          }
         }
       }
       double dXp[3];

@@ -234,7 +234,7 @@ class Context:
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self._check(lib().btrapz_eval_states_device(self._h, B, seg_stride, ptr(seg_count), ptr(seg), ptr(ctrl),
                                                     int(n_times), ptr(times), ptr(x), C.c_void_p(stream or 0)),
-                    "btrapz_eval_states_device", "btrapz_find_traj_mem")
+                    "btrapz_eval_states_device")
 
     def corridor_batch_device(self, variant, B, N, num_obs, delta, s_bounds, l_bounds, ds_bounds, dl_bounds_knots,
                               s_ref, l_ref, seg_stride, seg, seg_count, ref_end, dl_bounds, stream=None):
