@@ -92,6 +92,9 @@ template <int R> __device__ __forceinline__ void row_outer(double w, double t2, 
 __device__ __forceinline__ void opaque6(double (&v)[6]) {
   UNROLL for (int i = 0; i < 6; i++) asm volatile("" : "+v"(v[i]));
 }
+// First statement of a block guarded by a wave-uniform condition: keeps the block a real (scalar) branch -- the
+// optimiser would otherwise turn the rare path into selects executed on every pass.
+#define UNIFORM_BLOCK asm volatile("")
 #define PHASE_FENCE(...) do { asm volatile("" ::: "memory"); __VA_ARGS__; } while (0)
 template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
   if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
@@ -506,7 +509,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         // comes.  Only S <= 2 breaks that (the root is an end lane): a wave-uniform fix-up.
         double pZ[6], nZ[6];
         UNROLL for (int i = 0; i < 6; i++) { pZ[i] = from_prev(Z[i]); nZ[i] = from_next(Z[i]); }
-        if (S <= 2) { UNROLL for (int i = 0; i < 6; i++) { pZ[i] = first ? 0.0 : pZ[i]; nZ[i] = last ? 0.0 : nZ[i]; } }
+        if (S <= 2) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 6; i++) { pZ[i] = first ? 0.0 : pZ[i]; nZ[i] = last ? 0.0 : nZ[i]; } }
         if (step == my_step) {
           double Sk[6];
           UNROLL for (int i = 0; i < 6; i++) Sk[i] = T[i] - (pZ[i] + nZ[i]);
@@ -543,7 +546,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 #endif
         double pw[3], nw[3];
         UNROLL for (int i = 0; i < 3; i++) { pw[i] = from_prev(w[i]); nw[i] = from_next(w[i]); }
-        if (S <= 2) { UNROLL for (int i = 0; i < 3; i++) { pw[i] = first ? 0.0 : pw[i]; nw[i] = last ? 0.0 : nw[i]; } }
+        if (S <= 2) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) { pw[i] = first ? 0.0 : pw[i]; nw[i] = last ? 0.0 : nw[i]; } }
         if (step == my_step) {   // (same argument as in the factorisation: the unwanted neighbour still holds 0)
           UNROLL for (int i = 0; i < 3; i++) u[i] -= pw[i] + nw[i];
           if (!mid) {
@@ -564,11 +567,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       for (int step = m - 1; step >= 0; --step) {
 #endif
         double xin[3];
-        UNROLL for (int i = 0; i < 3; i++) {
-          double py = from_prev(y[i]), ny = from_next(y[i]);
-          if (S <= 2) { py = first ? 0.0 : py; ny = last ? 0.0 : ny; }
-          xin[i] = py + ny;
-        }
+        double py[3], ny[3];
+        UNROLL for (int i = 0; i < 3; i++) { py[i] = from_prev(y[i]); ny[i] = from_next(y[i]); }
+        if (S <= 2) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) { py[i] = first ? 0.0 : py[i]; ny[i] = last ? 0.0 : ny[i]; } }
+        UNROLL for (int i = 0; i < 3; i++) xin[i] = py[i] + ny[i];
         if (step == my_step) {  // the root (my_step == m) is final already
           UNROLL for (int i = 0; i < 3; i++) {
             dX[i] -= K[3 * i] * xin[0] + K[3 * i + 1] * xin[1] + K[3 * i + 2] * xin[2];
