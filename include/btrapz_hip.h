@@ -230,7 +230,8 @@ int btrapz_sample_ragged_device(btrapz_ctx *ctx, int B, int seg_stride, const in
  *   lam0    [2][36][B][seg_stride] multipliers (rows 0-17: lower bounds of the 6 position, 5 velocity,
  *           4 acceleration, 3 jerk rows; 18-35: upper bounds), as written to lam_out by an earlier solve;
  *           negative / non-finite entries count as 0.  NULL: none.
- *   lam_out same layout, multipliers at the end of this solve.  NULL: not stored.
+ *   lam_out same layout, multipliers at the end of this solve; may be the same array as lam0 (every entry is
+ *           read before the iterations and written after them by the same lane).  NULL: not stored.
  *   smin, mu0: slacks start at max(gap, smin), multipliers at lam0 + mu0 / slack (0 -> 1e-2 and 1e-4).
  * A warm-started candidate that stalls, or is still far from converged after 12 iterations, is restarted
  * once from the cold start inside the kernel: a bad guess costs iterations, never the result.

@@ -151,12 +151,19 @@ template <int OP> __device__ __forceinline__ double red_op(double acc, double v,
   else if constexpr (OP == 1) return fmax(acc, v);
   else return fmin(acc, v);
 }
+// One wavefront per workgroup and LDS operations of a wavefront complete in issue order, so publishing and
+// reading need no s_barrier and no wait in between: a wavefront-scope fence keeps the compiler from reordering.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <int O0, int O1, int O2, int O3>
 __device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gbase, int S, double v0, double v1,
                                              double v2, double v3) {
-  __syncthreads();
+  wave_lds_sync();
   lds[L_RED + 0][lane] = v0; lds[L_RED + 1][lane] = v1; lds[L_RED + 2][lane] = v2; lds[L_RED + 3][lane] = v3;
-  __syncthreads();
+  wave_lds_sync();
   Red4 r = {red_init<O0>(), red_init<O1>(), red_init<O2>(), red_init<O3>()};
   for (int j0 = 0; j0 < S; j0 += 8) {
     double a[8], b[8], c[8], d[8];
@@ -303,9 +310,9 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   // joint states (warm start; a lane whose values are not finite keeps the cold start) -----
   double X[3], Xcold0;
   {
-    __syncthreads();
+    wave_lds_sync();
     lds[L_RED][lane] = t;
-    __syncthreads();
+    wave_lds_sync();
     double tsum = 0.0;
     for (int j = 0; j < S; j++) tsum += (j <= k) ? lds[L_RED][gbase + j] : 0.0;
     Xcold0 = Xinit[0] + Xinit[1] * tsum;

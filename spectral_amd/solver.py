@@ -60,9 +60,9 @@ class BatchSolver:
             assert lam0.dtype == torch.float64 and lam0.is_contiguous() and tuple(lam0.shape) == (2, 36, dbatch.B, dbatch.S)
         lam_out = None
         if keep_multipliers:
-            lam_out = o.get("lam_buf")
-            if lam_out is None or lam_out is lam0:   # never write the array that is being read
-                lam_out = torch.empty((2, 36, dbatch.B, dbatch.S), dtype=torch.float64, device=self.device)
+            # in place when a previous solve's array is passed in (allowed: include/btrapz_hip.h, btrapz_warm)
+            lam_out = lam0 if lam0 is not None else torch.empty((2, 36, dbatch.B, dbatch.S), dtype=torch.float64,
+                                                                device=self.device)
             o = dict(o); o["lam"] = lam_out
         self.ctx.solve_warm_device(dbatch.B, dbatch.S, shared, dbatch.seg, None, dbatch.init, dbatch.ref_end,
                                    dbatch.dl_bounds, o["ctrl"], o["cost"], o["status"], o["iters"], x0=x0, lam0=lam0,

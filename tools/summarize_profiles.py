@@ -19,7 +19,12 @@ KERNEL = "ipm_solve_kernel"
 def counter_means(root):
     """{counter: (mean over launches of KERNEL, launches, resource columns)} over every pmc_* directory."""
     out = {}
+    newest = {}   # gpurun's merge keeps earlier runs' files: take the newest CSV of every counter group
     for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        group = os.path.relpath(path, root).split(os.sep)[0]
+        if group not in newest or os.path.getmtime(path) > os.path.getmtime(newest[group]):
+            newest[group] = path
+    for path in newest.values():
         acc = {}
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
@@ -43,7 +48,7 @@ def main():
     shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
-        shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+        shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
     wl = bench["config"]
     c = counter_means(src)
