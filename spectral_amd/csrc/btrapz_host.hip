@@ -237,8 +237,8 @@ BTRAPZ_EXPORT int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B
   a.B = B; a.N = N; a.num_obs = num_obs; a.variant = variant; a.seg_stride = seg_stride; a.delta = delta;
   a.s_bounds = s_bounds; a.l_bounds = l_bounds; a.ds_bounds = ds_bounds; a.dl_bounds = dl_bounds_knots;
   a.s_ref = s_ref; a.l_ref = l_ref; a.seg = seg; a.seg_count = seg_count; a.ref_end = ref_end; a.dl10 = dl_bounds;
-  // dynamic LDS: the two reference rows, plus the candidate's bounds when they fit beside the segment lists
-  const size_t ref_bytes = sizeof(double) * 2 * (size_t)N, bound_bytes = sizeof(double) * 4 * (size_t)N * num_obs;
+  // dynamic LDS: the two reference rows, plus the slopes of the s bounds when they fit beside the segment lists
+  const size_t ref_bytes = sizeof(double) * 2 * (size_t)N, bound_bytes = sizeof(double) * 2 * (size_t)N * num_obs;
   const int staged = ref_bytes + bound_bytes <= 36 * 1024 ? 1 : 0;
   hipLaunchKernelGGL(corridor_batch_kernel, dim3(B), dim3(64), ref_bytes + (staged ? bound_bytes : 0),
                      (hipStream_t)stream, a, staged);

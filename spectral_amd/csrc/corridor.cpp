@@ -77,7 +77,7 @@ static_assert(sizeof(std::pair<double, double>) == 2 * sizeof(double), "Bounds m
 std::vector<Segment> extract_segments(int variant, int N, double delta, const Bounds &sb, const Bounds &lb) {
   std::vector<Seg> buf(2 * (size_t)N + 16);
   const BoundsView s{reinterpret_cast<const double *>(sb.data())}, l{reinterpret_cast<const double *>(lb.data())};
-  const int n = extract_segments_core(variant, N, delta, s, l, buf.data(), (int)buf.size());
+  const int n = extract_segments_core(variant, N, delta, s, l, SlopesOnTheFly{s, delta}, buf.data(), (int)buf.size());
   std::vector<Segment> out;
   for (int i = 0; i < n; i++) out.push_back(to_segment(buf[i]));
   return out;

@@ -47,16 +47,32 @@ struct BoundsView {
   BTRAPZ_HD double hi(int i) const { return p[2 * i + 1]; }
 };
 
+// Per-knot slopes of the s bounds, (b(i) - b(i-1)) / delta for i = 1..N-1: computed on the fly on the host, read
+// from a table the lanes filled in parallel on the device (the divisions are the expensive part of the scan; the
+// expression -- hence the rounding -- is the same).
+struct SlopesOnTheFly {
+  BoundsView sb;
+  double delta;
+  BTRAPZ_HD double down(int i) const { return (sb.lo(i) - sb.lo(i - 1)) / delta; }
+  BTRAPZ_HD double up(int i) const { return (sb.hi(i) - sb.hi(i - 1)) / delta; }
+};
+struct SlopeTable {  // interleaved (down, up) pairs, entry i at p[2 i]
+  const double *p;
+  BTRAPZ_HD double down(int i) const { return p[2 * i]; }
+  BTRAPZ_HD double up(int i) const { return p[2 * i + 1]; }
+};
+
 // ---- CorridorGeneration + CorridorSplit for one obstacle.  Returns the number of segments written,
 // or -1 when `cap` is too small.
-BTRAPZ_HD int extract_segments_core(int variant, int N, double delta, BoundsView sb, BoundsView lb, Seg *v, int cap) {
+template <class Slopes>
+BTRAPZ_HD int extract_segments_core(int variant, int N, double delta, BoundsView sb, BoundsView lb, Slopes sk, Seg *v, int cap) {
   if (cap < 1 || N < 3) return -1;
   int n = 0;
   {
     Seg s = seg_default();
     s.beg_t = 0;
-    s.down_skew = (sb.lo(1) - sb.lo(0)) / delta; s.down_bias = sb.lo(0);
-    s.upp_skew = (sb.hi(1) - sb.hi(0)) / delta; s.upp_bias = sb.hi(0);
+    s.down_skew = sk.down(1); s.down_bias = sb.lo(0);
+    s.upp_skew = sk.up(1); s.upp_bias = sb.hi(0);
     if (variant == 0) {  // solve_3d.cc:338-341
       s.l_down_skew = (lb.lo(1) - lb.lo(0)) / delta; s.l_down_bias = lb.lo(0);
       s.l_upp_skew = (lb.hi(1) - lb.hi(0)) / delta; s.l_upp_bias = lb.hi(0);
@@ -65,15 +81,17 @@ BTRAPZ_HD int extract_segments_core(int variant, int N, double delta, BoundsView
     v[n++] = s;
   }
   const double threshold = 0.2;  // solve_3d.cc:372
+  double cur_down = v[0].down_skew, cur_up = v[0].upp_skew;  // slopes of the open segment
   for (int i = 2; i < N - 1; i++) {
-    const double dskew = (sb.lo(i) - sb.lo(i - 1)) / delta, uskew = (sb.hi(i) - sb.hi(i - 1)) / delta;
-    if (fabs(dskew - v[n - 1].down_skew) > threshold || fabs(uskew - v[n - 1].upp_skew) > threshold) {
+    const double dskew = sk.down(i), uskew = sk.up(i);
+    if (fabs(dskew - cur_down) > threshold || fabs(uskew - cur_up) > threshold) {
       if (n + 1 > cap) return -1;
       v[n - 1].end_t = i;
       Seg s = seg_default();
       s.beg_t = i;
-      s.down_skew = (sb.lo(i + 1) - sb.lo(i)) / delta; s.down_bias = sb.lo(i);
-      s.upp_skew = (sb.hi(i + 1) - sb.hi(i)) / delta; s.upp_bias = sb.hi(i);
+      s.down_skew = sk.down(i + 1); s.down_bias = sb.lo(i);
+      s.upp_skew = sk.up(i + 1); s.upp_bias = sb.hi(i);
+      cur_down = s.down_skew; cur_up = s.upp_skew;
       s.beg_l = lb.lo(i); s.end_l = lb.hi(i);
       if (variant == 0) {  // solve_3d.cc:358-367: the l line of a later segment is the backward difference at i
         s.l_down_bias = lb.lo(i); s.l_upp_bias = lb.hi(i);
@@ -84,11 +102,26 @@ BTRAPZ_HD int extract_segments_core(int variant, int N, double delta, BoundsView
   }
   v[n - 1].end_t = N - 1;
   for (int i = 0; i < n; i++) v[i].t = (v[i].end_t - v[i].beg_t) * delta;
-  // CorridorSplit: peel 1.0 s / 10-knot pieces (the reference hard-codes delta = 0.1: solve_3d.cc:735-746)
+  // CorridorSplit: peel 1.0 s / 10-knot pieces off the front of every segment while its t > 1 (the reference
+  // hard-codes delta = 0.1: solve_3d.cc:735-746; it inserts each piece with vector::insert).  Same pieces, same
+  // arithmetic, but written straight to their final slots: count first, then fill from the back (the slots of
+  // segment k start at k + the pieces peeled before it, so unread segments are never overwritten).
+  int total = 0;
   for (int k = 0; k < n; k++) {
-    while (v[k].t > 1) {
-      if (n + 1 > cap) return -1;
-      Seg rest = v[k];
+    double t = v[k].t;
+    int h = 0;
+    while (t > 1) { t = t - 1; if (++h > cap) return -1; }   // bounded: a huge (or infinite) t must not spin
+    total += h + 1;
+  }
+  if (total > cap) return -1;
+  int pos = total;
+  for (int k = n - 1; k >= 0; k--) {
+    Seg rest = v[k];
+    int h = 0;
+    { double t = rest.t; while (t > 1) { t = t - 1; h++; } }
+    pos -= h + 1;
+    int w = pos;
+    while (rest.t > 1) {
       rest.t = rest.t - 1;
       Seg head = seg_default();
       head.beg_t = rest.beg_t;
@@ -104,12 +137,11 @@ BTRAPZ_HD int extract_segments_core(int variant, int N, double delta, BoundsView
       rest.beg_t = rest.beg_t + 10;
       rest.down_bias = head.down_bias + 1.0 * head.down_skew;
       rest.upp_bias = head.upp_bias + 1.0 * head.upp_skew;
-      for (int j = n; j > k + 1; j--) v[j] = v[j - 1];  // insert(head) before position k
-      v[k] = head; v[k + 1] = rest;
-      n++; k++;
+      v[w++] = head;
     }
+    v[w] = rest;
   }
-  return n;
+  return total;
 }
 
 BTRAPZ_HD bool same_segment(const Seg &a, const Seg &b) {  // solve_3d.cc:621
@@ -143,19 +175,25 @@ BTRAPZ_HD int selection_pushes(int hits_inside, int &carry) {
 }
 
 // De-dup (keep first), then ordering and time-overlap resolution: solve_3d.cc:617-703 (trapezoid),
-// cuboid_3d.cc:538-567 (cuboid: no sort, no reorder, every later twin, a third of the span).
-BTRAPZ_HD int order_segments_core(int variant, double delta, Seg *v, int n) {
+// cuboid_3d.cc:538-567 (cuboid: no sort, no reorder, every later twin, a third of the span).  Three steps so that
+// the device can run the first two across the lanes (corridor_kernels.hip) and only the last one serially.
+BTRAPZ_HD int dedup_segments_core(Seg *v, int n) {
   for (int i = 0; i + 1 < n; i++)
     for (int j = i + 1; j < n;) {
       if (same_segment(v[i], v[j])) { for (int m = j; m + 1 < n; m++) v[m] = v[m + 1]; n--; } else j++;
     }
+  return n;
+}
+BTRAPZ_HD void sort_segments_core(Seg *v, int n) {  // stable insertion sort by beg_t (libstdc++'s behaviour for n <= 16)
+  for (int i = 1; i < n; i++) {
+    const Seg x = v[i];
+    int j = i - 1;
+    while (j >= 0 && x.beg_t < v[j].beg_t) { v[j + 1] = v[j]; j--; }
+    v[j + 1] = x;
+  }
+}
+BTRAPZ_HD void resolve_segments_core(int variant, double delta, Seg *v, int n) {
   if (variant == 0) {
-    for (int i = 1; i < n; i++) {  // stable insertion sort by beg_t (libstdc++'s behaviour for n <= 16)
-      const Seg x = v[i];
-      int j = i - 1;
-      while (j >= 0 && x.beg_t < v[j].beg_t) { v[j + 1] = v[j]; j--; }
-      v[j + 1] = x;
-    }
     for (int i = 0; i + 1 < n; i++)  // pull a segment that continues segment i's lane next to it
       for (int j = i + 1; j < n; j++) {
         if (v[i].beg_l == v[j].beg_l && j - i == 1) break;
@@ -183,6 +221,11 @@ BTRAPZ_HD int order_segments_core(int variant, double delta, Seg *v, int n) {
           v[j].beg_t += third; v[j].t = (v[j].end_t - v[j].beg_t) * delta;
         }
   }
+}
+BTRAPZ_HD int order_segments_core(int variant, double delta, Seg *v, int n) {
+  n = dedup_segments_core(v, n);
+  if (variant == 0) sort_segments_core(v, n);
+  resolve_segments_core(variant, delta, v, n);
   return n;
 }
 

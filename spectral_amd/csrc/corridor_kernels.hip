@@ -1,12 +1,12 @@
 // corridor_kernels.hip -- the corridor stage batched on the device and the
 // bucketing that lets the QP kernel take candidates with different segment counts.
 //
-// corridor_batch_kernel: one wavefront per candidate.  Per-knot bounds of every obstacle ->
-// CorridorGeneration + CorridorSplit (one lane per obstacle) -> CollisionCheck: reference knots are
-// tested against every segment with the lanes spread over the knots (ballot + popcount gives the hit
-// count; the reference's running counter becomes a carry, corridor_core.h) -> de-dup / order / overlap
-// resolution (lane 0, the lists live in LDS) -> the batch record of the QP kernel (one lane per
-// selected segment, coalesced field-major stores).  This is the one stage of the path that streams
+// corridor_batch_kernel: one wavefront per candidate.  Per-knot bounds of every obstacle -> slopes (all lanes)
+// -> CorridorGeneration + CorridorSplit (one lane per obstacle) -> CollisionCheck: reference knots are tested
+// against every segment with the lanes spread over (segment, knot) pairs (ballot + popcount gives the hit
+// counts; the reference's running counter becomes a carry, corridor_core.h) -> de-dup and stable sort across
+// the lanes (one selected segment per lane) -> reorder / overlap resolution (lane 0) -> the batch record of the
+// QP kernel (one lane per selected segment, coalesced field-major stores).  This is the one stage of the path that streams
 // HBM: num_obs * N * 4 doubles per candidate (11 KB at N = 71, 5 obstacles).
 // References: src/solve_3d.cc:323-486,488-714,729-772,835-845,1159-1166 ; src/cuboid_3d.cc:301-573.
 #include <hip/hip_runtime.h>
@@ -18,62 +18,136 @@ namespace btrapz {
 
 enum { MAX_ALL = 160, MAX_SEL = 64 };
 
-// Dynamic LDS: [s_ref N][l_ref N][s_bounds O*N*2][l_bounds O*N*2] when `staged` (it fits), else only the refs.
+// Dynamic LDS: [s_ref N][l_ref N], then the per-knot slopes of the s bounds [O][N][2] when `staged` (they fit).
 __global__ __launch_bounds__(64) void corridor_batch_kernel(const CorridorArgs a, int staged) {
-  __shared__ Seg all[MAX_ALL];
-  __shared__ Seg sel[MAX_SEL];
+  __shared__ Seg all[MAX_ALL];       // segments of every obstacle, obstacle o at [o * cap_o, ...)
+  __shared__ Seg sel[MAX_SEL];       // the selected, ordered corridor
   __shared__ int ocount[64];
-  __shared__ int nsel_sh;
+  __shared__ short slot_of[MAX_ALL]; // flattened segment index -> slot in all[]
+  __shared__ int hits[MAX_ALL];      // reference knots inside every segment
+  __shared__ short pick[MAX_SEL];    // slots of the selected segments, in selection order
+  __shared__ int key[MAX_SEL];       // beg_t of the survivors of the de-dup, for the rank sort
   extern __shared__ double dyn[];
 
   const int b = blockIdx.x, lane = threadIdx.x;
   const int N = a.N, O = a.num_obs;
   const int cap_o = MAX_ALL / (O > 0 ? O : 1);
   double *sref = dyn, *lref = dyn + N;
-  for (int i = lane; i < N; i += 64) { sref[i] = a.s_ref[(size_t)b * N + i]; lref[i] = a.l_ref[(size_t)b * N + i]; }
-  // The per-obstacle scan below is a serial walk over the knots: from HBM that is N dependent round trips
-  // per lane.  Stage the candidate's bounds into LDS with coalesced 16-byte loads first.
+  bool refs_finite = true;
+  for (int i = lane; i < N; i += 64) {
+    const double s_ = a.s_ref[(size_t)b * N + i], l_ = a.l_ref[(size_t)b * N + i];
+    sref[i] = s_; lref[i] = l_;
+    refs_finite = refs_finite && fabs(s_) < 1e300 && fabs(l_) < 1e300;
+  }
+  refs_finite = __all(refs_finite);
+  // The per-obstacle scan below is a serial walk over the knots that compares slopes: all lanes compute the
+  // slopes (two divisions per knot) with coalesced 16-byte loads and leave them in LDS; the bounds themselves
+  // are read again only where a segment starts (a handful of knots, L2 hits).
   const double *gs = a.s_bounds + (size_t)b * O * N * 2, *gl = a.l_bounds + (size_t)b * O * N * 2;
-  const double *ss = gs, *sl_ = gl;
+  double *slopes = dyn + 2 * N;
   if (staged) {
-    double *ls = dyn + 2 * N, *ll = ls + (size_t)O * N * 2;
     const int n2 = O * N;  // pairs
-    const double2 *gs2 = reinterpret_cast<const double2 *>(gs), *gl2 = reinterpret_cast<const double2 *>(gl);
-    double2 *ls2 = reinterpret_cast<double2 *>(ls), *ll2 = reinterpret_cast<double2 *>(ll);
-    for (int i = lane; i < n2; i += 64) { ls2[i] = gs2[i]; ll2[i] = gl2[i]; }
-    ss = ls; sl_ = ll;
+    const double2 *gs2 = reinterpret_cast<const double2 *>(gs);
+    double2 *sk2 = reinterpret_cast<double2 *>(slopes);
+    for (int i = lane; i < n2; i += 64) {
+      if (i % N > 0) {  // (b(i) - b(i-1)) / delta: the expression of SlopesOnTheFly
+        const double2 cur = gs2[i], prv = gs2[i - 1];
+        sk2[i] = make_double2((cur.x - prv.x) / a.delta, (cur.y - prv.y) / a.delta);
+      }
+    }
   }
   __syncthreads();
   // ---- per-obstacle extraction: lane o owns obstacle o ----
+#ifdef CABL_NOEXTRACT
+  if (lane < O) { ocount[lane] = 1; all[lane * cap_o] = seg_default(); all[lane * cap_o].end_t = N - 1; all[lane * cap_o].t = 1.0; }
+#else
   if (lane < O) {
-    const BoundsView sb{ss + (size_t)lane * N * 2}, lb{sl_ + (size_t)lane * N * 2};
-    ocount[lane] = extract_segments_core(a.variant, N, a.delta, sb, lb, all + lane * cap_o, cap_o);
+    const BoundsView sb{gs + (size_t)lane * N * 2}, lb{gl + (size_t)lane * N * 2};
+    if (staged)
+      ocount[lane] = extract_segments_core(a.variant, N, a.delta, sb, lb, SlopeTable{slopes + (size_t)lane * N * 2}, all + lane * cap_o, cap_o);
+    else
+      ocount[lane] = extract_segments_core(a.variant, N, a.delta, sb, lb, SlopesOnTheFly{sb, a.delta}, all + lane * cap_o, cap_o);
   }
+#endif
   __syncthreads();
-  // ---- selection along the reference: hits per segment, lanes over knots ----
-  int carry = 0, nsel = 0;
+  // ---- selection along the reference (solve_3d.cc:534-596): knots inside every segment, the lanes spread over
+  // (segment, knot) pairs; the reference's running hit counter then reduces to a carry over the segments in order
+  int total = 0;
   bool overflow = false;
   for (int o = 0; o < O; o++) {
     const int n = ocount[o];
     if (n < 0) { overflow = true; break; }
-    for (int j = 0; j < n; j++) {
-      const Seg c = all[o * cap_o + j];
-      int hits = 0;
-      for (int i0 = 0; i0 < N; i0 += 64) {
-        const int i = i0 + lane;
-        const bool in = i < N && knot_inside(c, sref[i], lref[i], (double)i, a.delta);
-        hits += __popcll(__ballot(in));
+    for (int j = lane; j < n; j += 64) slot_of[total + j] = (short)(o * cap_o + j);
+    total += n;
+  }
+#ifdef CABL_NOSELECT
+  total = 0;
+#endif
+  __syncthreads();
+  int nsel = 0;
+  if (!overflow) {
+    // One lane per segment, its fields in registers.  A knot before beg_t or after end_t cannot be inside: with
+    // upp_bias > down_bias and the upper end above the lower end, the edge functions d0 and d2 of knot_inside
+    // (whose first products are exact zeros for a finite reference) have opposite signs there -- so the lane only
+    // visits its own knots.  A segment that fails those conditions, or a reference that is not finite, takes all.
+    for (int q0 = 0; q0 < total; q0 += 64) {
+      const int q = q0 + lane;
+      if (q < total) {
+        const Seg c = all[slot_of[q]];
+        const bool own_range = refs_finite && (c.upp_bias - c.down_bias) > 0.0 &&
+                               (c.down_skew * a.delta + c.down_bias - c.upp_skew * a.delta - c.upp_bias) < 0.0 &&
+                               c.beg_t <= c.end_t;
+        const int i_lo = own_range ? (c.beg_t > 0 ? c.beg_t : 0) : 0;
+        const int i_hi = own_range ? (c.end_t < N - 1 ? c.end_t : N - 1) : N - 1;
+        int h = 0;
+        for (int i = i_lo; i <= i_hi; i++) h += knot_inside(c, sref[i], lref[i], (double)i, a.delta) ? 1 : 0;
+        hits[q] = h;
       }
-      if (selection_pushes(hits, carry) >= 1) {
-        if (nsel < MAX_SEL) { if (lane == 0) { sel[nsel] = c; sel[nsel].count = 3; } nsel++; }
+    }
+    __syncthreads();
+    int carry = 0;
+    for (int q = 0; q < total; q++) {
+      if (selection_pushes(hits[q], carry) >= 1) {
+        if (nsel < MAX_SEL) { if (lane == 0) pick[nsel] = slot_of[q]; nsel++; }
         else overflow = true;
       }
     }
   }
   __syncthreads();
-  if (lane == 0) nsel_sh = (overflow || nsel == 0) ? (overflow ? -1 : 0) : order_segments_core(a.variant, a.delta, sel, nsel);
+  // ---- de-dup (keep first), stable sort by beg_t: lane j holds selected segment j ----
+  int S = overflow ? -1 : 0;
+  if (!overflow && nsel > 0) {
+#ifdef CABL_NOORDER
+    if (lane < nsel) { sel[lane] = all[pick[lane]]; sel[lane].count = 3; }
+    S = nsel;
+#else
+    Seg mine = seg_default();
+    bool keep = false;
+    if (lane < nsel) {
+      mine = all[pick[lane]];
+      mine.count = 3;                                      // the reference pushes a counted copy (solve_3d.cc:590)
+      keep = true;
+      for (int i = 0; i < lane; i++) if (same_segment(all[pick[i]], mine)) { keep = false; break; }  // equality is transitive
+    }
+    const unsigned long long kept = __ballot(keep);
+    const int pos = __popcll(kept & ((1ull << lane) - 1ull)), n = __popcll(kept);
+    int rank = pos;
+    if (a.variant == 0) {
+      if (keep) key[pos] = mine.beg_t;
+      __syncthreads();
+      if (keep) {
+        rank = 0;
+        for (int i = 0; i < n; i++) rank += (key[i] < mine.beg_t || (key[i] == mine.beg_t && i < pos)) ? 1 : 0;
+      }
+    }
+    if (keep) sel[rank] = mine;
+    __syncthreads();
+    // the data-dependent reordering and the overlap resolution stay serial (a few neighbour comparisons)
+    if (lane == 0) resolve_segments_core(a.variant, a.delta, sel, n);
+    S = n;
+#endif
+  }
   __syncthreads();
-  int S = nsel_sh;
   // ---- batch record: lane k writes segment k ----
   bool bad = S > a.seg_stride;
   if (S > 0 && !bad && lane < S) {

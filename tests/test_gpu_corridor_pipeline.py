@@ -129,3 +129,55 @@ def test_ragged_batch_equals_uniform_batches():
     bi, bc = solver.argmin(out["cost"])
     torch.cuda.synchronize()
     assert int(bi[0]) == int(np.argmin(cost))
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_device_corridors_on_degenerate_and_non_finite_inputs(variant):
+    """The device selection visits only a segment's own knots when that is provably the same count (non-degenerate
+    quad, finite reference) and all knots otherwise: force the 'otherwise' paths and random corridors, and compare
+    with the oracle field by field.  Inputs: collapsed s bounds (upper == lower), inverted s bounds, inf / NaN in the
+    reference, random piecewise-linear obstacles with many slope changes."""
+    import torch
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    base = knots.parse_corridor_file(os.path.join(GOLD, "inputs", "c_road_s1_3.txt"))
+    B = 48
+    kb = knots.jittered(base, B, seed=21)
+    rng = np.random.default_rng(5)
+    N = kb.N
+    for b in range(B):
+        mode = b % 6
+        if mode == 0:      # collapsed: upper == lower on one obstacle over a stretch of knots
+            o = b % kb.num_obs; i0 = int(rng.integers(0, N - 20))
+            kb.s_bounds[b, o, i0:i0 + 15, 1] = kb.s_bounds[b, o, i0:i0 + 15, 0]
+        elif mode == 1:    # inverted bounds
+            o = b % kb.num_obs
+            kb.s_bounds[b, o, :, :] = kb.s_bounds[b, o, :, ::-1].copy()
+        elif mode == 2:    # non-finite reference knots
+            kb.s_ref[b, int(rng.integers(0, N))] = np.inf
+            kb.l_ref[b, int(rng.integers(0, N))] = np.nan
+        elif mode == 3:    # random piecewise-linear obstacle: many slope changes
+            o = b % kb.num_obs
+            steps = rng.choice([0.0, 0.05, 0.3, -0.2, 0.5], size=N)
+            kb.s_bounds[b, o, :, 0] = np.round(5.0 + np.cumsum(steps), 2)
+            kb.s_bounds[b, o, :, 1] = kb.s_bounds[b, o, :, 0] + np.round(rng.uniform(5, 30), 2)
+        elif mode == 4:    # reference far outside every corridor
+            kb.s_ref[b] += 500.0
+        # mode 5: plain jitter
+    rec = solver.corridor_batch(kb, variant, seg_stride=40)
+    torch.cuda.synchronize()
+    seg = rec["seg"].cpu().numpy(); cnt = rec["seg_count"].cpu().numpy()
+    seen = set()
+    for b in range(B):
+        n, cubes = oracle_pipeline(kb, b, variant)
+        want = n if n > 0 else 0
+        if n > 40 or any(not (c.t > 0) for c in cubes):
+            want = -1
+        assert cnt[b] == want, (variant, b, b % 6, cnt[b], n)
+        seen.add((b % 6, want > 0))
+        if want > 0:
+            for k, c in enumerate(cubes):
+                for f, attr in FIELDS:
+                    got, exp = seg[f, b, k], getattr(c, attr)
+                    assert got == exp or (np.isnan(got) and np.isnan(exp)), (variant, b, k, attr, got, exp)
+    assert len({m for m, ok in seen if ok}) >= 3      # several modes produce usable corridors
