@@ -145,8 +145,9 @@ typedef struct btrapz_shared {
 } btrapz_shared;
 
 typedef struct btrapz_options {
-  int max_iter;  /* interior-point iterations; 0 -> default (60) */
-  double eps;    /* KKT score target; 0 -> default (1e-9) */
+  int max_iter;          /* interior-point iterations; 0 -> default (60) */
+  double eps;            /* KKT score target; 0 -> default (1e-9) */
+  double step_fraction;  /* fraction of the step to the boundary taken per iteration, in (0,1); 0 -> default (0.9999) */
 } btrapz_options;
 
 /* A context owns the per-launch workspace of one device: it is NOT thread-safe (one context per calling

@@ -39,6 +39,7 @@ struct KernelArgs {
   int *axis_iters;          // [2B]
   Shared sh;
   double eps;
+  double tau;               // fraction of the step to the boundary
   int max_iter;
   // warm start (btrapz_warm): all optional
   const double *x0;         // [B][2][seg_stride][3] joint states at the end of every segment
