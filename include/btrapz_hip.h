@@ -148,6 +148,9 @@ typedef struct btrapz_options {
   int max_iter;          /* interior-point iterations; 0 -> default (60) */
   double eps;            /* KKT score target; 0 -> default (1e-9) */
   double step_fraction;  /* fraction of the step to the boundary taken per iteration, in (0,1); 0 -> default (0.9999) */
+  double step_threshold; /* the fraction above is used only when the step to the boundary is at least this long
+                            (blocked steps, and every step after the 12th iteration, take 0.995 of it, which
+                            keeps the iterates centred); 0 -> default (0.9) */
 } btrapz_options;
 
 /* A context owns the per-launch workspace of one device: it is NOT thread-safe (one context per calling

@@ -39,8 +39,10 @@ struct KernelArgs {
   int *axis_iters;          // [2B]
   Shared sh;
   double eps;
-  double tau;               // fraction of the step to the boundary
+  double tau;               // fraction of the step to the boundary ...
+  double tau_thr;           // ... when that step is at least this long; 0.995 of it otherwise
   int max_iter;
+  int tau_iters;            // iterations (since the start) during which tau may be used
   // warm start (btrapz_warm): all optional
   const double *x0;         // [B][2][seg_stride][3] joint states at the end of every segment
   const double *lam0;       // [2][36][B][seg_stride] multipliers of an earlier solve

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -12,10 +13,19 @@
 
 using namespace btrapz;
 
-// Fraction of the step to the boundary.  Measured on MI355X (65 536 x 20, mean iterations / kernel ms): 0.995: 9.47 /
-// 8.06, 0.999: 8.62 / 7.26, 0.9999: 7.81 / 6.76, 0.99999: 7.37 / 6.57 (all parity tests pass), 0.999999: 7.24 / 6.53 (one
-// ragged parity case fails).  0.9999 keeps two orders of magnitude to the value that breaks.
+// Step-length rule of the interior-point iterations (btrapz_options).  Measured on MI355X, 65 536 x 20 synthetic
+// candidates (mean iterations / kernel ms) and 65 536 jittered copies of c_road_s1_3.txt, a quarter of them infeasible
+// and many close to it (candidates the 0.995 rule solves and the setting loses):
+//   fraction 0.995 everywhere                     9.47 / 8.06    lost  0   (the classic conservative choice)
+//   fraction 0.9999 everywhere                    7.81 / 6.85    lost 91   (blocked steps end too close to the
+//                                                                           boundary, centrality is lost, mu stalls)
+//   0.9999 when the step to the boundary >= 0.9,
+//   0.995 otherwise and after 12 iterations       8.24 / 7.11    lost  0   <- default
+// and over 262 144 jittered candidates of all bundled scenarios, both variants: lost 0 (1 lost / 17 gained with the
+// jitter raised to 1.5 m).  tests/test_gpu_properties.py keeps that comparison as a regression test.
 #define BTRAPZ_DEFAULT_STEP_FRACTION 0.9999
+#define BTRAPZ_DEFAULT_STEP_THRESHOLD 0.9
+#define BTRAPZ_AGGRESSIVE_ITERATIONS 12
 
 struct btrapz_ctx {
   int device = 0;
@@ -152,6 +162,8 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   a.eps = (opt && opt->eps > 0) ? opt->eps : 1e-9;
   a.max_iter = (opt && opt->max_iter > 0) ? opt->max_iter : 60;
   a.tau = (opt && opt->step_fraction > 0 && opt->step_fraction < 1) ? opt->step_fraction : BTRAPZ_DEFAULT_STEP_FRACTION;
+  a.tau_iters = BTRAPZ_AGGRESSIVE_ITERATIONS;
+  a.tau_thr = (opt && opt->step_threshold > 0) ? opt->step_threshold : BTRAPZ_DEFAULT_STEP_THRESHOLD;
   a.x0 = warm ? warm->x0 : nullptr; a.lam0 = warm ? warm->lam0 : nullptr; a.lam_out = warm ? warm->lam_out : nullptr;
   a.mu0 = (warm && warm->mu0 > 0) ? warm->mu0 : 1e-4;
   a.smin = (warm && warm->smin > 0) ? warm->smin : 1e-2;

@@ -661,7 +661,11 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         dr = fmax(dr, fmax(-dll * rcp_fast(ll), -dlu * rcp_fast(lu)));
       END_ROWS
       const Red4 ra = group_reduce<0, 1, 1, 1>(lds, lane, gbase, S, 0.0, pr, dr, 0.0);
-      const double alpha = fmin(1.0, a.tau / fmax(fmax(ra.b, ra.c), a.tau));
+      // m = largest ratio -ds/s, -dlambda/lambda: the boundary is 1/m away.  A long step may go almost all the way
+      // (fewer iterations); a blocked one keeps 0.5 % distance, or the iterates lose centrality and crawl.
+      const double m_ = fmax(ra.b, ra.c);
+      const double tau = (m_ * a.tau_thr <= 1.0 && iter - it0 < a.tau_iters) ? a.tau : fmin(a.tau, 0.995);
+      const double alpha = fmin(1.0, tau / fmax(m_, tau));
       // a finished group keeps its state (a branch, not alpha = 0: 0 * inf would poison it); a step that is
       // not finite is not taken either -- the score of the unchanged iterate then stalls and the group stops
       if (!done && alpha == alpha) {

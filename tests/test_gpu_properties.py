@@ -79,3 +79,40 @@ def test_full_size_batches(cfg, B, S, variant):
     bi, bc = solver.argmin(o["cost"])
     torch.cuda.synchronize()
     assert int(bi[0]) == int(np.argmin(cost)) and float(bc[0]) == cost.min()
+
+
+def test_default_step_rule_loses_no_candidate_the_conservative_rule_solves(monkeypatch):
+    """The default step-length rule (0.9999 of a long step, 0.995 of a blocked one) against the classic 0.995
+    everywhere, on a hard set: jittered copies of the bundled scenarios, a quarter infeasible and many close to
+    it.  Always-aggressive stepping loses ~0.14 % of these (csrc/btrapz_host.hip); the default must lose none, and
+    both must agree on the optimum where both solve."""
+    import os
+    import torch
+    from spectral_amd import knots
+    from spectral_amd.solver import BatchSolver
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    W = np.loadtxt(os.path.join(gold, "inputs", "weights.txt"))
+    solver = BatchSolver(0)
+    B = 16384
+    for name, variant in (("c_road_s1_3", 0), ("c1", 1), ("c3", 0)):
+        kb = knots.jittered(knots.parse_corridor_file(os.path.join(gold, "inputs", name + ".txt")), B, seed=3)
+        sh = synth.shared_params(variant, weights=W)
+        sh.ds_ref, sh.dl_ref = kb.header["ds_ref"], kb.header["dl_ref"]
+        sh.dds, sh.ddds, sh.ddl, sh.dddl = kb.header["dds"], kb.header["ddds"], kb.header["ddl"], kb.header["dddl"]
+        rec = solver.corridor_batch(kb, variant, seg_stride=24)
+        res = {}
+        for label, frac, thr in (("conservative", "0.995", "1.0"), ("default", "0", "0")):
+            monkeypatch.setenv("BTRAPZ_STEP_FRACTION", frac)
+            monkeypatch.setenv("BTRAPZ_STEP_THRESHOLD", thr)
+            o = solver.solve_ragged(rec, sh)
+            torch.cuda.synchronize()
+            res[label] = (o["status"].cpu().numpy().copy(), o["ctrl"].cpu().numpy().copy(), o["iters"].cpu().numpy().copy())
+        sc, cc, ic = res["conservative"]
+        sd, cd, idf = res["default"]
+        assert (sc > 0).sum() > 0.3 * B
+        lost = (sc > 0) & ~(sd > 0)
+        assert lost.sum() == 0, (name, variant, int(lost.sum()))
+        both = (sc > 0) & (sd > 0)
+        scale = np.abs(cc[both]).max(axis=1)
+        assert (np.abs(cc[both] - cd[both]).max(axis=1) <= 1e-5 * scale).all()
+        assert idf[both].mean() < ic[both].mean()
