@@ -43,6 +43,7 @@ struct KernelArgs {
   double tau_thr;           // ... when that step is at least this long; 0.995 of it otherwise
   int max_iter;
   int tau_iters;            // iterations (since the start) during which tau may be used
+  int stall_start, stall_len; // divergence test: after stall_start iterations, stall_len without a better score
   // warm start (btrapz_warm): all optional
   const double *x0;         // [B][2][seg_stride][3] joint states at the end of every segment
   const double *lam0;       // [2][36][B][seg_stride] multipliers of an earlier solve

@@ -26,6 +26,11 @@ using namespace btrapz;
 #define BTRAPZ_DEFAULT_STEP_FRACTION 0.9999
 #define BTRAPZ_DEFAULT_STEP_THRESHOLD 0.9
 #define BTRAPZ_AGGRESSIVE_ITERATIONS 12
+// Divergence / infeasibility test: after BTRAPZ_STALL_START iterations, BTRAPZ_STALL_LENGTH iterations without a better
+// score end the solve.  On the same 2 x 262 144 jittered candidates: (12, 8) 0 lost, infeasible candidates end after
+// 21.5 iterations on average; (10, 6) 0 lost, 19.5; (8, 5) 3 lost; (8, 4) 18 lost; (6, 3) 87 lost.
+#define BTRAPZ_STALL_START 10
+#define BTRAPZ_STALL_LENGTH 6
 
 struct btrapz_ctx {
   int device = 0;
@@ -163,6 +168,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   a.max_iter = (opt && opt->max_iter > 0) ? opt->max_iter : 60;
   a.tau = (opt && opt->step_fraction > 0 && opt->step_fraction < 1) ? opt->step_fraction : BTRAPZ_DEFAULT_STEP_FRACTION;
   a.tau_iters = BTRAPZ_AGGRESSIVE_ITERATIONS;
+  a.stall_start = BTRAPZ_STALL_START; a.stall_len = BTRAPZ_STALL_LENGTH;
   a.tau_thr = (opt && opt->step_threshold > 0) ? opt->step_threshold : BTRAPZ_DEFAULT_STEP_THRESHOLD;
   a.x0 = warm ? warm->x0 : nullptr; a.lam0 = warm ? warm->lam0 : nullptr; a.lam_out = warm ? warm->lam_out : nullptr;
   a.mu0 = (warm && warm->mu0 > 0) ? warm->mu0 : 1e-4;

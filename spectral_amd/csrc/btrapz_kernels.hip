@@ -432,12 +432,12 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       if (score < best_score) { best_score = score; best_it = iter; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
 #ifndef ABL_FIXED
       // stop: converged; at the round-off floor (best < 1e-5, 3 iterations without progress); diverging or
-      // infeasible (8 iterations without progress after the start-up phase); not finite.  A warm-started group
+      // infeasible (stall_len iterations without progress after the first stall_start); not finite.  A warm-started group
       // that ends in the last two ways, or is still far from converged after 12 iterations (a useful guess
       // needs about 5, a cold start 8-14; below 1e-4 the method is in its fast final phase), or is still running
       // after 24, is restarted once from the cold start: a bad guess must neither turn a solvable candidate
       // into a failure nor cost more than a bounded number of iterations.
-      const bool stalled = (iter - it0 >= 12 && iter - best_it >= 8) || !(score < 1e299);
+      const bool stalled = (iter - it0 >= a.stall_start && iter - best_it >= a.stall_len) || !(score < 1e299);
       if (score < eps || (best_score < 1e-5 && iter - best_it >= 3)) done = true;
       else if (WARM && !restarted && (stalled || (iter - it0 >= 12 && best_score > 1e-4) || iter - it0 >= 24)) restart_now = true;
       else if (stalled) done = true;
