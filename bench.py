@@ -60,7 +60,7 @@ def measured_traffic(B, S, variant):
         except Exception:
             continue
         w = d.get("workload", {})
-        if (w.get("batch"), w.get("segments"), w.get("variant")) == (B, S, variant):
+        if (w.get("batch_per_gpu", w.get("batch")), w.get("segments"), w.get("variant")) == (B, S, variant):
             return float(d["bytes_per_launch_raw"]), os.path.basename(f)
     return None, None
 
