@@ -13,7 +13,8 @@ trajectory at the new joint times plus its previous multipliers (rolled by one s
 
 What is timed per step (HIP events around the whole step, inputs resident): window assembly (torch slicing --
 workload generation, not part of the library), btrapz_eval_states_device x2, btrapz_solve_warm_device,
-btrapz_argmin_device(group = candidates per agent).  One JSON line on stdout."""
+btrapz_argmin_device(group = candidates per agent).  One JSON line on stdout.  --dump writes the winners of a few
+agents at --check steps (problem + control points) so that a test can hold them against the oracle."""
 import argparse
 import json
 import os
@@ -35,7 +36,8 @@ def main():
     ap.add_argument("--segments", type=int, default=20)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--cold", action="store_true", help="cold start at every step (the reference's behaviour)")
-    ap.add_argument("--check", type=int, default=3, help="steps whose winners are checked against the oracle's x*")
+    ap.add_argument("--check", type=int, default=3, help="steps whose winners are written to --dump")
+    ap.add_argument("--dump", default="", help=".npz path: winners' problems and control points at the checked steps")
     ap.add_argument("--min-first", type=float, default=0.1,
                     help="shortest first segment in seconds before the window rolls (0.1 = one knot)")
     ap.add_argument("--mu0", type=float, default=0.0, help="btrapz_warm.mu0 (0 = library default)")
@@ -78,7 +80,7 @@ def main():
 
     prev = None
     lat, iters_mean, solved = [], [], []
-    checks = []
+    dumped = []
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     check_steps = set(np.linspace(0, a.steps - 1, a.check).astype(int).tolist()) if a.check > 0 else set()
     torch.cuda.synchronize()
@@ -120,21 +122,15 @@ def main():
             print("step %3d j0 %2d t0 %.2f ms %.2f iters mean %.2f p50 %d p99 %d max %d" %
                   (n, j0, float(seg[L.F_T, 0, 0].item()), lat[-1], it.mean(), np.percentile(it, 50), np.percentile(it, 99), it.max()),
                   file=sys.stderr)
-        if n in check_steps:
-            from oracle import oracle as O
-            from spectral_amd.layout import Batch
-            hb = Batch(B=B, S=S, seg=seg.cpu().numpy(), init=db.init.cpu().numpy(), ref_end=ref_end.cpu().numpy(),
-                       dl_bounds=world.dl_bounds)
-            ctrl = out["ctrl"].cpu().numpy()
-            worst = 0.0
+        if n in check_steps and a.dump:
+            # winners of three agents with their problems, for tests/test_gpu_mpc_shape.py to hold against the oracle
+            # (this tool never touches oracle/)
             for g in (0, G // 2, G - 1):
                 wi = int(bi[g].item())
-                if wi < 0:
-                    continue
-                xs, obj, st, _ = O.batch_solve(hb, sh, wi, wi + 1, exact=True)
-                if st[0] == 1:
-                    worst = max(worst, float(np.abs(ctrl[wi] - xs[0]).max() / np.abs(xs[0]).max()))
-            checks.append(dict(step=n, worst_rel_err_vs_oracle=worst))
+                if wi >= 0:
+                    dumped.append(dict(step=n, agent=g, seg=seg[:, wi].cpu().numpy(), init=db.init[wi].cpu().numpy(),
+                                       ref_end=ref_end[wi].cpu().numpy(), dl_bounds=world.dl_bounds[wi],
+                                       ctrl=out["ctrl"][wi].cpu().numpy()))
         prev = dict(db=db, ctrl=out["ctrl"], lam=out.get("lam"), j0=j0)
     wall = time.perf_counter() - wall0
     lat = np.array(lat)
@@ -150,8 +146,10 @@ def main():
         "mean_ipm_iterations_first_step": iters_mean[0],
         "solved_fraction_mean": float(np.mean(solved)), "solved_fraction_min": float(np.min(solved)),
         "candidates_per_s": B * 1e3 / float(steady.mean()),
-        "oracle_checks": checks,
+        "dumped_winners": len(dumped),
     }))
+    if a.dump:
+        np.savez(a.dump, **{"%s_%d" % (k, i): v for i, d_ in enumerate(dumped) for k, v in d_.items()}, n=len(dumped))
 
 
 if __name__ == "__main__":
