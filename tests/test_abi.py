@@ -108,3 +108,17 @@ def test_bad_arguments_are_rejected_without_a_device(built):
                                            None) == -1
     h = C.c_void_p()
     assert built.btrapz_create(C.byref(h), -1) in (-2,)
+
+
+def test_public_header_is_plain_c99(tmp_path):
+    """include/btrapz_hip.h is the drop-in boundary: it must compile as strict C and agree with the ctypes mirrors."""
+    src = tmp_path / "hdr.c"
+    src.write_text('#include <stdio.h>\n#include "btrapz_hip.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(Params), sizeof(btrapz_shared), '
+                   'sizeof(btrapz_options), sizeof(btrapz_warm), sizeof(btrapz_traj_input), sizeof(btrapz_segment)); return 0; }\n')
+    exe = tmp_path / "hdr"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)], text=True).split()]
+    assert sizes == [C.sizeof(native.CParams), C.sizeof(native.CShared), C.sizeof(native.COptions), C.sizeof(native.CWarm),
+                     C.sizeof(native.CTrajInput), C.sizeof(native.CSegment)]
