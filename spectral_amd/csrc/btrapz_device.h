@@ -61,6 +61,10 @@ struct CorridorArgs {
   int *seg_count;                      // [B]
   double *ref_end;                     // [B][2]
   double *dl10;                        // [B][10]
+  // segment-list capacities of this launch and the retry list (see corridor_kernels.hip)
+  int cap_o, cap_sel;                  // segments per obstacle, selected segments
+  int pass;                            // 0: one workgroup per candidate; 1: workgroups loop over retry_list
+  int *retry_list, *retry_count;       // candidates whose lists overflowed in pass 0
 };
 
 __global__ void corridor_batch_kernel(const CorridorArgs a, int staged);

@@ -44,6 +44,7 @@ struct btrapz_ctx {
   // ragged batches: candidate order by segment count + bucket tables
   int *d_order = nullptr; size_t order_cap = 0;
   int *d_meta = nullptr;            // [198] histogram/cand_prefix, wave_prefix, cursors
+  int *d_retry = nullptr; size_t retry_cap = 0;   // corridor stage: [0] count, [1..] candidates of the retry pass
   // staging for the host-pointer wrapper
   double *d_stage = nullptr; size_t stage_cap = 0;
   int *d_istage = nullptr; size_t istage_cap = 0;
@@ -110,7 +111,7 @@ BTRAPZ_EXPORT int btrapz_destroy(btrapz_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters);
   (void)hipFree(c->d_mqm); (void)hipFree(c->d_stage); (void)hipFree(c->d_istage);
-  (void)hipFree(c->d_order); (void)hipFree(c->d_meta);
+  (void)hipFree(c->d_order); (void)hipFree(c->d_meta); (void)hipFree(c->d_retry);
   delete c;
   return BTRAPZ_OK;
 }
@@ -248,7 +249,7 @@ BTRAPZ_EXPORT int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B
                                             const double *s_bounds, const double *l_bounds, const double *ds_bounds,
                                             const double *dl_bounds_knots, const double *s_ref, const double *l_ref,
                                             int seg_stride, double *seg, int *seg_count, double *ref_end,
-                                            double *dl_bounds, void *stream) {
+                                            double *dl_bounds, void *stream_) {
   if (!c) return BTRAPZ_EINVAL;
   if (variant < 0 || variant > 1 || B < 1 || N < 3 || N > 512 || num_obs < 1 || num_obs > 64 || !(delta > 0) ||
       seg_stride < 1 || !s_bounds || !l_bounds || !ds_bounds || !dl_bounds_knots || !s_ref || !l_ref || !seg ||
@@ -261,11 +262,37 @@ BTRAPZ_EXPORT int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B
   a.B = B; a.N = N; a.num_obs = num_obs; a.variant = variant; a.seg_stride = seg_stride; a.delta = delta;
   a.s_bounds = s_bounds; a.l_bounds = l_bounds; a.ds_bounds = ds_bounds; a.dl_bounds = dl_bounds_knots;
   a.s_ref = s_ref; a.l_ref = l_ref; a.seg = seg; a.seg_count = seg_count; a.ref_end = ref_end; a.dl10 = dl_bounds;
-  // dynamic LDS: the two reference rows, plus the slopes of the s bounds when they fit beside the segment lists
-  const size_t ref_bytes = sizeof(double) * 2 * (size_t)N, bound_bytes = sizeof(double) * 2 * (size_t)N * num_obs;
-  const int staged = ref_bytes + bound_bytes <= 36 * 1024 ? 1 : 0;
-  hipLaunchKernelGGL(corridor_batch_kernel, dim3(B), dim3(64), ref_bytes + (staged ? bound_bytes : 0),
-                     (hipStream_t)stream, a, staged);
+  // Two passes (corridor_kernels.hip): lists sized for the usual case first -- LDS per workgroup is what limits the
+  // wavefronts per CU -- then the candidates that overflowed them, with the full capacities.
+  if ((size_t)B + 1 > c->retry_cap) {
+    (void)hipFree(c->d_retry); c->d_retry = nullptr; c->retry_cap = 0;
+    HIPCHK(c, hipMalloc(&c->d_retry, sizeof(int) * ((size_t)B + 1)));
+    c->retry_cap = (size_t)B + 1;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  HIPCHK(c, hipMemsetAsync(c->d_retry, 0, sizeof(int), stream));
+  a.retry_count = c->d_retry; a.retry_list = c->d_retry + 1;
+  const int cap_o_big = 160 / num_obs, cap_sel_big = 64;        // MAX_ALL / O, MAX_SEL of corridor_kernels.hip
+  int cap_o_small = (N - 1) / 10 + 9, cap_sel_small = 2 * seg_stride < 16 ? 16 : 2 * seg_stride;
+  if (cap_o_small > cap_o_big) cap_o_small = cap_o_big;
+  if (cap_sel_small > cap_sel_big) cap_sel_small = cap_sel_big;
+  const size_t slope_bytes = sizeof(double) * 2 * (size_t)N * num_obs;
+  const int staged = slope_bytes <= 24 * 1024 ? 1 : 0;
+  auto lds_bytes = [&](int cap_o, int cap_sel) {
+    const size_t cap_all = (size_t)cap_o * num_obs;
+    return 104 * (cap_all + cap_sel) + sizeof(double) * 2 * (size_t)N + (staged ? slope_bytes : 0) +
+           sizeof(int) * (cap_all + 64 + cap_sel) + sizeof(short) * (cap_all + cap_sel) + 16;
+  };
+  const bool two_pass = cap_o_small < cap_o_big || cap_sel_small < cap_sel_big;
+  a.pass = 0; a.cap_o = cap_o_small; a.cap_sel = cap_sel_small;
+  if (!two_pass) { a.retry_list = nullptr; a.retry_count = nullptr; }
+  hipLaunchKernelGGL(corridor_batch_kernel, dim3(B), dim3(64), lds_bytes(a.cap_o, a.cap_sel), stream, a, staged);
+  HIPCHK(c, hipGetLastError());
+  if (two_pass) {
+    a.pass = 1; a.cap_o = cap_o_big; a.cap_sel = cap_sel_big;
+    const unsigned blocks = B < 1024 ? (unsigned)B : 1024u;
+    hipLaunchKernelGGL(corridor_batch_kernel, dim3(blocks), dim3(64), lds_bytes(a.cap_o, a.cap_sel), stream, a, staged);
+  }
   HIPCHK(c, hipGetLastError());
   return BTRAPZ_OK;
 }

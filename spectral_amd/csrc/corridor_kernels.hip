@@ -16,23 +16,45 @@
 
 namespace btrapz {
 
-enum { MAX_ALL = 160, MAX_SEL = 64 };
+enum { MAX_ALL = 160, MAX_SEL = 64 };   // capacities of the retry pass (see btrapz_corridor_batch_device)
 
-// Dynamic LDS: [s_ref N][l_ref N], then the per-knot slopes of the s bounds [O][N][2] when `staged` (they fit).
+// LDS is what limits the wavefronts per CU here, and the serial phases of this kernel live on latency, so the
+// segment lists are sized per launch: a first pass with room for the usual case (cap_o segments per obstacle,
+// cap_sel selected ones: 14 KB, 11 wavefronts per CU at N = 71 with 3 obstacles) and, for the candidates that
+// overflow it, a retry pass with the full MAX_ALL / MAX_SEL (29 KB, 5 per CU).  Same code, same results.
+// Dynamic LDS: Seg all[O * cap_o] | Seg sel[cap_sel] | s_ref[N] | l_ref[N] | slopes[O][N][2] (when `staged`) |
+//              int hits[O * cap_o] | int ocount[64] | int key[cap_sel] | short slot_of[O * cap_o] | short pick[cap_sel]
+__device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw);
+
 __global__ __launch_bounds__(64) void corridor_batch_kernel(const CorridorArgs a, int staged) {
-  __shared__ Seg all[MAX_ALL];       // segments of every obstacle, obstacle o at [o * cap_o, ...)
-  __shared__ Seg sel[MAX_SEL];       // the selected, ordered corridor
-  __shared__ int ocount[64];
-  __shared__ short slot_of[MAX_ALL]; // flattened segment index -> slot in all[]
-  __shared__ int hits[MAX_ALL];      // reference knots inside every segment
-  __shared__ short pick[MAX_SEL];    // slots of the selected segments, in selection order
-  __shared__ int key[MAX_SEL];       // beg_t of the survivors of the de-dup, for the rank sort
-  extern __shared__ double dyn[];
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  if (a.pass == 0) {
+    corridor_candidate(a, staged, (int)blockIdx.x, lds_raw);
+  } else {  // retry pass: the candidates the first pass could not hold
+    const int n = *a.retry_count;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+      corridor_candidate(a, staged, a.retry_list[i], lds_raw);
+      __syncthreads();
+    }
+  }
+}
 
-  const int b = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw) {
+  const int lane = threadIdx.x;
   const int N = a.N, O = a.num_obs;
-  const int cap_o = MAX_ALL / (O > 0 ? O : 1);
+  const int cap_o = a.cap_o, cap_all = cap_o * O, cap_sel = a.cap_sel;
+  Seg *all = reinterpret_cast<Seg *>(lds_raw);           // segments of every obstacle, obstacle o at [o * cap_o, ...)
+  Seg *sel = all + cap_all;                              // the selected, ordered corridor
+  // (16-byte aligned: the slopes are written as double2)
+  double *dyn = reinterpret_cast<double *>((reinterpret_cast<size_t>(sel + cap_sel) + 15) & ~(size_t)15);
   double *sref = dyn, *lref = dyn + N;
+  double *slopes = dyn + 2 * N;
+  int *hits = reinterpret_cast<int *>(slopes + (staged ? (size_t)O * N * 2 : 0));   // reference knots inside every segment
+  int *ocount = hits + cap_all;
+  int *key = ocount + 64;                                // beg_t of the survivors of the de-dup, for the rank sort
+  short *slot_of = reinterpret_cast<short *>(key + cap_sel);  // flattened segment index -> slot in all[]
+  short *pick = slot_of + cap_all;                       // slots of the selected segments, in selection order
+
   bool refs_finite = true;
   for (int i = lane; i < N; i += 64) {
     const double s_ = a.s_ref[(size_t)b * N + i], l_ = a.l_ref[(size_t)b * N + i];
@@ -44,7 +66,6 @@ __global__ __launch_bounds__(64) void corridor_batch_kernel(const CorridorArgs a
   // slopes (two divisions per knot) with coalesced 16-byte loads and leave them in LDS; the bounds themselves
   // are read again only where a segment starts (a handful of knots, L2 hits).
   const double *gs = a.s_bounds + (size_t)b * O * N * 2, *gl = a.l_bounds + (size_t)b * O * N * 2;
-  double *slopes = dyn + 2 * N;
   if (staged) {
     const int n2 = O * N;  // pairs
     const double2 *gs2 = reinterpret_cast<const double2 *>(gs);
@@ -108,12 +129,13 @@ __global__ __launch_bounds__(64) void corridor_batch_kernel(const CorridorArgs a
     int carry = 0;
     for (int q = 0; q < total; q++) {
       if (selection_pushes(hits[q], carry) >= 1) {
-        if (nsel < MAX_SEL) { if (lane == 0) pick[nsel] = slot_of[q]; nsel++; }
+        if (nsel < cap_sel) { if (lane == 0) pick[nsel] = slot_of[q]; nsel++; }
         else overflow = true;
       }
     }
   }
   __syncthreads();
+  if (overflow && a.pass == 0 && a.retry_list && lane == 0) a.retry_list[atomicAdd(a.retry_count, 1)] = b;  // second chance
   // ---- de-dup (keep first), stable sort by beg_t: lane j holds selected segment j ----
   int S = overflow ? -1 : 0;
   if (!overflow && nsel > 0) {

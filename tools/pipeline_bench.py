@@ -1,30 +1,81 @@
-"""Knot-level end-to-end timing: device corridor stage + ragged QP solve on jittered copies of a bundled
-corridor file (CB_IN, default c_road_s1_3) -- the SURVEY 8(f) rank-1 widening.  CB_B candidates."""
-import sys, os, numpy as np, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from spectral_amd import knots, synth, layout as L
-from spectral_amd.solver import BatchSolver
-GOLD=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),'tests','golden')
-W=np.loadtxt(GOLD+'/inputs/weights.txt')
-solver=BatchSolver(0); d=solver.device
-B=int(os.environ.get('CB_B','65536')); name=os.environ.get('CB_IN','c_road_s1_3')
-kb=knots.jittered(knots.parse_corridor_file(GOLD+'/inputs/%s.txt'%name),B,seed=3)
-sh=synth.shared_params(0,weights=W); sh.ds_ref,sh.dl_ref=kb.header['ds_ref'],kb.header['dl_ref']
-sh.dds,sh.ddds,sh.ddl,sh.dddl=kb.header['dds'],kb.header['ddds'],kb.header['ddl'],kb.header['dddl']
-f=lambda a: torch.from_numpy(np.ascontiguousarray(a,dtype=np.float64)).to(d)
-ins=[f(kb.s_bounds),f(kb.l_bounds),f(kb.ds_bounds),f(kb.dl_bounds),f(kb.s_ref),f(kb.l_ref)]
-st=16
-rec=dict(B=B,seg_stride=st,seg=torch.zeros((L.NUM_SEG_FIELDS,B,st),dtype=torch.float64,device=d),seg_count=torch.zeros(B,dtype=torch.int32,device=d),init=f(kb.init),ref_end=torch.zeros((B,2),dtype=torch.float64,device=d),dl_bounds=torch.zeros((B,10),dtype=torch.float64,device=d))
-stream=torch.cuda.current_stream(d).cuda_stream
-def corr(): solver.ctx.corridor_batch_device(0,B,kb.N,kb.num_obs,kb.delta,*ins,st,rec['seg'],rec['seg_count'],rec['ref_end'],rec['dl_bounds'],stream=stream)
-for _ in range(2): corr(); out=solver.solve_ragged(rec,sh)
-torch.cuda.synchronize()
-tc=[];ts=[]
-for _ in range(5):
-    a=torch.cuda.Event(enable_timing=True);b=torch.cuda.Event(enable_timing=True);c=torch.cuda.Event(enable_timing=True)
-    a.record(); corr(); b.record(); out=solver.solve_ragged(rec,sh); c.record(); torch.cuda.synchronize()
-    tc.append(a.elapsed_time(b)); ts.append(b.elapsed_time(c))
-inbytes=sum(t.numel()*8 for t in ins); outbytes=L.NUM_SEG_FIELDS*B*10*8
-cnt=rec['seg_count'].cpu().numpy(); stt=out['status'].cpu().numpy()
-print(name,'B',B,'N',kb.N,'obs',kb.num_obs,'corridor ms min %.3f'%min(tc),'-> %.1f GB/s of %.0f MB input'%(inbytes/min(tc)/1e6,inbytes/1e6),'| ragged solve ms min %.3f'%min(ts),'| end-to-end %.3e cand/s'%(B/(min(tc)+min(ts))*1e3),'cnt',dict(zip(*np.unique(cnt,return_counts=True))),'solved %.3f'%np.mean(stt>0))
+#!/usr/bin/env python3
+"""Knot-level end-to-end timing: device corridor stage (btrapz_corridor_batch_device) + ragged QP
+solve (btrapz_solve_ragged_device) on jittered copies of a bundled corridor file.
+
+    python tools/pipeline_bench.py [--input c_road_s1_3] [--batch 65536] [--variant 0] [--reps 5]
+
+The corridor stage is the one HBM-streaming kernel of the path: its roofline entry divides the input it must read
+(per-knot bounds of every obstacle, reference, ds/dl bounds) plus the batch record it writes by the kernel's
+HIP-event duration.  One JSON line on stdout."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--input", default="c_road_s1_3", help="bundled corridor file (tests/golden/inputs/<name>.txt)")
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--seg-stride", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    import torch
+    from spectral_amd import knots, synth, layout as L
+    from spectral_amd.solver import BatchSolver
+    gold = os.path.join(ROOT, "tests", "golden", "inputs")
+    W = np.loadtxt(os.path.join(gold, "weights.txt"))
+    solver = BatchSolver(0)
+    d = solver.device
+    B, st = a.batch, a.seg_stride
+    kb = knots.jittered(knots.parse_corridor_file(os.path.join(gold, a.input + ".txt")), B, seed=3)
+    sh = synth.shared_params(a.variant, weights=W)
+    sh.ds_ref, sh.dl_ref = kb.header["ds_ref"], kb.header["dl_ref"]
+    sh.dds, sh.ddds, sh.ddl, sh.dddl = kb.header["dds"], kb.header["ddds"], kb.header["ddl"], kb.header["dddl"]
+    f = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(d)
+    ins = [f(kb.s_bounds), f(kb.l_bounds), f(kb.ds_bounds), f(kb.dl_bounds), f(kb.s_ref), f(kb.l_ref)]
+    rec = dict(B=B, seg_stride=st, seg=torch.zeros((L.NUM_SEG_FIELDS, B, st), dtype=torch.float64, device=d),
+               seg_count=torch.zeros(B, dtype=torch.int32, device=d), init=f(kb.init),
+               ref_end=torch.zeros((B, 2), dtype=torch.float64, device=d),
+               dl_bounds=torch.zeros((B, 10), dtype=torch.float64, device=d))
+    stream = torch.cuda.current_stream(d).cuda_stream
+
+    def corridors():
+        solver.ctx.corridor_batch_device(a.variant, B, kb.N, kb.num_obs, kb.delta, *ins, st, rec["seg"], rec["seg_count"],
+                                         rec["ref_end"], rec["dl_bounds"], stream=stream)
+
+    for _ in range(2):
+        corridors(); out = solver.solve_ragged(rec, sh)
+    torch.cuda.synchronize()
+    tc, ts = [], []
+    for _ in range(a.reps):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record(); corridors(); e1.record(); out = solver.solve_ragged(rec, sh); e2.record()
+        torch.cuda.synchronize()
+        tc.append(e0.elapsed_time(e1)); ts.append(e1.elapsed_time(e2))
+    cnt = rec["seg_count"].cpu().numpy(); status = out["status"].cpu().numpy()
+    mean_cnt = float(cnt[cnt > 0].mean()) if (cnt > 0).any() else 0.0
+    in_bytes = sum(t.numel() * 8 for t in ins)
+    out_bytes = int(B * (L.NUM_SEG_FIELDS * mean_cnt * 8 + 4 + 16 + 80))
+    c_ms, s_ms = float(np.median(tc)), float(np.median(ts))
+    print(json.dumps({
+        "workload": "%d jittered copies of %s.txt (N = %d knots, %d obstacles), %s constraints" %
+                    (B, a.input, kb.N, kb.num_obs, "trapezoid" if a.variant == 0 else "cuboid"),
+        "corridor_ms": c_ms, "ragged_solve_ms": s_ms, "end_to_end_candidates_per_s": B / (c_ms + s_ms) * 1e3,
+        "segments_per_candidate": {int(k): int(v) for k, v in zip(*np.unique(cnt, return_counts=True))},
+        "solved_fraction": float(np.mean((status == 1) | (status == 2))),
+        "corridor_roofline": {"bound": "hbm", "kernel": "btrapz::corridor_batch_kernel", "kernel_ms": c_ms,
+                              "algorithmic_bytes_per_candidate": (in_bytes + out_bytes) / B,
+                              "achieved": (in_bytes + out_bytes) / (c_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                              "frac": (in_bytes + out_bytes) / (c_ms * 1e-3) / 1e9 / 8000.0},
+    }))
+
+
+if __name__ == "__main__":
+    main()
