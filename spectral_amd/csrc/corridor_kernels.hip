@@ -207,11 +207,19 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
 
 // ---- bucketing by segment count ------------------------------------------------------------------
 // meta[0..65]: histogram, then cand_prefix ; meta[66..131]: wave_prefix ; meta[132..197]: cursors.
+// Counts are aggregated per workgroup in LDS first: with one global atomic per candidate a batch whose candidates
+// all have the same count (the usual case) serialises on one address -- 0.74 ms per kernel at B = 65 536.
 __global__ void bucket_hist_kernel(int B, int seg_stride, const int *seg_count, int *meta) {
+  __shared__ int h[65];
+  for (int j = threadIdx.x; j < 65; j += blockDim.x) h[j] = 0;
+  __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B) return;
-  const int s = seg_count[i];
-  if (s >= 1 && s <= 64 && s <= seg_stride) atomicAdd(&meta[132 + s], 1);
+  if (i < B) {
+    const int s = seg_count[i];
+    if (s >= 1 && s <= 64 && s <= seg_stride) atomicAdd(&h[s], 1);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 65; j += blockDim.x) if (h[j]) atomicAdd(&meta[132 + j], h[j]);
 }
 __global__ void bucket_prefix_kernel(int *meta) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -229,17 +237,27 @@ __global__ void bucket_prefix_kernel(int *meta) {
 // wavefront, and every group of a wavefront is solved independently, so results do not depend on it.
 __global__ void bucket_scatter_kernel(int B, int seg_stride, const int *seg_count, int *meta, int *order,
                                       double *axis_obj, int *axis_status, int *axis_iters) {
+  __shared__ int h[65], base[65];
+  for (int j = threadIdx.x; j < 65; j += blockDim.x) h[j] = 0;
+  __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B) return;
-  const int s = seg_count[i];
-  if (s >= 1 && s <= 64 && s <= seg_stride) {
-    const int pos = atomicAdd(&meta[132 + s], 1);
-    order[meta[s] + pos] = i;
-  } else {  // no usable corridor: the reference's find_traj fails here (empty selection / CHECK)
-    axis_obj[2 * i] = 0.0; axis_obj[2 * i + 1] = 0.0;
-    axis_status[2 * i] = BTRAPZ_NO_CORRIDOR; axis_status[2 * i + 1] = BTRAPZ_NO_CORRIDOR;
-    axis_iters[2 * i] = 0; axis_iters[2 * i + 1] = 0;
+  int s = 0, local = 0;
+  bool usable = false;
+  if (i < B) {
+    s = seg_count[i];
+    usable = s >= 1 && s <= 64 && s <= seg_stride;
+    if (usable) {
+      local = atomicAdd(&h[s], 1);                       // rank inside the workgroup
+    } else {  // no usable corridor: the reference's find_traj fails here (empty selection / CHECK)
+      axis_obj[2 * i] = 0.0; axis_obj[2 * i + 1] = 0.0;
+      axis_status[2 * i] = BTRAPZ_NO_CORRIDOR; axis_status[2 * i + 1] = BTRAPZ_NO_CORRIDOR;
+      axis_iters[2 * i] = 0; axis_iters[2 * i + 1] = 0;
+    }
   }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 65; j += blockDim.x) if (h[j]) base[j] = atomicAdd(&meta[132 + j], h[j]);  // one range per bucket
+  __syncthreads();
+  if (usable) order[meta[s] + base[s] + local] = i;
 }
 
 }  // namespace btrapz

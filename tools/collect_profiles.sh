@@ -29,6 +29,16 @@ for group in \
   rocprofv3 --pmc $group --output-format csv -d "$OUT/pmc_$name" -- python3 "$BENCH" $PMC_ARGS \
     > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" || echo "pmc group failed: $group" >> "$OUT/failed.txt"
 done
+# the other tools: BASELINE config 5 (receding horizon), knots -> control points, configs 2 and 4 through bench.py
+python3 "$ROOT/tools/mpc_bench.py" > "$OUT/mpc_warm.json" 2> /dev/null
+python3 "$ROOT/tools/mpc_bench.py" --cold > "$OUT/mpc_cold.json" 2> /dev/null
+python3 "$ROOT/tools/mpc_bench.py" --min-first 0.5 > "$OUT/mpc_warm_minfirst05.json" 2> /dev/null
+python3 "$ROOT/tools/mpc_bench.py" --cold --min-first 0.5 > "$OUT/mpc_cold_minfirst05.json" 2> /dev/null
+python3 "$ROOT/tools/pipeline_bench.py" > "$OUT/pipeline.json" 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_pipeline" -- \
+  python3 "$ROOT/tools/pipeline_bench.py" > "$OUT/pipeline_under_rocprof.json" 2> "$OUT/trace_pipeline.err"
+python3 "$BENCH" --segments 10 --batch 4096 --no-cpu-baseline > "$OUT/bench_config2.json" 2> /dev/null
+python3 "$BENCH" --variant 1 --no-cpu-baseline > "$OUT/bench_config4.json" 2> /dev/null
 # keep only the CSVs (the merge-back limit is 64 MiB)
 find "$OUT" -name "*.db" -delete 2>/dev/null
 du -sh "$OUT"

@@ -49,6 +49,13 @@ def main():
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+    pstats = glob.glob(os.path.join(src, "trace_pipeline", "**", "*kernel_stats.csv"), recursive=True)
+    if pstats:
+        shutil.copy(max(pstats, key=os.path.getmtime), os.path.join(dst, f"{tag}_pipeline_kernel_stats.csv"))
+    for name in ("mpc_warm", "mpc_cold", "mpc_warm_minfirst05", "mpc_cold_minfirst05", "pipeline", "bench_config2",
+                 "bench_config4"):
+        if os.path.exists(os.path.join(src, name + ".json")):
+            shutil.copy(os.path.join(src, name + ".json"), os.path.join(dst, f"{tag}_{name}.json"))
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
     wl = bench["config"]
     c = counter_means(src)
