@@ -188,3 +188,39 @@ def test_device_corridors_on_degenerate_and_non_finite_inputs(variant):
                     assert got == exp or (np.isnan(got) and np.isnan(exp)), (variant, b, k, attr, got, exp)
     assert len({m for m, ok in seen if ok}) >= 3      # several modes produce usable corridors
     assert retried_ok >= 1                            # ... and the retry pass produced some of them
+
+
+@pytest.mark.parametrize("name,variant", [("c_road_s1_3", 0), ("c6", 0), ("c1", 1)])
+def test_hard_jittered_candidates_agree_with_oracle_on_solvability_and_optimum(name, variant):
+    """1 024 jittered copies of a bundled scenario, many infeasible or close to it: the device pipeline and the
+    oracle must agree on WHICH candidates are solvable (a couple of borderline ones apart) and on the optimum of
+    every candidate both solve."""
+    import torch
+    from spectral_amd.layout import Batch
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    B = 1024
+    kb = knots.jittered(knots.parse_corridor_file(os.path.join(GOLD, "inputs", name + ".txt")), B, seed=17)
+    sh = synth.shared_params(variant, weights=W)
+    sh.ds_ref, sh.dl_ref = kb.header["ds_ref"], kb.header["dl_ref"]
+    sh.dds, sh.ddds, sh.ddl, sh.dddl = kb.header["dds"], kb.header["ddds"], kb.header["ddl"], kb.header["dddl"]
+    rec = solver.corridor_batch(kb, variant, seg_stride=16)
+    out = solver.solve_ragged(rec, sh)
+    torch.cuda.synchronize()
+    cnt = rec["seg_count"].cpu().numpy(); st = out["status"].cpu().numpy(); ctrl = out["ctrl"].cpu().numpy()
+    seg = rec["seg"].cpu().numpy(); init = rec["init"].cpu().numpy()
+    ref_end = rec["ref_end"].cpu().numpy(); dl = rec["dl_bounds"].cpu().numpy()
+    both = disagree = 0
+    for S in np.unique(cnt[cnt > 0]):
+        idx = np.where(cnt == S)[0]
+        b = Batch(B=len(idx), S=int(S), seg=np.ascontiguousarray(seg[:, idx, :S]), init=init[idx], ref_end=ref_end[idx],
+                  dl_bounds=dl[idx])
+        xs, obj, ost, _ = O.batch_solve(b, sh, 0, len(idx), exact=True, threads=os.cpu_count())
+        g, o = st[idx] > 0, ost == 1
+        disagree += int((g != o).sum())
+        m = g & o
+        both += int(m.sum())
+        if m.any():
+            c = ctrl[idx][:, :12 * S]
+            assert (np.abs(c[m] - xs[m]).max(axis=1) <= 1e-5 * np.abs(xs[m]).max(axis=1)).all(), (name, S)
+    assert both >= 0.5 * B and disagree <= 2, (name, variant, both, disagree)
