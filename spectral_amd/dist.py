@@ -33,12 +33,10 @@ def global_argmin(best_cost, best_idx, group=None):
     allp = torch.stack(gathered).to(dev)             # [world, n, 2]
     cost, idx = allp[..., 0], allp[..., 1]
     idx_key = torch.where(idx < 0, torch.full_like(idx, float("inf")), idx)
-    # lexicographic min over ranks: cost first, then global index
-    best = torch.zeros(cost.shape[1], dtype=torch.int64, device=cost.device)
-    for r in range(1, world):
-        cur_c = cost.gather(0, best[None])[0]; cur_i = idx_key.gather(0, best[None])[0]
-        better = (cost[r] < cur_c) | ((cost[r] == cur_c) & (idx_key[r] < cur_i))
-        best = torch.where(better, torch.full_like(best, r), best)
-    out_c = cost.gather(0, best[None])[0]
-    out_i = idx.gather(0, best[None])[0].to(torch.int64)
+    # lexicographic min over ranks: cost first, then global index (a handful of small launches whatever the
+    # world size: this runs once per step, next to a ~7 ms solve)
+    out_c = cost.min(dim=0).values
+    tied = cost == out_c[None]
+    out_k = torch.where(tied, idx_key, torch.full_like(idx_key, float("inf"))).min(dim=0).values
+    out_i = torch.where(torch.isinf(out_k), torch.full_like(out_k, -1.0), out_k).to(torch.int64)
     return out_c, out_i
