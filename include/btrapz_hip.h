@@ -246,6 +246,10 @@ typedef struct btrapz_warm {
   double *lam_out;
   double mu0;
   double smin;
+  const int *hint;  /* [B] or NULL (uniform batches): expected difficulty of every candidate, e.g. the iters[] of the
+                       previous replanning step.  Candidates of one class (the value clamped to 1..64) share
+                       wavefronts, so a few hard or infeasible candidates no longer hold up the wavefronts of the
+                       easy ones.  Scheduling only: results do not depend on it. */
 } btrapz_warm;
 
 /* btrapz_solve_ragged_device with a warm start (seg_count == NULL: uniform batch of seg_stride segments). */

@@ -175,7 +175,9 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   a.mu0 = (warm && warm->mu0 > 0) ? warm->mu0 : 1e-4;
   a.smin = (warm && warm->smin > 0) ? warm->smin : 1e-2;
   unsigned blocks;
-  if (seg_count) {
+  const int *hint = (warm && !seg_count) ? warm->hint : nullptr;   // uniform batches only
+  a.bucket_S = 0;
+  if (seg_count || hint) {
     if ((size_t)B > c->order_cap) {
       (void)hipFree(c->d_order); c->d_order = nullptr; c->order_cap = 0;
       HIPCHK(c, hipMalloc(&c->d_order, sizeof(int) * (size_t)B));
@@ -184,19 +186,23 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     if (!c->d_meta) HIPCHK(c, hipMalloc(&c->d_meta, sizeof(int) * 198));
     HIPCHK(c, hipMemsetAsync(c->d_meta, 0, sizeof(int) * 198, stream));
     const unsigned nb = (unsigned)((B + 255) / 256);
-    hipLaunchKernelGGL(bucket_hist_kernel, dim3(nb), dim3(256), 0, stream, B, S, seg_count, c->d_meta);
-    hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(64), 0, stream, c->d_meta);
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nb), dim3(256), 0, stream, B, S, seg_count, c->d_meta, c->d_order,
-                       c->d_axis_obj, c->d_axis_status, c->d_axis_iters);
+    const int fixed_S = seg_count ? 0 : S;
+    const int *keys = seg_count ? seg_count : hint;
+    hipLaunchKernelGGL(bucket_hist_kernel, dim3(nb), dim3(256), 0, stream, B, S, keys, c->d_meta, fixed_S);
+    hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(64), 0, stream, c->d_meta, fixed_S);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nb), dim3(256), 0, stream, B, S, keys, c->d_meta, c->d_order,
+                       c->d_axis_obj, c->d_axis_status, c->d_axis_iters, fixed_S);
     HIPCHK(c, hipGetLastError());
     a.order = c->d_order; a.seg_count = seg_count; a.cand_prefix = c->d_meta; a.wave_prefix = c->d_meta + 66;
+    a.bucket_S = fixed_S;
     // upper bound on wavefront pairs without a host round trip: every bucket wastes less than one pair
-    blocks = 2u * (unsigned)(B + 64);
+    const int gpw_min = fixed_S ? 64 / fixed_S : 1;
+    blocks = 2u * (unsigned)(B / gpw_min + 65);
   } else {
     const int gpw = 64 / S;  // axis problems per wavefront; wave w: axis w&1 of candidates (w>>1)*gpw + [0,gpw)
     blocks = 2u * (unsigned)((B + gpw - 1) / gpw);
   }
-  if (a.x0 || a.lam0 || a.lam_out)
+  if (a.x0 || a.lam0 || a.lam_out)   // (a hint alone only reorders the candidates: cold kernel)
     hipLaunchKernelGGL(ipm_solve_warm_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
   else
     hipLaunchKernelGGL(ipm_solve_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);

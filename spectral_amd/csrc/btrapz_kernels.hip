@@ -194,9 +194,15 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   if (a.order) {
     // ragged batch: candidates are bucketed by segment count; find this wave's bucket (wave-uniform)
     if (pair >= a.wave_prefix[65]) return;
-    int s = 1;
-    while (a.wave_prefix[s + 1] <= pair) ++s;
-    S = s; pair -= a.wave_prefix[s]; cand0 = a.cand_prefix[s]; ncand = a.cand_prefix[s + 1] - cand0;
+    // slot s with wave_prefix[s] <= pair < wave_prefix[s + 1] (empty buckets repeat their prefix): binary search,
+    // six dependent scalar loads instead of up to 63
+    int s = 1, hi = 65;
+    while (hi - s > 1) {
+      const int mid = (s + hi) >> 1;
+      if (a.wave_prefix[mid] <= pair) s = mid; else hi = mid;
+    }
+    S = a.bucket_S ? a.bucket_S : 65 - s;   // slot s holds key 65 - s (longest first); hint mode: classes of a uniform batch
+    pair -= a.wave_prefix[s]; cand0 = a.cand_prefix[s]; ncand = a.cand_prefix[s + 1] - cand0;
   } else {
     S = a.S;
   }

@@ -209,55 +209,80 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
 // meta[0..65]: histogram, then cand_prefix ; meta[66..131]: wave_prefix ; meta[132..197]: cursors.
 // Counts are aggregated per workgroup in LDS first: with one global atomic per candidate a batch whose candidates
 // all have the same count (the usual case) serialises on one address -- 0.74 ms per kernel at B = 65 536.
-__global__ void bucket_hist_kernel(int B, int seg_stride, const int *seg_count, int *meta) {
+// fixed_S > 0: the keys are difficulty hints of a uniform batch (any int; clamped to a class 1..64) instead of counts.
+__device__ __forceinline__ int hint_class(int v) { return v < 1 ? 1 : (v > 64 ? 64 : v); }
+__global__ void bucket_hist_kernel(int B, int seg_stride, const int *seg_count, int *meta, int fixed_S) {
   __shared__ int h[65];
   for (int j = threadIdx.x; j < 65; j += blockDim.x) h[j] = 0;
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) {
-    const int s = seg_count[i];
-    if (s >= 1 && s <= 64 && s <= seg_stride) atomicAdd(&h[s], 1);
+    const int s = fixed_S ? hint_class(seg_count[i]) : seg_count[i];
+    if (s >= 1 && s <= 64 && (fixed_S || s <= seg_stride)) atomicAdd(&h[65 - s], 1);   // slot 65 - key: see the prefix kernel
   }
   __syncthreads();
   for (int j = threadIdx.x; j < 65; j += blockDim.x) if (h[j]) atomicAdd(&meta[132 + j], h[j]);
 }
-__global__ void bucket_prefix_kernel(int *meta) {
+// Buckets are laid out by DESCENDING key (slot j holds key 65 - j): wavefronts of long corridors / hard classes are
+// launched first, so the longest-running wavefronts do not start at the tail of the launch.
+__global__ void bucket_prefix_kernel(int *meta, int fixed_S) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int cand = 0, wave = 0;
   meta[0] = 0; meta[66] = 0;
-  for (int s = 1; s <= 64; s++) {
-    const int cnt = meta[132 + s], gpw = 64 / s;
-    meta[s] = cand; meta[66 + s] = wave;
+  for (int j = 1; j <= 64; j++) {
+    const int key = 65 - j;
+    const int cnt = meta[132 + j], gpw = 64 / (fixed_S ? fixed_S : key);
+    meta[j] = cand; meta[66 + j] = wave;
     cand += cnt; wave += (cnt + gpw - 1) / gpw;
-    meta[132 + s] = 0;  // becomes the scatter cursor
+    meta[132 + j] = 0;  // becomes the scatter cursor
   }
   meta[65] = cand; meta[66 + 65] = wave;
 }
-// Candidate order inside a bucket comes from atomics: it only decides which candidates share a
-// wavefront, and every group of a wavefront is solved independently, so results do not depend on it.
-__global__ void bucket_scatter_kernel(int B, int seg_stride, const int *seg_count, int *meta, int *order,
-                                      double *axis_obj, int *axis_status, int *axis_iters) {
-  __shared__ int h[65], base[65];
-  for (int j = threadIdx.x; j < 65; j += blockDim.x) h[j] = 0;
+// Order inside a bucket: index order within a 256-candidate workgroup (stable ranks from ballots), workgroups in
+// the order their atomics land.  It only decides which candidates share a wavefront -- every group of a wavefront
+// is solved independently, so results do not depend on it -- but neighbours in a wavefront stay neighbours in
+// memory, which keeps the loads of the batch record and of the warm-start arrays coalesced.
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(int B, int seg_stride, const int *seg_count, int *meta,
+                                                             int *order, double *axis_obj, int *axis_status,
+                                                             int *axis_iters, int fixed_S) {
+  __shared__ int wcount[4][65], base[65];
+  for (int j = threadIdx.x; j < 4 * 65; j += blockDim.x) (&wcount[0][0])[j] = 0;
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int s = 0, local = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int s = 0, rank = 0;
   bool usable = false;
   if (i < B) {
-    s = seg_count[i];
-    usable = s >= 1 && s <= 64 && s <= seg_stride;
-    if (usable) {
-      local = atomicAdd(&h[s], 1);                       // rank inside the workgroup
-    } else {  // no usable corridor: the reference's find_traj fails here (empty selection / CHECK)
+    s = fixed_S ? hint_class(seg_count[i]) : seg_count[i];
+    usable = s >= 1 && s <= 64 && (fixed_S || s <= seg_stride);
+    if (!usable) {  // no usable corridor: the reference's find_traj fails here (empty selection / CHECK)
       axis_obj[2 * i] = 0.0; axis_obj[2 * i + 1] = 0.0;
       axis_status[2 * i] = BTRAPZ_NO_CORRIDOR; axis_status[2 * i + 1] = BTRAPZ_NO_CORRIDOR;
       axis_iters[2 * i] = 0; axis_iters[2 * i + 1] = 0;
     }
   }
+  // rank among the lanes of this wavefront with the same key, in lane order: one ballot per distinct key
+  unsigned long long remaining = __ballot(usable);
+  while (remaining) {
+    const int leader = __ffsll((long long)remaining) - 1;
+    const int k = __builtin_amdgcn_readlane(s, leader);
+    const unsigned long long m = __ballot(usable && s == k);
+    if (usable && s == k) rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == leader) wcount[wave][65 - k] = __popcll(m);
+    remaining &= ~m;
+  }
   __syncthreads();
-  for (int j = threadIdx.x; j < 65; j += blockDim.x) if (h[j]) base[j] = atomicAdd(&meta[132 + j], h[j]);  // one range per bucket
+  for (int j = threadIdx.x; j < 65; j += blockDim.x) {
+    const int n = wcount[0][j] + wcount[1][j] + wcount[2][j] + wcount[3][j];
+    if (n) base[j] = atomicAdd(&meta[132 + j], n);   // one range per bucket and workgroup
+  }
   __syncthreads();
-  if (usable) order[meta[s] + base[s] + local] = i;
+  if (usable) {
+    int before = 0;
+    const int j = 65 - s;   // slot
+    for (int w = 0; w < wave; w++) before += wcount[w][j];
+    order[meta[j] + base[j] + before + rank] = i;
+  }
 }
 
 }  // namespace btrapz

@@ -47,7 +47,7 @@ class COptions(C.Structure):
 class CWarm(C.Structure):
     """btrapz_warm (include/btrapz_hip.h): optional warm start of a solve."""
     _fields_ = [("x0", C.c_void_p), ("lam0", C.c_void_p), ("lam_out", C.c_void_p),
-                ("mu0", C.c_double), ("smin", C.c_double)]
+                ("mu0", C.c_double), ("smin", C.c_double), ("hint", C.c_void_p)]
 
 
 class CTrajInput(C.Structure):
@@ -219,11 +219,11 @@ class Context:
 
     def solve_warm_device(self, B, seg_stride, shared, seg, seg_count, init, ref_end, dl_bounds, ctrl, cost, status,
                           iters=None, x0=None, lam0=None, lam_out=None, mu0=0.0, smin=0.0, stream=None, max_iter=0,
-                          eps=0.0):
+                          eps=0.0, hint=None):
         """btrapz_solve_warm_device: seg_count None = uniform batch; x0 / lam0 / lam_out optional."""
         sh = CShared.from_shared(shared); opt = COptions(int(max_iter), float(eps), float(os.environ.get("BTRAPZ_STEP_FRACTION", "0")), float(os.environ.get("BTRAPZ_STEP_THRESHOLD", "0")))
         raw = lambda t: t.data_ptr() if t is not None else None
-        warm = CWarm(raw(x0), raw(lam0), raw(lam_out), float(mu0), float(smin))
+        warm = CWarm(raw(x0), raw(lam0), raw(lam_out), float(mu0), float(smin), raw(hint))
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self._check(lib().btrapz_solve_warm_device(self._h, C.byref(sh), C.byref(opt), C.byref(warm), B, seg_stride,
                                                    ptr(seg), ptr(seg_count), ptr(init), ptr(ref_end), ptr(dl_bounds),

@@ -43,7 +43,8 @@ class BatchSolver:
         """Launches the solve on torch's current stream; returns dict of device tensors.
 
         warm: dict with optional "x0" ([B,2,S,3] joint states, e.g. from eval_states) and "lam" ([2,36,B,S]
-        multipliers kept by an earlier solve) plus optional "mu0", "smin" -- btrapz_warm.  keep_multipliers
+        multipliers kept by an earlier solve) plus optional "mu0", "smin" and "hint" ([B] int32 expected difficulty,
+        e.g. the previous step's iters: scheduling only) -- btrapz_warm.  keep_multipliers
         adds this solve's multipliers to the result as "lam"."""
         o = out if out is not None else self._buffers(dbatch.B, dbatch.S)
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -53,7 +54,9 @@ class BatchSolver:
                                   max_iter=max_iter, eps=eps)
             return o
         warm = warm or {}
-        x0, lam0 = warm.get("x0"), warm.get("lam")
+        x0, lam0, hint = warm.get("x0"), warm.get("lam"), warm.get("hint")
+        if hint is not None:
+            assert hint.dtype == torch.int32 and hint.is_contiguous() and hint.numel() == dbatch.B
         if x0 is not None:
             assert x0.dtype == torch.float64 and x0.is_contiguous() and tuple(x0.shape) == (dbatch.B, 2, dbatch.S, 3)
         if lam0 is not None:
@@ -67,7 +70,7 @@ class BatchSolver:
         self.ctx.solve_warm_device(dbatch.B, dbatch.S, shared, dbatch.seg, None, dbatch.init, dbatch.ref_end,
                                    dbatch.dl_bounds, o["ctrl"], o["cost"], o["status"], o["iters"], x0=x0, lam0=lam0,
                                    lam_out=lam_out, mu0=warm.get("mu0", 0.0), smin=warm.get("smin", 0.0),
-                                   stream=stream, max_iter=max_iter, eps=eps)
+                                   stream=stream, max_iter=max_iter, eps=eps, hint=hint)
         return o
 
     def eval_states(self, dbatch, ctrl, times):

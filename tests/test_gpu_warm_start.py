@@ -188,3 +188,32 @@ def test_warm_start_on_ragged_batch(solver):
     w = o["ctrl"].cpu().numpy()
     assert (np.abs(w[ok] - ctrl_cold[ok]).max(axis=1) <= RTOL * np.abs(ctrl_cold[ok]).max(axis=1)).all()
     assert o["iters"].cpu().numpy()[ok].mean() <= it_cold[ok].mean() - 2.0
+
+
+def test_scheduling_hint_changes_nothing_but_the_schedule(solver):
+    """btrapz_warm.hint groups candidates of one difficulty class into the same wavefronts: results must be
+    bit-identical whatever the hint says (constant, informative, random, out of range), cold and warm."""
+    import torch
+    B, S = 4099, 20                                   # not a multiple of anything
+    batch, sh = synth.make_batch(B, S, config=3)
+    db = solver.upload(batch)
+    ref = solver.solve(db, sh, keep_multipliers=True)
+    torch.cuda.synchronize()
+    r_ctrl, r_cost, r_st, r_it = (ref[k].clone() for k in ("ctrl", "cost", "status", "iters"))
+    g = torch.Generator().manual_seed(2)
+    hints = {"constant": torch.full((B,), 3, dtype=torch.int32),
+             "own iterations": (r_it + 1).to(torch.int32).cpu(),
+             "random, out of range": torch.randint(-50, 200, (B,), generator=g, dtype=torch.int32)}
+    for name, h in hints.items():
+        o = solver.solve(db, sh, warm=dict(hint=h.to(solver.device).contiguous()))
+        torch.cuda.synchronize()
+        assert torch.equal(o["ctrl"], r_ctrl) and torch.equal(o["cost"], r_cost), name
+        assert torch.equal(o["status"], r_st) and torch.equal(o["iters"], r_it), name
+    # warm start + hint against warm start alone
+    x0 = solver.eval_states(db, r_ctrl, joint_times(batch))
+    w0 = solver.solve(db, sh, warm=dict(x0=x0, lam=ref["lam"].clone()))
+    torch.cuda.synchronize()
+    w_ctrl, w_it = w0["ctrl"].clone(), w0["iters"].clone()
+    w1 = solver.solve(db, sh, warm=dict(x0=x0, lam=ref["lam"].clone(), hint=hints["random, out of range"].to(solver.device)))
+    torch.cuda.synchronize()
+    assert torch.equal(w1["ctrl"], w_ctrl) and torch.equal(w1["iters"], w_it)

@@ -9,7 +9,8 @@ the horizon starts at now = n*dt: the first segment is the rest of the piece con
 re-based to `now`; when less than one knot of it is left the window rolls and the next piece is extended
 backwards instead, so min_first <= t_0 <= 1 + min_first, --min-first 0.1 = one knot), followed by 19 whole pieces.  Every agent's initial state is its
 previous winner's state dt later (btrapz_eval_states_device); the warm start is the candidate's own previous
-trajectory at the new joint times plus its previous multipliers (rolled by one segment when the window rolls).
+trajectory at the new joint times plus its previous multipliers (rolled by one segment when the window rolls),
+and the previous iteration counts go in as scheduling hint (btrapz_warm.hint).
 
 What is timed per step (HIP events around the whole step, inputs resident): window assembly (torch slicing --
 workload generation, not part of the library), btrapz_eval_states_device x2, btrapz_solve_warm_device,
@@ -42,6 +43,7 @@ def main():
                     help="shortest first segment in seconds before the window rolls (0.1 = one knot)")
     ap.add_argument("--mu0", type=float, default=0.0, help="btrapz_warm.mu0 (0 = library default)")
     ap.add_argument("--smin", type=float, default=0.0, help="btrapz_warm.smin (0 = library default)")
+    ap.add_argument("--no-hint", action="store_true", help="do not pass the previous iteration counts as scheduling hint")
     ap.add_argument("--trace", action="store_true", help="per-step latency / iterations on stderr")
     a = ap.parse_args()
 
@@ -98,6 +100,10 @@ def main():
             if j0 != prev["j0"]:                                     # the window rolled: segment k was k+1
                 lam = torch.roll(lam, shifts=-1, dims=3); lam[:, :, :, -1] = 0.0
             warm = dict(x0=x0, lam=lam, mu0=a.mu0, smin=a.smin)
+            if not a.no_hint:
+                # difficulty persists: hard / infeasible candidates share wavefronts.  Coarse classes -- everything that
+                # took fewer than 8 iterations is "easy" -- so that easy candidates keep their memory order.
+                warm["hint"] = torch.clamp((prev["iters"] - 4) // 4 + 1, min=1).to(torch.int32)
         out = solver.solve(db, sh, warm=warm, keep_multipliers=not a.cold,
                            out=dict(ctrl=torch.empty((B, 12 * S), dtype=torch.float64, device=dev),
                                     cost=torch.empty(B, dtype=torch.float64, device=dev),
@@ -131,7 +137,7 @@ def main():
                     dumped.append(dict(step=n, agent=g, seg=seg[:, wi].cpu().numpy(), init=db.init[wi].cpu().numpy(),
                                        ref_end=ref_end[wi].cpu().numpy(), dl_bounds=world.dl_bounds[wi],
                                        ctrl=out["ctrl"][wi].cpu().numpy()))
-        prev = dict(db=db, ctrl=out["ctrl"], lam=out.get("lam"), j0=j0)
+        prev = dict(db=db, ctrl=out["ctrl"], lam=out.get("lam"), j0=j0, iters=out["iters"])
     wall = time.perf_counter() - wall0
     lat = np.array(lat)
     steady = lat[1:] if len(lat) > 1 else lat
