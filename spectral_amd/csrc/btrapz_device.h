@@ -25,7 +25,6 @@ struct KernelArgs {
   int seg_stride;           // k-stride owner: seg[f][b][k] has seg_stride slots per candidate (== S when uniform)
   // ragged mode (order != nullptr): candidates bucketed by segment count s = 1..64
   const int *order;         // [B] candidate ids, stable counting sort by s
-  int bucket_S;             // 0: the bucket id IS the segment count (ragged); else buckets are hint classes, S = bucket_S
   const int *seg_count;     // [B] s of every candidate (<= 0 or > seg_stride: skipped, status set by the bucket kernel)
   const int *cand_prefix;   // [66] candidates with count < s
   const int *wave_prefix;   // [66] wavefront pairs needed by buckets < s
@@ -50,6 +49,7 @@ struct KernelArgs {
   const double *lam0;       // [2][36][B][seg_stride] multipliers of an earlier solve
   double *lam_out;          // same layout, multipliers at the end of this solve
   double mu0, smin;         // lambda = lam0 + mu0 / s , s = max(gap, smin)
+  int bucket_S;             // 0: the bucket id IS the segment count (ragged); else buckets are hint classes, S = bucket_S
 };
 
 struct CorridorArgs {
@@ -75,7 +75,9 @@ __global__ void bucket_prefix_kernel(int *meta, int fixed_S);
 __global__ void bucket_scatter_kernel(int B, int seg_stride, const int *seg_count, int *meta, int *order,
                                       double *axis_obj, int *axis_status, int *axis_iters, int fixed_S);
 __global__ void ipm_solve_kernel(const KernelArgs a, const double *__restrict__ mqm);
-__global__ void ipm_solve_warm_kernel(const KernelArgs a, const double *__restrict__ mqm);  // + btrapz_warm
+__global__ void ipm_solve_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);       // through a.order
+__global__ void ipm_solve_warm_kernel(const KernelArgs a, const double *__restrict__ mqm);          // + btrapz_warm
+__global__ void ipm_solve_warm_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void finalize_kernel(int B, const double *axis_obj, const int *axis_status, const int *axis_iters,
                                 double *cost, int *status, int *iters);
 __global__ void argmin_kernel(int group, long long index_base, const double *cost, long long *best_idx,

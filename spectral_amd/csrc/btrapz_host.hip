@@ -202,10 +202,10 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     const int gpw = 64 / S;  // axis problems per wavefront; wave w: axis w&1 of candidates (w>>1)*gpw + [0,gpw)
     blocks = 2u * (unsigned)((B + gpw - 1) / gpw);
   }
-  if (a.x0 || a.lam0 || a.lam_out)   // (a hint alone only reorders the candidates: cold kernel)
-    hipLaunchKernelGGL(ipm_solve_warm_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
-  else
-    hipLaunchKernelGGL(ipm_solve_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
+  const bool warm_kernel = a.x0 || a.lam0 || a.lam_out;   // (a hint alone only reorders the candidates)
+  auto kernel = warm_kernel ? (a.order ? ipm_solve_warm_ordered_kernel : ipm_solve_warm_kernel)
+                            : (a.order ? ipm_solve_ordered_kernel : ipm_solve_kernel);
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, B, c->d_axis_obj, c->d_axis_status,
                      c->d_axis_iters, cost, status, iters);

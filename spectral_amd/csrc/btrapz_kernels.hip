@@ -183,7 +183,7 @@ __device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gb
 // -----------------------------------------------------------------------------------------
 // WARM = false: the cold-start kernel (bench path).  WARM = true adds the warm start and the cold restart of a
 // group whose guess did not pay off; a separate instantiation, so the cold kernel keeps its register footprint.
-template <bool WARM>
+template <bool WARM, bool ORDERED>
 __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double *__restrict__ mqm) {
   __shared__ double lds[L_ROWS][64];
 
@@ -191,7 +191,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   // wave w solves axis (w & 1) of gpw consecutive candidates: the axis is wave-uniform
   const int axis = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 1));
   int S, pair = (int)(blockIdx.x >> 1), ncand = a.B, cand0 = 0;
-  if (a.order) {
+  if constexpr (ORDERED) {
     // ragged batch: candidates are bucketed by segment count; find this wave's bucket (wave-uniform)
     if (pair >= a.wave_prefix[65]) return;
     // slot s with wave_prefix[s] <= pair < wave_prefix[s + 1] (empty buckets repeat their prefix): binary search,
@@ -216,7 +216,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   long long cand = (long long)pair * gpw + gl;
   const bool valid = lane_in_group && cand < ncand;
   if (cand >= ncand) cand = ncand - 1;
-  const int b = a.order ? a.order[cand0 + (int)cand] : (int)cand;
+  const int b = ORDERED ? a.order[cand0 + (int)cand] : (int)cand;
   const long long prob = 2LL * b + axis;
   const bool first = (k == 0), last = (k == S - 1);
   const int m = S >> 1;                               // root block of the two-sided elimination
@@ -744,14 +744,21 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   }
 }
 
+// Four instantiations: {cold, warm start} x {candidates in memory order, candidates through a.order (ragged batches
+// and scheduling hints)}.  The bench path is the first; keeping the others out of it keeps its register allocation.
 __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const double *__restrict__ mqm) {
-  ipm_solve_body<false>(a, mqm);
+  ipm_solve_body<false, false>(a, mqm);
+}
+__global__ __launch_bounds__(64) void ipm_solve_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  ipm_solve_body<false, true>(a, mqm);
 }
 __global__ __launch_bounds__(64) void ipm_solve_warm_kernel(const KernelArgs a, const double *__restrict__ mqm) {
-  ipm_solve_body<true>(a, mqm);
+  ipm_solve_body<true, false>(a, mqm);
+}
+__global__ __launch_bounds__(64) void ipm_solve_warm_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  ipm_solve_body<true, true>(a, mqm);
 }
 
-// ---- per-candidate cost/status from the two axis problems (acceptance: solve_3d.cc:1251-1277)
 __global__ void finalize_kernel(int B, const double *axis_obj, const int *axis_status, const int *axis_iters,
                                 double *cost, int *status, int *iters) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
