@@ -11,6 +11,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -32,6 +34,8 @@ const char *kDefaultOutputPrefix[2] = {"/home/srujan_d/RISS/code/btrapz/src/s1_s
 std::mutex g_ctx_mutex;
 std::mutex g_run_mutex;  // the shared context's workspace serves one find_traj at a time
 btrapz_ctx *g_ctx = nullptr;
+void *g_scratch = nullptr;        // device block of find_traj's single-candidate launches (under g_run_mutex)
+size_t g_scratch_bytes = 0;
 
 btrapz_ctx *shared_ctx() {
   std::lock_guard<std::mutex> lk(g_ctx_mutex);
@@ -45,13 +49,6 @@ btrapz_ctx *shared_ctx() {
 bool verbose() { const char *v = getenv("BTRAPZ_VERBOSE"); return v && *v && *v != '0'; }
 
 int clampi(int i, int hi) { return i < 0 ? 0 : (i > hi ? hi : i); }
-
-struct DeviceBuf {
-  void *p = nullptr;
-  ~DeviceBuf() { if (p) (void)hipFree(p); }
-  bool alloc(size_t bytes) { return hipMalloc(&p, bytes) == hipSuccess; }
-  template <class T> T *as() { return static_cast<T *>(p); }
-};
 
 // a_cost of trp_wrapper.cpp:207-286 / cub_wrapper.cpp:201-262.  Reads of x_ref[i] past N
 // and of l[N-1] past the sampled length (undefined in the reference) are clamped.
@@ -191,31 +188,46 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   // A btrapz_ctx is not thread-safe (its per-axis workspace is shared by every launch): concurrent callers of
   // find_traj queue here.  The reference's own calls only ever race on the output file.
   std::lock_guard<std::mutex> run_lock(g_run_mutex);
-  DeviceBuf d_seg, d_init, d_re, d_dl, d_ctrl, d_cost, d_status, d_sel, d_out, d_np;
-  if (!d_seg.alloc(h_seg.size() * 8) || !d_init.alloc(48) || !d_re.alloc(16) || !d_dl.alloc(80) ||
-      !d_ctrl.alloc((size_t)12 * S * 8) || !d_cost.alloc(8) || !d_status.alloc(8) || !d_sel.alloc(8) ||
-      !d_out.alloc((size_t)6 * max_points * 8) || !d_np.alloc(4)) return FAIL;
+  // One persistent device block and one pinned-size host block, laid out as doubles:
+  //   in : seg[17 S] init[6] ref_end[2] dl[10] sel[1]            (one H2D copy)
+  //   out: cost[1] status,iters[1] np[1] ctrl[12 S] traj[6 max_points]   (one D2H copy)
+  const size_t n_in = (size_t)BTRAPZ_NUM_SEG_FIELDS * S + 6 + 2 + 10 + 1;
+  const size_t n_out = 3 + (size_t)12 * S + (size_t)6 * max_points;
+  if ((n_in + n_out) * 8 > g_scratch_bytes) {
+    if (g_scratch) (void)hipFree(g_scratch);
+    g_scratch = nullptr; g_scratch_bytes = 0;
+    const size_t want = (n_in + n_out) * 8 * 2;
+    if (hipMalloc(&g_scratch, want) != hipSuccess) return FAIL;
+    g_scratch_bytes = want;
+  }
+  double *d_in = static_cast<double *>(g_scratch), *d_out_blk = d_in + n_in;
+  double *d_seg = d_in, *d_init = d_seg + (size_t)BTRAPZ_NUM_SEG_FIELDS * S, *d_re = d_init + 6, *d_dl = d_re + 2;
+  long long *d_sel = reinterpret_cast<long long *>(d_dl + 10);
+  double *d_cost = d_out_blk;
+  int *d_status = reinterpret_cast<int *>(d_out_blk + 1), *d_np = reinterpret_cast<int *>(d_out_blk + 2);
+  double *d_ctrl = d_out_blk + 3, *d_traj = d_ctrl + (size_t)12 * S;
+  std::vector<double> h_in(n_in), h_out(n_out);
+  std::copy(h_seg.begin(), h_seg.end(), h_in.begin());
+  std::copy(h_init.begin(), h_init.end(), h_in.begin() + (d_init - d_in));
+  std::copy(h_ref_end.begin(), h_ref_end.end(), h_in.begin() + (d_re - d_in));
+  std::copy(h_dl.begin(), h_dl.end(), h_in.begin() + (d_dl - d_in));
   const long long sel0 = 0;
-  if (hipMemcpy(d_seg.p, h_seg.data(), h_seg.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(d_init.p, h_init.data(), 48, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(d_re.p, h_ref_end.data(), 16, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(d_dl.p, h_dl.data(), 80, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(d_sel.p, &sel0, 8, hipMemcpyHostToDevice) != hipSuccess) return FAIL;
-  if (btrapz_solve_batch_device(ctx, &sh, nullptr, 1, S, d_seg.as<double>(), d_init.as<double>(), d_re.as<double>(),
-                                d_dl.as<double>(), d_ctrl.as<double>(), d_cost.as<double>(), d_status.as<int>(),
-                                d_status.as<int>() + 1, nullptr) != BTRAPZ_OK ||
-      btrapz_sample_device(ctx, 1, S, in.delta, d_seg.as<double>(), d_init.as<double>(), d_ctrl.as<double>(), 1,
-                           d_sel.as<long long>(), max_points, d_out.as<double>(), d_np.as<int>(), nullptr) != BTRAPZ_OK) {
+  memcpy(&h_in[n_in - 1], &sel0, 8);
+  if (hipMemcpy(d_in, h_in.data(), n_in * 8, hipMemcpyHostToDevice) != hipSuccess) return FAIL;
+  if (btrapz_solve_batch_device(ctx, &sh, nullptr, 1, S, d_seg, d_init, d_re, d_dl, d_ctrl, d_cost, d_status, d_status + 1,
+                                nullptr) != BTRAPZ_OK ||
+      btrapz_sample_device(ctx, 1, S, in.delta, d_seg, d_init, d_ctrl, 1, d_sel, max_points, d_traj, d_np, nullptr) !=
+          BTRAPZ_OK) {
     fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
     return FAIL;
   }
+  // (a blocking copy on the null stream waits for the two launches before it)
+  if (hipMemcpy(h_out.data(), d_out_blk, n_out * 8, hipMemcpyDeviceToHost) != hipSuccess) return FAIL;
   int h_status[2] = {0, 0}, h_np = 0;
-  double h_cost = 0.0;
-  std::vector<double> out((size_t)6 * max_points);
-  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h_status, d_status.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(&h_cost, d_cost.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(&h_np, d_np.p, 4, hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(out.data(), d_out.p, out.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return FAIL;
+  double h_cost = h_out[0];
+  memcpy(h_status, &h_out[1], 8);
+  memcpy(&h_np, &h_out[2], 4);
+  std::vector<double> out(h_out.begin() + 3 + 12 * S, h_out.end());
   if (verbose()) fprintf(stderr, "btrapz: S=%d status=%d iters=%d obj=%.9g\n", S, h_status[0], h_status[1], h_cost);
   // acceptance: solve_3d.cc:1251-1277
   if (h_status[0] != BTRAPZ_SOLVED && h_status[0] != BTRAPZ_SOLVED_INACCURATE) return FAIL;
@@ -226,8 +238,7 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   const double cost = trajectory_cost(variant, *p, in, max_points, s, ds, dds, l, dl, ddl);
 
   res.S = S; res.np = max_points; res.out = std::move(out);
-  res.ctrl.resize((size_t)12 * S);
-  if (hipMemcpy(res.ctrl.data(), d_ctrl.p, res.ctrl.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return FAIL;
+  res.ctrl.assign(h_out.begin() + 3, h_out.begin() + 3 + 12 * S);
   return cost;
 }
 
