@@ -462,16 +462,33 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     }
 
     // ---- 2. Newton matrix: H = P + G'WG ; M = Phi' H Phi ; block tridiagonal T, M01 ----
-    double M01[9], T[6];
+    // right-hand side in control-point space -> reduced to X space, sign flipped: u = -Phi' h
+    auto reduce_rhs = [&](const double (&h)[6], double (&u)[3]) {
+      double hn[3];
+      VT_apply(nm, h[3], h[4], h[5], u);
+      UT_apply(nm, h[0], h[1], h[2], hn);
+      UNROLL for (int i = 0; i < 3; i++) { const double v = from_next(hn[i]); u[i] = -(u[i] + (last ? 0.0 : v)); }
+    };
+    double M01[9], T[6], up[3];   // up: the predictor's reduced right-hand side
     {
-      double H[21];
+      double H[21], hp[6];
       LOAD_P(H)
-      PHASE_FENCE();
+      PHASE_FENCE(opaque6(c));
+      // The predictor's right-hand side (rc = s*lambda -> tv = lambda_l (s_l + rp_l)/s_l - lambda_u (s_u - rp_u)/s_u)
+      // needs exactly what this loop has in its hands -- the fresh reciprocals, the multipliers, G c -- so it is
+      // accumulated here instead of in a row loop of its own (one pass over the rows and 72 LDS reads less).
+      UNROLL for (int i = 0; i < 6; i++) hp[i] = gc[i];
       FOR_ROWS(r)
         const double isl = rcp(sl[r]), isu = rcp(su[r]);
+        const double ll = LL(r), lu = LU(r);
         lds[L_ISL + r][lane] = isl; lds[L_ISU + r][lane] = isu;
-        row_outer<r>(LL(r) * isl + LU(r) * isu, t2, H);
+        const double wl = ll * isl, wu = lu * isu;
+        row_outer<r>(wl + wu, t2, H);
+        const double gcr = row_dot<r>(c, t);
+        const double rpl = gcr - sl[r] - LO(r), rpu = gcr + su[r] - UP(r);
+        row_scatter<r>(wl * (sl[r] + rpl) - wu * (su[r] - rpu), t, hp);
       END_ROWS
+      reduce_rhs(hp, up);
       double w0[3], w1[3], w2[3], col[3], M00[6];
       // M00 = U' H00 U
       UT_apply(nm, H[SYM(0, 0)], H[SYM(0, 1)], H[SYM(0, 2)], w0);
@@ -503,6 +520,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     // updates.  A lane that has factored its pivot S_k = T_k - Z_in forms K = S_k^{-1} Mc and Z_out = Mc' K for
     // its neighbour towards the middle (Mc = M01_{k+1} for the upper half, M01_k' for the lower half).
     double F[6] = {0.0, 0.0, 0.0, 1.0, 1.0, 1.0}, K[9], Z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double wp[3] = {0.0, 0.0, 0.0};   // forward-sweep vector of the predictor (see the loop)
     {
       double Mc[9];
       UNROLL for (int i = 0; i < 3; i++)
@@ -520,12 +538,18 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         // neighbour towards the root one step later; the neighbour on the other side -- and, across a group
         // boundary, the neighbouring group's end lane, whose step is 0 -- still holds 0 when this lane's step
         // comes.  Only S <= 2 breaks that (the root is an end lane): a wave-uniform fix-up.
-        double pZ[6], nZ[6];
+        double pZ[6], nZ[6], pw[3], nw[3];
         UNROLL for (int i = 0; i < 6; i++) { pZ[i] = from_prev(Z[i]); nZ[i] = from_next(Z[i]); }
-        if (S <= 2) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 6; i++) { pZ[i] = first ? 0.0 : pZ[i]; nZ[i] = last ? 0.0 : nZ[i]; } }
+        UNROLL for (int i = 0; i < 3; i++) { pw[i] = from_prev(wp[i]); nw[i] = from_next(wp[i]); }
+        if (S <= 2) {
+          UNIFORM_BLOCK;
+          UNROLL for (int i = 0; i < 6; i++) { pZ[i] = first ? 0.0 : pZ[i]; nZ[i] = last ? 0.0 : nZ[i]; }
+          UNROLL for (int i = 0; i < 3; i++) { pw[i] = first ? 0.0 : pw[i]; nw[i] = last ? 0.0 : nw[i]; }
+        }
         if (step == my_step) {
           double Sk[6];
           UNROLL for (int i = 0; i < 6; i++) Sk[i] = T[i] - (pZ[i] + nZ[i]);
+          UNROLL for (int i = 0; i < 3; i++) up[i] -= pw[i] + nw[i];   // the predictor's forward sweep rides along
           ldl3(Sk, F);
           if (!mid) {
             UNROLL for (int j = 0; j < 3; j++) ldl3_solve(F, Mc[j], Mc[3 + j], Mc[6 + j], K[j], K[3 + j], K[6 + j]);
@@ -535,6 +559,9 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
             Z[3] = Mc[1] * K[1] + Mc[4] * K[4] + Mc[7] * K[7];
             Z[4] = Mc[1] * K[2] + Mc[4] * K[5] + Mc[7] * K[8];
             Z[5] = Mc[2] * K[2] + Mc[5] * K[5] + Mc[8] * K[8];
+            wp[0] = K[0] * up[0] + K[3] * up[1] + K[6] * up[2];
+            wp[1] = K[1] * up[0] + K[4] * up[1] + K[7] * up[2];
+            wp[2] = K[2] * up[0] + K[5] * up[1] + K[8] * up[2];
           }
         }
       }
@@ -542,14 +569,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 
     // ---- 4. predictor (sigma = 0), then corrector ----
     // One solve: rhs u (already reduced to X space) -> dX by the block LDL^T sweeps -> dc.
-    auto solve_dc = [&](const double (&h)[6], double (&dX)[3], double (&dc)[6]) {
-      double u[3];
-      {
-        double hn[3];
-        VT_apply(nm, h[3], h[4], h[5], u);
-        UT_apply(nm, h[0], h[1], h[2], hn);
-        UNROLL for (int i = 0; i < 3; i++) { const double v = from_next(hn[i]); u[i] = -(u[i] + (last ? 0.0 : v)); }
-      }
+    auto forward_u = [&](double (&u)[3]) {
       // forward, both halves towards the root: a lane whose u is final sends w = K' u inwards
       double w[3] = {0.0, 0.0, 0.0};
 #if defined(ABL_NOSEQ) || defined(ABL_NOSWEEP)
@@ -569,6 +589,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
           }
         }
       }
+    };
+    auto backward_u = [&](const double (&u)[3], double (&dX)[3], double (&dc)[6]) {
       // backward, from the root outwards: dX_k = S_k^{-1} u_k - K_k dX_(neighbour towards the root).  y carries
       // the FINAL dX of a lane (0 until then), so the neighbour away from the root contributes 0: an add, no select.
       ldl3_solve(F, u[0], u[1], u[2], dX[0], dX[1], dX[2]);
@@ -596,6 +618,12 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       U_apply(nm, dXp, dc[0], dc[1], dc[2]);
       V_apply(nm, dX, dc[3], dc[4], dc[5]);
     };
+    auto solve_dc = [&](const double (&h)[6], double (&dX)[3], double (&dc)[6]) {
+      double u[3];
+      reduce_rhs(h, u);
+      forward_u(u);
+      backward_u(u, dX, dc);
+    };
     // per row: reciprocal slacks and multipliers from this lane's LDS column, residuals from c
     // The four LDS values of row r+1 are requested while row r is computed (one wavefront per SIMD: nobody else
     // hides the LDS latency); a scheduling barrier that only LDS reads may not cross keeps the compiler from
@@ -617,15 +645,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     double sigma_mu;
     {
       // predictor.  rc = s*lambda  ->  tv = lambda_l (s_l + rp_l)/s_l - lambda_u (s_u - rp_u)/s_u
-      double h[6];
-      UNROLL for (int i = 0; i < 6; i++) h[i] = gc[i];
-      PHASE_FENCE(opaque6(c));
-      ROW_PREFETCH();
-      FOR_ROWS(r)
-        ROW_BASE(r)
-        row_scatter<r>(ll * (sl[r] + rpl) * isl - lu * (su[r] - rpu) * isu, t, h);
-      END_ROWS
-      solve_dc(h, dX, dca);
+      backward_u(up, dX, dca);   // right-hand side from the Newton-matrix loop, forward sweep done in the factorisation loop
       // With rc = s*lambda:  dlambda/lambda = -(1 + ds/s).  Step lengths come from q = ds/s alone, and
       //   m*mu_aff = (1-ad) S0 + (ap - ad - ap*ad) S1 - ap*ad S4,   S0 = sum s*lambda (= m*mu),
       //   S1 = sum lambda*ds,  S4 = sum lambda*ds*q        -- no second pass over the rows.
