@@ -9,7 +9,9 @@ the horizon starts at now = n*dt: the first segment is the rest of the piece con
 re-based to `now`; when less than one knot of it is left the window rolls and the next piece is extended
 backwards instead, so min_first <= t_0 <= 1 + min_first, --min-first 0.1 = one knot), followed by 19 whole pieces.  Every agent's initial state is its
 previous winner's state dt later (btrapz_eval_states_device); the warm start is the candidate's own previous
-trajectory at the new joint times plus its previous multipliers (rolled by one segment when the window rolls),
+trajectory at the new joint times plus its previous multipliers -- except at the steps that roll the window, where
+the first segment becomes another piece of the corridor and a cold start is faster (--roll: measured 7.4 ms cold,
+8.0 ms from the plan alone, 13.8 ms with the multipliers rolled by one segment) --
 and the previous iteration counts go in as scheduling hint (btrapz_warm.hint).
 
 What is timed per step (HIP events around the whole step, inputs resident): window assembly (torch slicing --
@@ -44,6 +46,8 @@ def main():
     ap.add_argument("--mu0", type=float, default=0.0, help="btrapz_warm.mu0 (0 = library default)")
     ap.add_argument("--smin", type=float, default=0.0, help="btrapz_warm.smin (0 = library default)")
     ap.add_argument("--no-hint", action="store_true", help="do not pass the previous iteration counts as scheduling hint")
+    ap.add_argument("--roll", default="cold", choices=["lam", "x0", "cold"],
+                    help="what a step that rolls the window starts from: previous plan + rolled multipliers, plan only, nothing")
     ap.add_argument("--trace", action="store_true", help="per-step latency / iterations on stderr")
     a = ap.parse_args()
 
@@ -97,9 +101,14 @@ def main():
             times = (torch.cumsum(seg[L.F_T], dim=1) + a.dt).contiguous()
             x0 = solver.eval_states(prev["db"], prev["ctrl"], times)
             lam = prev["lam"]
-            if j0 != prev["j0"]:                                     # the window rolled: segment k was k+1
+            rolled = j0 != prev["j0"]
+            if rolled and a.roll == "lam":                           # the window rolled: segment k was k+1
                 lam = torch.roll(lam, shifts=-1, dims=3); lam[:, :, :, -1] = 0.0
             warm = dict(x0=x0, lam=lam, mu0=a.mu0, smin=a.smin)
+            if rolled and a.roll == "x0":
+                warm = dict(x0=x0, mu0=a.mu0, smin=a.smin)
+            if rolled and a.roll == "cold":
+                warm = dict()
             if not a.no_hint:
                 # difficulty persists: hard / infeasible candidates share wavefronts.  Coarse classes -- everything that
                 # took fewer than 8 iterations is "easy" -- so that easy candidates keep their memory order.
