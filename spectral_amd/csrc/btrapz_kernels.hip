@@ -272,7 +272,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 #define UP(r) ((r) < 6 ? phi0 + (double)(r) * dphi : (r) < 11 ? vhi[((r) >= 6 && (r) < 11) ? (r) - 6 : 0] : (r) < 15 ? ahi : jhi)
 
   // P block (solve_3d.cc:159-171) from the batch-invariant MQM_d = M' pQp_d M: the table is
-  // wave-uniform (one axis per wave) -> scalar loads; P is rebuilt where it is needed.
+  // wave-uniform (one axis per wave) -> scalar loads.
   const double *__restrict__ mq = mqm + axis * 84;
   const double t3 = t * t * t, it3 = it * it * it, t2 = t * t;
   const double pend = last ? 2.0 * (axis == 0 ? sh.weight_end_s : sh.weight_end_l) * t2 : 0.0;  // :164-168
@@ -379,6 +379,11 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   bool restarted = !warm_started;   // a warm-started group that stalls gets ONE cold restart
   int it0 = 0;                      // iteration at which the current start was made
 
+  // P block of this lane's segment, once per solve: rebuilding it from the scalar table where it is needed (twice
+  // per iteration: 168 FMAs and the spill traffic of 84 scalar doubles) was the price of an earlier, tighter
+  // register budget; kept live it costs the allocator nothing measurable (6.67 -> 6.32 ms).
+  double Pk[21];
+  LOAD_P(Pk)
   const double eps = a.eps;
   const double inv_m = 1.0 / (36.0 * (double)S);
   double best_score = 1e300, Xb[3] = {X[0], X[1], X[2]};
@@ -404,7 +409,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       END_ROWS
       UNROLL for (int i = 0; i < 6; i++) dscale = fmax(dscale, fabs(gc[i]));
       double Pm[21];
-      LOAD_P(Pm)
+      UNROLL for (int i_ = 0; i_ < 21; i_++) Pm[i_] = Pk[i_];
       UNROLL for (int i = 0; i < 6; i++) {
         double s = 0.0;
         UNROLL for (int j = 0; j < 6; j++) s += HSYM(Pm, i, j) * c[j];
@@ -472,7 +477,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     double M01[9], T[6], up[3];   // up: the predictor's reduced right-hand side
     {
       double H[21], hp[6];
-      LOAD_P(H)
+      UNROLL for (int i_ = 0; i_ < 21; i_++) H[i_] = Pk[i_];
       PHASE_FENCE(opaque6(c));
       // The predictor's right-hand side (rc = s*lambda -> tv = lambda_l (s_l + rp_l)/s_l - lambda_u (s_u - rp_u)/s_u)
       // needs exactly what this loop has in its hands -- the fresh reciprocals, the multipliers, G c -- so it is
@@ -739,7 +744,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     V_apply(nm, Xb, c[3], c[4], c[5]);
     double obj = 0.0;
     double Pm[21];
-    LOAD_P(Pm)
+    UNROLL for (int i_ = 0; i_ < 21; i_++) Pm[i_] = Pk[i_];
     UNROLL for (int i = 0; i < 6; i++) {
       double s = 0.0;
       UNROLL for (int j = 0; j < 6; j++) s += HSYM(Pm, i, j) * c[j];
