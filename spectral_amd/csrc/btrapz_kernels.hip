@@ -142,9 +142,10 @@ __device__ __forceinline__ void ldl3_solve(const double (&F)[6], double b0, doub
 enum { L_LL = 0, L_LU = 18, L_ISL = 36, L_ISU = 54, L_RED = 72, L_ROWS = 76 };
 
 // Reductions over the S lanes of a group: every lane publishes 4 values, then reads its
-// group's S entries in batches of 8 (reads issued back to back, one wait per batch; fixed order
+// group's S entries in batches of RB (reads issued back to back, one wait per batch; fixed order
 // -> bit-reproducible).  OPn: 0 sum, 1 max, 2 min.
 struct Red4 { double a, b, c, d; };
+enum { RB = 10 };   // entries read per batch: 20 segments = 2 batches, 10 segments = 1
 template <int OP> __device__ __forceinline__ double red_init() { return OP == 0 ? 0.0 : OP == 1 ? -1e300 : 1e300; }
 template <int OP> __device__ __forceinline__ double red_op(double acc, double v, bool in_range) {
   if constexpr (OP == 0) return acc + (in_range ? v : 0.0);   // padded slots repeat entry S-1: harmless for max/min
@@ -165,13 +166,13 @@ __device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gb
   lds[L_RED + 0][lane] = v0; lds[L_RED + 1][lane] = v1; lds[L_RED + 2][lane] = v2; lds[L_RED + 3][lane] = v3;
   wave_lds_sync();
   Red4 r = {red_init<O0>(), red_init<O1>(), red_init<O2>(), red_init<O3>()};
-  for (int j0 = 0; j0 < S; j0 += 8) {
-    double a[8], b[8], c[8], d[8];
-    UNROLL for (int u = 0; u < 8; u++) {
+  for (int j0 = 0; j0 < S; j0 += RB) {
+    double a[RB], b[RB], c[RB], d[RB];
+    UNROLL for (int u = 0; u < RB; u++) {
       const int j = gbase + (j0 + u < S ? j0 + u : S - 1);
       a[u] = lds[L_RED + 0][j]; b[u] = lds[L_RED + 1][j]; c[u] = lds[L_RED + 2][j]; d[u] = lds[L_RED + 3][j];
     }
-    UNROLL for (int u = 0; u < 8; u++) {
+    UNROLL for (int u = 0; u < RB; u++) {
       const bool in = j0 + u < S;
       r.a = red_op<O0>(r.a, a[u], in); r.b = red_op<O1>(r.b, b[u], in);
       r.c = red_op<O2>(r.c, c[u], in); r.d = red_op<O3>(r.d, d[u], in);
