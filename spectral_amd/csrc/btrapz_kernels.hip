@@ -145,7 +145,7 @@ enum { L_LL = 0, L_LU = 18, L_ISL = 36, L_ISU = 54, L_RED = 72, L_ROWS = 76 };
 // group's S entries in batches of RB (reads issued back to back, one wait per batch; fixed order
 // -> bit-reproducible).  OPn: 0 sum, 1 max, 2 min.
 struct Red4 { double a, b, c, d; };
-enum { RB = 10 };   // entries read per batch: 20 segments = 2 batches, 10 segments = 1
+enum { RB = 10 };   // entries read per batch (pairs of lanes, see group_reduce): 20 segments = 1 batch
 template <int OP> __device__ __forceinline__ double red_init() { return OP == 0 ? 0.0 : OP == 1 ? -1e300 : 1e300; }
 template <int OP> __device__ __forceinline__ double red_op(double acc, double v, bool in_range) {
   if constexpr (OP == 0) return acc + (in_range ? v : 0.0);   // padded slots repeat entry S-1: harmless for max/min
@@ -159,21 +159,32 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+template <int OP> __device__ __forceinline__ double pair_op(double v, bool has_next) {
+  const double n = from_next(v);
+  if constexpr (OP == 0) return v + (has_next ? n : 0.0);
+  else if constexpr (OP == 1) return has_next ? fmax(v, n) : v;
+  else return has_next ? fmin(v, n) : v;
+}
+// Every lane first combines its value with its right neighbour's (DPP, if that lane belongs to the same group), so
+// only the even lanes' entries have to be read back: half the LDS reads and half the combining operations.
 template <int O0, int O1, int O2, int O3>
-__device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gbase, int S, double v0, double v1,
+__device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gbase, int k, int S, double v0, double v1,
                                              double v2, double v3) {
+  const bool has_next = k + 1 < S;
+  v0 = pair_op<O0>(v0, has_next); v1 = pair_op<O1>(v1, has_next); v2 = pair_op<O2>(v2, has_next); v3 = pair_op<O3>(v3, has_next);
   wave_lds_sync();
   lds[L_RED + 0][lane] = v0; lds[L_RED + 1][lane] = v1; lds[L_RED + 2][lane] = v2; lds[L_RED + 3][lane] = v3;
   wave_lds_sync();
   Red4 r = {red_init<O0>(), red_init<O1>(), red_init<O2>(), red_init<O3>()};
-  for (int j0 = 0; j0 < S; j0 += RB) {
+  const int n2 = (S + 1) >> 1;   // pairs (the last one may be a single lane)
+  for (int j0 = 0; j0 < n2; j0 += RB) {
     double a[RB], b[RB], c[RB], d[RB];
     UNROLL for (int u = 0; u < RB; u++) {
-      const int j = gbase + (j0 + u < S ? j0 + u : S - 1);
+      const int j = gbase + 2 * (j0 + u < n2 ? j0 + u : n2 - 1);
       a[u] = lds[L_RED + 0][j]; b[u] = lds[L_RED + 1][j]; c[u] = lds[L_RED + 2][j]; d[u] = lds[L_RED + 3][j];
     }
     UNROLL for (int u = 0; u < RB; u++) {
-      const bool in = j0 + u < S;
+      const bool in = j0 + u < n2;
       r.a = red_op<O0>(r.a, a[u], in); r.b = red_op<O1>(r.b, b[u], in);
       r.c = red_op<O2>(r.c, c[u], in); r.d = red_op<O3>(r.d, d[u], in);
     }
@@ -326,7 +337,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     Xcold0 = Xinit[0] + Xinit[1] * tsum;
   }
   {
-    const Red4 r0 = group_reduce<0, 1, 1, 2>(lds, lane, gbase, S, 0.0, bnorm, qn, gapmin);
+    const Red4 r0 = group_reduce<0, 1, 1, 2>(lds, lane, gbase, k, S, 0.0, bnorm, qn, gapmin);
     bnorm = r0.b; qn = r0.c; gapmin = r0.d;
   }
   const bool infeasible_bounds = !(gapmin >= 0.0) || !(t > 0.0);
@@ -437,7 +448,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     if (!(mu_part == mu_part) || !(rd_part == rd_part) || !(rp_part == rp_part) || !(dscale == dscale) ||
         !(fabs(rd_part) < 1e300) || !(fabs(mu_part) < 1e300))
       rp_part = 1e300;
-    const Red4 rr = group_reduce<0, 1, 1, 1>(lds, lane, gbase, S, mu_part, rd_part, rp_part, dscale);
+    const Red4 rr = group_reduce<0, 1, 1, 1>(lds, lane, gbase, k, S, mu_part, rd_part, rp_part, dscale);
     const double mu = rr.a * inv_m;
     // KKT score: dual residual relative to (1+|q|) with a round-off floor, primal residual
     // relative to the bound scale, complementarity absolute.
@@ -675,7 +686,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         S1 += al + au;
         S4 += al * ql + au * qu;
       END_ROWS
-      const Red4 ra = group_reduce<0, 0, 1, 2>(lds, lane, gbase, S, S1, S4, qmax, qmin);
+      const Red4 ra = group_reduce<0, 0, 1, 2>(lds, lane, gbase, k, S, S1, S4, qmax, qmin);
       const double ap = 1.0 / fmax(-ra.d, 1.0), ad = 1.0 / fmax(1.0 + ra.c, 1.0);
       const double mua = ((1.0 - ad) * rr.a + (ap - ad - ap * ad) * ra.a - ap * ad * ra.b) * inv_m;
       const double sr = mua / mu;
@@ -713,7 +724,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         pr = fmax(pr, fmax(-dsl * isl, -dsu * isu));
         dr = fmax(dr, fmax(-dll * rcp_fast(ll), -dlu * rcp_fast(lu)));
       END_ROWS
-      const Red4 ra = group_reduce<0, 1, 1, 1>(lds, lane, gbase, S, 0.0, pr, dr, 0.0);
+      const Red4 ra = group_reduce<0, 1, 1, 1>(lds, lane, gbase, k, S, 0.0, pr, dr, 0.0);
       // m = largest ratio -ds/s, -dlambda/lambda: the boundary is 1/m away.  A long step may go almost all the way
       // (fewer iterations); a blocked one keeps 0.5 % distance, or the iterates lose centrality and crawl.
       const double m_ = fmax(ra.b, ra.c);
@@ -758,7 +769,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       UNROLL for (int j = 0; j < 6; j++) s += HSYM(Pm, i, j) * c[j];
       obj += c[i] * (0.5 * s + q[i]);
     }
-    const Red4 ro = group_reduce<0, 1, 1, 1>(lds, lane, gbase, S, obj, 0.0, 0.0, 0.0);
+    const Red4 ro = group_reduce<0, 1, 1, 1>(lds, lane, gbase, k, S, obj, 0.0, 0.0, 0.0);
     if (valid) {
       // control points in the reference's order: s axis (6 S), then l axis (6 S); rows are 12*seg_stride apart
       double *dst = a.ctrl + (size_t)b * 12 * a.seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
