@@ -151,6 +151,22 @@ typedef struct btrapz_options {
   double step_threshold; /* the fraction above is used only when the step to the boundary is at least this long
                             (blocked steps, and every step after the 12th iteration, take 0.995 of it, which
                             keeps the iterates centred); 0 -> default (0.9) */
+  /* Rescue of stalled candidates (acceptance, solve_3d.cc:1251-1277 / trp_wrapper.cpp:191-200).  The reference
+   * accepts OSQP's status 2: on a marginally infeasible corridor (e.g. src/c7.txt) that is an ADMM iterate which
+   * violates rows by up to ~0.5 in their own units, and find_traj returns a trajectory.  An exact method has no
+   * such iterate -- the QP has no solution -- so the equivalent here is explicit: an axis problem whose
+   * interior-point solve stalls is solved again with every inequality row relaxed, l <= g'x - d <= u, and
+   * sum d^2 / (2 elastic_delta) added to the objective (equalities -- continuity, initial state -- stay exact):
+   * the least-squares violation of the rows, the reference's objective deciding among its minimisers.
+   *   elastic        0: off (stalled candidates keep status -2, cost +inf) -- default of the batched entry points;
+   *                  1: rescue pass over the stalled axis problems after the solve; 2: every candidate is solved
+   *                  with elastic rows straight away.  find_traj uses 1 (BTRAPZ_ELASTIC=0 turns it off).
+   *   elastic_tol    a rescued problem whose largest row violation is at most this is reported as
+   *                  BTRAPZ_SOLVED_INACCURATE (2), beyond it as BTRAPZ_PRIMAL_INFEASIBLE (-3); 0 -> default (0.5)
+   *   elastic_delta  0 -> default (1e-8) */
+  int elastic;
+  double elastic_tol;
+  double elastic_delta;
 } btrapz_options;
 
 /* A context owns the per-launch workspace of one device: it is NOT thread-safe (one context per calling

@@ -1340,7 +1340,11 @@ static void lu_solve(const double *M, const int *piv, double *b, int N) {
   for (int r = N - 1; r >= 0; r--) { double s = b[r]; for (int k = r + 1; k < N; k++) s -= M[(size_t)r * N + k] * b[k]; b[r] = s / M[(size_t)r * N + r]; }
 }
 
-int orc_ipm_solve(const orc_qp *qp, double eps, int max_iter, double *x_out, double *y_out, orc_info *info) {
+/* delta > 0: every inequality row is elastic, l <= a'x - d <= u with d^2 / (2 delta) added to the objective (the
+ * rescue pass of the product, include/btrapz_hip.h btrapz_options.elastic).  Eliminating d = delta (lambda_u - lambda_l)
+ * changes three things per row: its value a'x - delta y, its weight W / (1 + delta W) in the Newton matrix, and the step
+ * of its value (a'dx - delta t) / (1 + delta W), t the row's entry of the right-hand side.  delta = 0: the plain method. */
+static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, double *x_out, double *y_out, orc_info *info) {
   const int n = qp->n, m = qp->m;
   const double eq_tol = 1e-12;
   int *iseq = (int *)malloc(sizeof(int) * m), *rowpos = (int *)malloc(sizeof(int) * m);
@@ -1368,7 +1372,7 @@ int orc_ipm_solve(const orc_qp *qp, double eps, int max_iter, double *x_out, dou
   double *dsl = (double *)malloc(sizeof(double) * (mi + 1)), *dsu = (double *)malloc(sizeof(double) * (mi + 1));
   double *dll = (double *)malloc(sizeof(double) * (mi + 1)), *dlu = (double *)malloc(sizeof(double) * (mi + 1));
   double *rcl = (double *)malloc(sizeof(double) * (mi + 1)), *rcu = (double *)malloc(sizeof(double) * (mi + 1));
-  double *Adx = (double *)malloc(sizeof(double) * m);
+  double *Adx = (double *)malloc(sizeof(double) * m), *tt = (double *)malloc(sizeof(double) * (mi + 1));
   double *bx = (double *)malloc(sizeof(double) * n), *by = (double *)calloc(m, sizeof(double));
   double qn = vnorm_inf(qp->q, n), bn = 0;
   for (int i = 0; i < m; i++) { bn = fmax(bn, fabs(qp->l[i])); bn = fmax(bn, fabs(qp->u[i])); }
@@ -1385,7 +1389,10 @@ int orc_ipm_solve(const orc_qp *qp, double eps, int max_iter, double *x_out, dou
     for (int i = 0; i < m; i++) {
       int r = rowpos[i];
       if (iseq[i]) { re[r] = Ax[i] - qp->l[i]; rpn = fmax(rpn, fabs(re[r])); }
-      else { rpl[r] = Ax[i] - sl[r] - qp->l[i]; rpu[r] = Ax[i] + su[r] - qp->u[i]; mu += sl[r] * ll[r] + su[r] * lu_[r]; rpn = fmax(rpn, fmax(fabs(rpl[r]), fabs(rpu[r]))); }
+      else {
+        const double v = Ax[i] - delta * (lu_[r] - ll[r]);
+        rpl[r] = v - sl[r] - qp->l[i]; rpu[r] = v + su[r] - qp->u[i]; mu += sl[r] * ll[r] + su[r] * lu_[r]; rpn = fmax(rpn, fmax(fabs(rpl[r]), fabs(rpu[r])));
+      }
     }
     mu = mi ? mu / (2.0 * mi) : 0;
     double score = fmax(fmax(vnorm_inf(rd, n) / (1 + qn), rpn / (1 + bn)), mu);
@@ -1402,7 +1409,8 @@ int orc_ipm_solve(const orc_qp *qp, double eps, int max_iter, double *x_out, dou
       if (iseq[i]) { for (int j = 0; j < n; j++) if (a[j] != 0) { K[(size_t)(n + r) * Nk + j] = a[j]; K[(size_t)j * Nk + (n + r)] = a[j]; } }
       else {
         W[r] = ll[r] / sl[r] + lu_[r] / su[r];
-        for (int j = 0; j < n; j++) if (a[j] != 0) { double f = W[r] * a[j]; for (int k = 0; k < n; k++) if (a[k] != 0) K[(size_t)j * Nk + k] += f * a[k]; }
+        const double We = W[r] / (1.0 + delta * W[r]);
+        for (int j = 0; j < n; j++) if (a[j] != 0) { double f = We * a[j]; for (int k = 0; k < n; k++) if (a[k] != 0) K[(size_t)j * Nk + k] += f * a[k]; }
       }
     }
     if (lu_factor(K, piv, Nk) != 0) break;
@@ -1418,6 +1426,7 @@ int orc_ipm_solve(const orc_qp *qp, double eps, int max_iter, double *x_out, dou
         if (iseq[i]) rhs[n + r] = -re[r];
         else {
           double t = rcl[r] / sl[r] - rcu[r] / su[r] + (ll[r] / sl[r]) * rpl[r] + (lu_[r] / su[r]) * rpu[r];
+          tt[r] = t; t /= 1.0 + delta * W[r];
           const double *a = Ad + (size_t)i * n; for (int j = 0; j < n; j++) if (a[j] != 0) rhs[j] -= a[j] * t;
         }
       }
@@ -1426,7 +1435,8 @@ int orc_ipm_solve(const orc_qp *qp, double eps, int max_iter, double *x_out, dou
       double ap = 1, ad = 1;
       for (int i = 0; i < m; i++) if (!iseq[i]) {
         int r = rowpos[i];
-        dsl[r] = Adx[i] + rpl[r]; dsu[r] = -Adx[i] - rpu[r];
+        const double g = (Adx[i] - delta * tt[r]) / (1.0 + delta * W[r]);
+        dsl[r] = g + rpl[r]; dsu[r] = -g - rpu[r];
         dll[r] = (-rcl[r] - ll[r] * dsl[r]) / sl[r]; dlu[r] = (-rcu[r] - lu_[r] * dsu[r]) / su[r];
         if (dsl[r] < 0) ap = fmin(ap, -sl[r] / dsl[r]);
         if (dsu[r] < 0) ap = fmin(ap, -su[r] / dsu[r]);
@@ -1451,12 +1461,19 @@ int orc_ipm_solve(const orc_qp *qp, double eps, int max_iter, double *x_out, dou
   status = best_score < 1e-7 ? 1 : (best_score < 1e-5 ? 2 : -2);
   for (int j = 0; j < n; j++) { double s = 0; const double *pr = Pd + (size_t)j * n; for (int k = 0; k < n; k++) s += pr[k] * bx[k]; obj += 0.5 * bx[j] * s + qp->q[j] * bx[j]; }
   free(Ad); free(Pd); free(K); free(piv); free(x); free(nu); free(sl); free(su); free(ll); free(lu_); free(Ax); free(rd);
-  free(rpl); free(rpu); free(re); free(W); free(rhs); free(dsl); free(dsu); free(dll); free(dlu); free(rcl); free(rcu); free(Adx); free(bx); free(by);
+  free(rpl); free(rpu); free(re); free(W); free(rhs); free(dsl); free(dsu); free(dll); free(dlu); free(rcl); free(rcu); free(Adx); free(tt); free(bx); free(by);
   }
 fin:
   if (info) { memset(info, 0, sizeof(*info)); info->status = status; info->iter = iter; info->obj_val = obj; info->pri_res = best_score; }
   free(iseq); free(rowpos);
   return 0;
+}
+
+int orc_ipm_solve(const orc_qp *qp, double eps, int max_iter, double *x_out, double *y_out, orc_info *info) {
+  return ipm_core(qp, 0.0, eps, max_iter, x_out, y_out, info);
+}
+int orc_elastic_solve(const orc_qp *qp, double delta, double eps, int max_iter, double *x_out, double *y_out, orc_info *info) {
+  return ipm_core(qp, delta, eps, max_iter, x_out, y_out, info);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -154,6 +154,14 @@ int orc_osqp_solve(const orc_qp *qp, const orc_settings *s, double *x,
 int orc_ipm_solve(const orc_qp *qp, double eps, int max_iter, double *x,
                   double *y, orc_info *info);
 
+/* The same method on the relaxed problem of the product's rescue pass
+ * (include/btrapz_hip.h, btrapz_options.elastic; no reference counterpart -- the
+ * reference's behaviour it stands in for is the acceptance of OSQP's status 2,
+ * solve_3d.cc:1251-1253): every inequality row elastic, l <= a'x - d <= u, with
+ * sum d^2 / (2 delta) added to the objective; equality rows stay exact. */
+int orc_elastic_solve(const orc_qp *qp, double delta, double eps, int max_iter,
+                      double *x, double *y, orc_info *info);
+
 /* Unscaled KKT residuals of (x,y): stationarity inf-norm, primal violation,
  * complementarity; res[0..2]. */
 void orc_kkt_residuals(const orc_qp *qp, const double *x, const double *y,

@@ -126,6 +126,9 @@ def lib():
         L.orc_ipm_solve.argtypes = [C.POINTER(Qp), C.c_double, C.c_int, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double), C.POINTER(Info)]
         L.orc_ipm_solve.restype = C.c_int
+        L.orc_elastic_solve.argtypes = [C.POINTER(Qp), C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double), C.POINTER(Info)]
+        L.orc_elastic_solve.restype = C.c_int
         L.orc_kkt_residuals.argtypes = [C.POINTER(Qp), C.POINTER(C.c_double),
                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_sample.argtypes = [C.c_int, C.POINTER(Cube), C.c_double, C.POINTER(C.c_double),
@@ -274,6 +277,16 @@ class AssembledQp:
         lib().orc_ipm_solve(C.byref(self.raw), eps, max_iter, _dp(x), _dp(y), C.byref(info))
         return x, y, info
 
+    def solve_elastic(self, delta=1e-8, eps=1e-9, max_iter=120):
+        """Least-violation solution of the rescue pass (orc_elastic_solve): x, y, info, largest row violation."""
+        x = np.zeros(self.n); y = np.zeros(self.m); info = Info()
+        lib().orc_elastic_solve(C.byref(self.raw), float(delta), eps, max_iter, _dp(x), _dp(y), C.byref(info))
+        _, A = self.dense()
+        Ax = A @ x
+        ineq = (self.u - self.l) > 1e-12
+        viol = np.abs(Ax - np.clip(Ax, self.l, self.u))[ineq].max() if ineq.any() else 0.0
+        return x, y, info, float(viol)
+
     def kkt(self, x, y):
         res = np.zeros(3)
         x = np.ascontiguousarray(x); y = np.ascontiguousarray(y)
@@ -285,6 +298,26 @@ class AssembledQp:
             lib().orc_qp_free(C.byref(self.raw))
         except Exception:
             pass
+
+
+class DenseQp(AssembledQp):
+    """A general QP given as dense numpy arrays (tests of the oracle's own solvers)."""
+
+    def __init__(self, P, q, A, l, u):
+        import scipy.sparse as sp
+        Pu = sp.csc_matrix(np.triu(P)); Ac = sp.csc_matrix(A)
+        Pu.sort_indices(); Ac.sort_indices()
+        self.n, self.m = len(q), len(l)
+        ll = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        self.P_p, self.P_i, self.P_x = ll(Pu.indptr), ll(Pu.indices), np.ascontiguousarray(Pu.data, dtype=np.float64)
+        self.A_p, self.A_i, self.A_x = ll(Ac.indptr), ll(Ac.indices), np.ascontiguousarray(Ac.data, dtype=np.float64)
+        self.q, self.l, self.u = [np.ascontiguousarray(v, dtype=np.float64) for v in (q, l, u)]
+        lp = lambda a: a.ctypes.data_as(C.POINTER(C.c_longlong))
+        self.raw = Qp(self.n, self.m, lp(self.P_p), lp(self.P_i), _dp(self.P_x), len(self.P_x), lp(self.A_p), lp(self.A_i),
+                      _dp(self.A_x), len(self.A_x), _dp(self.q), _dp(self.l), _dp(self.u))
+
+    def __del__(self):   # the arrays belong to numpy
+        pass
 
 
 def sample(cubes, delta, x, init_s, init_l, cap=4096):

@@ -50,6 +50,9 @@ struct KernelArgs {
   double *lam_out;          // same layout, multipliers at the end of this solve
   double mu0, smin;         // lambda = lam0 + mu0 / s , s = max(gap, smin)
   int bucket_S;             // 0: the bucket id IS the segment count (ragged); else buckets are hint classes, S = bucket_S
+  // rescue pass (btrapz_options.elastic): order = [2][B] per-axis lists, cand_prefix / wave_prefix = [2][198] tables
+  double elastic_delta;     // penalty d^2 / (2 delta) on the relaxation d of every inequality row
+  double elastic_tol;       // largest row violation still reported as BTRAPZ_SOLVED_INACCURATE
 };
 
 struct CorridorArgs {
@@ -78,6 +81,11 @@ __global__ void ipm_solve_kernel(const KernelArgs a, const double *__restrict__ 
 __global__ void ipm_solve_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);       // through a.order
 __global__ void ipm_solve_warm_kernel(const KernelArgs a, const double *__restrict__ mqm);          // + btrapz_warm
 __global__ void ipm_solve_warm_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);
+__global__ void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm);       // rescue pass
+__global__ void rescue_keys_kernel(int B, int S, const int *seg_count, const int *axis_status, int *keys, int all);
+__global__ void rescue_init_kernel(int B, int S, const int *seg_count, double *axis_obj, int *axis_status, int *axis_iters);
+struct MqmWeights { double w[2][4]; };   // [axis][ref, dref, acc, jerk]
+__global__ void mqm_table_kernel(MqmWeights w, double *out);
 __global__ void finalize_kernel(int B, const double *axis_obj, const int *axis_status, const int *axis_iters,
                                 double *cost, int *status, int *iters);
 __global__ void argmin_kernel(int group, long long index_base, const double *cost, long long *best_idx,
@@ -89,4 +97,7 @@ __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, doubl
                               double *out, int *npoints);
 
 }  // namespace btrapz
+
+// library-internal: the HIP device a context lives on
+int btrapz_ctx_device(const btrapz_ctx *ctx);
 #endif

@@ -31,6 +31,14 @@ using namespace btrapz;
 // 21.5 iterations on average; (10, 6) 0 lost, 19.5; (8, 5) 3 lost; (8, 4) 18 lost; (6, 3) 87 lost.
 #define BTRAPZ_STALL_START 10
 #define BTRAPZ_STALL_LENGTH 6
+// Rescue pass (btrapz_options.elastic): penalty parameter of the relaxed rows and the violation still accepted.
+// delta: the relaxed solution is within delta * |multipliers| (1e2..1e4 here) of the least-violation limit; 1e-8 keeps
+// that below 1e-4 and the interior-point method still converges in 25-40 iterations (1e-10: 40+, scores near 1e-7).
+// tol: the reference accepted an iterate that violates acceleration rows by 0.49 on src/c7.txt (oracle OSQP port, status
+// 2); the least-squares violation of the c7 family is 0.09 (trapezoid) / 0.02 (cuboid), that of a grossly infeasible
+// input such as src/c_road_s1_2.txt is 15.
+#define BTRAPZ_DEFAULT_ELASTIC_DELTA 1e-8
+#define BTRAPZ_DEFAULT_ELASTIC_TOL 0.5
 
 struct btrapz_ctx {
   int device = 0;
@@ -45,6 +53,12 @@ struct btrapz_ctx {
   int *d_order = nullptr; size_t order_cap = 0;
   int *d_meta = nullptr;            // [198] histogram/cand_prefix, wave_prefix, cursors
   int *d_retry = nullptr; size_t retry_cap = 0;   // corridor stage: [0] count, [1..] candidates of the retry pass
+  // rescue pass (btrapz_options.elastic): keys [2][B], per-axis candidate lists [2][B], bucket tables [2][198]
+  // The workspaces above serve one launch sequence at a time.  Launches of one context issued on DIFFERENT streams are
+  // ordered behind each other with this event (recorded after every sequence, waited for when the stream changes).
+  hipEvent_t ws_free = nullptr; hipStream_t ws_stream = nullptr; bool ws_used = false;
+  int *d_rescue = nullptr; size_t rescue_cap = 0;
+  int *d_rescue_meta = nullptr;
   // staging for the host-pointer wrapper
   double *d_stage = nullptr; size_t stage_cap = 0;
   int *d_istage = nullptr; size_t istage_cap = 0;
@@ -59,33 +73,7 @@ struct btrapz_ctx {
     }                                                                                         \
   } while (0)
 
-// M' pQp_d M, solve_3d.cc:87-143 (batch-invariant: depends on the weights only).
-static void build_mqm(const double w[4], double out[4][21]) {
-  static const double M[6][6] = {{1, 0, 0, 0, 0, 0},      {-5, 5, 0, 0, 0, 0},      {10, -20, 10, 0, 0, 0},
-                                 {-10, 30, -30, 10, 0, 0}, {5, -20, 30, -20, 5, 0}, {-1, 5, -10, 10, -5, 1}};
-  for (int d = 0; d < 4; d++) {
-    double pq[6][6] = {};
-    for (int i = d; i < 6; i++)
-      for (int j = d; j < 6; j++) {
-        double num = w[d];
-        for (int r = 0; r < d; r++) num *= double((i - r) * (j - r));
-        pq[i][j] = num / double(i + j - 2 * d + 1);
-      }
-    double T[6][6];
-    for (int i = 0; i < 6; i++)
-      for (int j = 0; j < 6; j++) {
-        double s = 0;
-        for (int r = 0; r < 6; r++) s += M[r][i] * pq[r][j];
-        T[i][j] = s;
-      }
-    for (int j = 0; j < 6; j++)
-      for (int i = 0; i <= j; i++) {
-        double s = 0;
-        for (int r = 0; r < 6; r++) s += T[i][r] * M[r][j];
-        out[d][j * (j + 1) / 2 + i] = s;
-      }
-  }
-}
+int btrapz_ctx_device(const btrapz_ctx *c) { return c ? c->device : 0; }
 
 BTRAPZ_EXPORT int btrapz_device_count(void) {
   int n = 0;
@@ -102,6 +90,7 @@ BTRAPZ_EXPORT int btrapz_create(btrapz_ctx **out, int device) {
   btrapz_ctx *c = new btrapz_ctx();
   c->device = device;
   if (hipMalloc(&c->d_mqm, sizeof(double) * 168) != hipSuccess) { delete c; return BTRAPZ_ENOMEM; }
+  if (hipEventCreateWithFlags(&c->ws_free, hipEventDisableTiming) != hipSuccess) { (void)hipFree(c->d_mqm); delete c; return BTRAPZ_ENOMEM; }
   *out = c;
   return BTRAPZ_OK;
 }
@@ -112,6 +101,8 @@ BTRAPZ_EXPORT int btrapz_destroy(btrapz_ctx *c) {
   (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters);
   (void)hipFree(c->d_mqm); (void)hipFree(c->d_stage); (void)hipFree(c->d_istage);
   (void)hipFree(c->d_order); (void)hipFree(c->d_meta); (void)hipFree(c->d_retry);
+  (void)hipFree(c->d_rescue); (void)hipFree(c->d_rescue_meta);
+  if (c->ws_free) (void)hipEventDestroy(c->ws_free);
   delete c;
   return BTRAPZ_OK;
 }
@@ -141,16 +132,19 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   }
   hipStream_t stream = (hipStream_t)stream_;
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->ws_used && stream != c->ws_stream) HIPCHK(c, hipStreamWaitEvent(stream, c->ws_free, 0));
   int rc = ensure_axis_ws(c, 2 * (size_t)B);
   if (rc != BTRAPZ_OK) return rc;
   // batch-invariant M'QM table: rebuilt only when the weights change
   double wkey[8];
   memcpy(wkey, sh->w_s, sizeof(double) * 4); memcpy(wkey + 4, sh->w_l, sizeof(double) * 4);
   if (memcmp(wkey, c->h_mqm_w, sizeof(wkey)) != 0) {
-    double tab[2][4][21];
-    build_mqm(sh->w_s, tab[0]); build_mqm(sh->w_l, tab[1]);
-    HIPCHK(c, hipMemcpyAsync(c->d_mqm, tab, sizeof(tab), hipMemcpyHostToDevice, stream));
-    HIPCHK(c, hipStreamSynchronize(stream));  // tab is a stack buffer
+    // built on the device, in stream order: no host buffer to keep alive, no synchronisation, and a launch that is
+    // still reading the previous table (same stream, or ordered by the event above) finishes first
+    MqmWeights mw;
+    memcpy(mw.w[0], sh->w_s, sizeof(double) * 4); memcpy(mw.w[1], sh->w_l, sizeof(double) * 4);
+    hipLaunchKernelGGL(mqm_table_kernel, dim3(1), dim3(192), 0, stream, mw, c->d_mqm);
+    HIPCHK(c, hipGetLastError());
     memcpy(c->h_mqm_w, wkey, sizeof(wkey));
   }
   KernelArgs a;
@@ -174,6 +168,10 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   a.x0 = warm ? warm->x0 : nullptr; a.lam0 = warm ? warm->lam0 : nullptr; a.lam_out = warm ? warm->lam_out : nullptr;
   a.mu0 = (warm && warm->mu0 > 0) ? warm->mu0 : 1e-4;
   a.smin = (warm && warm->smin > 0) ? warm->smin : 1e-2;
+  const int elastic = opt ? opt->elastic : 0;
+  if (elastic < 0 || elastic > 2) { c->err = "invalid argument: btrapz_options.elastic"; return BTRAPZ_EINVAL; }
+  a.elastic_delta = (opt && opt->elastic_delta > 0) ? opt->elastic_delta : BTRAPZ_DEFAULT_ELASTIC_DELTA;
+  a.elastic_tol = (opt && opt->elastic_tol > 0) ? opt->elastic_tol : BTRAPZ_DEFAULT_ELASTIC_TOL;
   unsigned blocks;
   const int *hint = (warm && !seg_count) ? warm->hint : nullptr;   // uniform batches only
   a.bucket_S = 0;
@@ -205,11 +203,53 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   const bool warm_kernel = a.x0 || a.lam0 || a.lam_out;   // (a hint alone only reorders the candidates)
   auto kernel = warm_kernel ? (a.order ? ipm_solve_warm_ordered_kernel : ipm_solve_warm_kernel)
                             : (a.order ? ipm_solve_ordered_kernel : ipm_solve_kernel);
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
-  HIPCHK(c, hipGetLastError());
+  if (elastic != 2) {
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
+    HIPCHK(c, hipGetLastError());
+  }
+  if (elastic) {
+    // Rescue pass: the axis problems that stalled (elastic == 2: all of them) are listed per axis, bucketed by
+    // segment count with the machinery of the ragged batches, and solved again with elastic rows.  The lists are
+    // built on the device; the launch is sized for the worst case and its unused wavefronts leave at once.
+    if (2 * (size_t)B > c->rescue_cap) {
+      (void)hipFree(c->d_rescue); c->d_rescue = nullptr; c->rescue_cap = 0;
+      HIPCHK(c, hipMalloc(&c->d_rescue, sizeof(int) * 4 * (size_t)B));
+      c->rescue_cap = 2 * (size_t)B;
+    }
+    if (!c->d_rescue_meta) HIPCHK(c, hipMalloc(&c->d_rescue_meta, sizeof(int) * 2 * 198));
+    int *keys = c->d_rescue, *lists = c->d_rescue + 2 * (size_t)B;
+    const unsigned nb = (unsigned)((B + 255) / 256);
+    if (elastic == 2)
+      hipLaunchKernelGGL(rescue_init_kernel, dim3(nb), dim3(256), 0, stream, B, S, seg_count, c->d_axis_obj,
+                         c->d_axis_status, c->d_axis_iters);
+    hipLaunchKernelGGL(rescue_keys_kernel, dim3(nb), dim3(256), 0, stream, B, S, seg_count, (const int *)c->d_axis_status,
+                       keys, elastic == 2 ? 1 : 0);
+    HIPCHK(c, hipMemsetAsync(c->d_rescue_meta, 0, sizeof(int) * 2 * 198, stream));
+    for (int ax = 0; ax < 2; ax++) {
+      int *meta = c->d_rescue_meta + ax * 198;
+      const int *k = keys + (size_t)ax * B;
+      hipLaunchKernelGGL(bucket_hist_kernel, dim3(nb), dim3(256), 0, stream, B, S, k, meta, 0);
+      hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(64), 0, stream, meta, 0);
+      hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nb), dim3(256), 0, stream, B, S, k, meta, lists + (size_t)ax * B,
+                         (double *)nullptr, (int *)nullptr, (int *)nullptr, 0);
+    }
+    HIPCHK(c, hipGetLastError());
+    KernelArgs e = a;
+    e.order = lists; e.seg_count = seg_count; e.cand_prefix = c->d_rescue_meta; e.wave_prefix = c->d_rescue_meta + 66;
+    e.bucket_S = 0; e.x0 = nullptr; e.lam0 = nullptr; e.lam_out = nullptr;
+    e.max_iter = a.max_iter < 80 ? 80 : a.max_iter;   // least-violation problems take 25-40 iterations
+    e.tau_iters = 0;                                  // conservative step rule throughout
+    e.stall_start = 2 * BTRAPZ_STALL_START; e.stall_len = 2 * BTRAPZ_STALL_LENGTH;
+    const int smax = seg_count ? (S < 64 ? S : 64) : S;
+    const unsigned eblocks = 2u * (unsigned)(B / (64 / smax) + 65);
+    hipLaunchKernelGGL(ipm_solve_elastic_kernel, dim3(eblocks), dim3(64), 0, stream, e, (const double *)c->d_mqm);
+    HIPCHK(c, hipGetLastError());
+  }
   hipLaunchKernelGGL(finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, B, c->d_axis_obj, c->d_axis_status,
                      c->d_axis_iters, cost, status, iters);
   HIPCHK(c, hipGetLastError());
+  c->ws_stream = stream; c->ws_used = true;
+  HIPCHK(c, hipEventRecord(c->ws_free, stream));
   return BTRAPZ_OK;
 }
 

@@ -195,9 +195,14 @@ __device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gb
 // -----------------------------------------------------------------------------------------
 // WARM = false: the cold-start kernel (bench path).  WARM = true adds the warm start and the cold restart of a
 // group whose guess did not pay off; a separate instantiation, so the cold kernel keeps its register footprint.
-template <bool WARM, bool ORDERED>
+// ELASTIC = true: every inequality row l <= g'x <= u becomes l <= g'x - d <= u with the penalty d^2 / (2 delta) in the
+// objective (the rescue pass of btrapz_options.elastic, see the header).  Eliminating d (d = delta * (lambda_u -
+// lambda_l)) leaves the same iteration with three changes per row: the row value is g'c - delta (lambda_u - lambda_l),
+// the row's weight in the Newton matrix is w / (1 + delta w), and the step of the row value is
+// (g'dc - delta b) / (1 + delta w), b the row's entry of the right-hand side.  delta = 0 is the plain method.
+template <bool WARM, bool ORDERED, bool ELASTIC = false>
 __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double *__restrict__ mqm) {
-  constexpr bool CACHE_RP = !WARM;   // see the main loop
+  constexpr bool CACHE_RP = !WARM && !ELASTIC;   // see the main loop
   __shared__ double lds[L_ROWS][64];
 
   const int lane = threadIdx.x;
@@ -206,16 +211,18 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   int S, pair = (int)(blockIdx.x >> 1), ncand = a.B, cand0 = 0;
   if constexpr (ORDERED) {
     // ragged batch: candidates are bucketed by segment count; find this wave's bucket (wave-uniform)
-    if (pair >= a.wave_prefix[65]) return;
+    // (rescue pass: one set of tables and one candidate list per axis, the stalled axis problems only)
+    const int *wave_prefix = a.wave_prefix + (ELASTIC ? axis * 198 : 0), *cand_prefix = a.cand_prefix + (ELASTIC ? axis * 198 : 0);
+    if (pair >= wave_prefix[65]) return;
     // slot s with wave_prefix[s] <= pair < wave_prefix[s + 1] (empty buckets repeat their prefix): binary search,
     // six dependent scalar loads instead of up to 63
     int s = 1, hi = 65;
     while (hi - s > 1) {
       const int mid = (s + hi) >> 1;
-      if (a.wave_prefix[mid] <= pair) s = mid; else hi = mid;
+      if (wave_prefix[mid] <= pair) s = mid; else hi = mid;
     }
     S = a.bucket_S ? a.bucket_S : 65 - s;   // slot s holds key 65 - s (longest first); hint mode: classes of a uniform batch
-    pair -= a.wave_prefix[s]; cand0 = a.cand_prefix[s]; ncand = a.cand_prefix[s + 1] - cand0;
+    pair -= wave_prefix[s]; cand0 = cand_prefix[s] + (ELASTIC ? axis * a.B : 0); ncand = cand_prefix[s + 1] - cand_prefix[s];
   } else {
     S = a.S;
   }
@@ -398,12 +405,19 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   double Pk[21];
   LOAD_P(Pk)
   const double eps = a.eps;
+  [[maybe_unused]] const double edelta = ELASTIC ? a.elastic_delta : 0.0;
   const double inv_m = 1.0 / (36.0 * (double)S);
   double best_score = 1e300, Xb[3] = {X[0], X[1], X[2]};
   int best_it = 0, iters = 0;
   bool done = !valid || infeasible_bounds;
+  // Warm-start instantiations: when one group of the wavefront restarts cold, the others lose that pass of the loop
+  // (wave-uniform `continue` below).  Their iteration count must not see it, or a candidate's stall / step-rule /
+  // iteration bookkeeping would depend on which candidates share its wavefront: every test below uses the group's own
+  // count `eit` (= iter in the cold instantiations).
+  [[maybe_unused]] int skipped = 0;
 
   for (int iter = 0; iter < a.max_iter; ++iter) {
+    const int eit = WARM ? iter - skipped : iter;
     // ---- 1. control points of this segment, rows, residuals, gradient ----
     // Row residuals r_l = G c - s_l - l, r_u = G c + s_u - u: constant within an iteration and needed by six row
     // loops.  Cached (36 doubles; the allocator parks them in AGPRs) they save ~100 instructions per row loop:
@@ -417,7 +431,9 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       V_apply(nm, X, c[3], c[4], c[5]);
       UNROLL for (int i = 0; i < 6; i++) gc[i] = 0.0;
       FOR_ROWS(r)
-        const double gcr = row_dot<r>(c, t), ll = LL(r), lu = LU(r);
+        const double ll = LL(r), lu = LU(r);
+        double gcr = row_dot<r>(c, t);
+        if constexpr (ELASTIC) gcr -= edelta * (lu - ll);
         const double rpl = gcr - sl[r] - LO(r), rpu = gcr + su[r] - UP(r);
         if constexpr (CACHE_RP) { rpl_[CACHE_RP ? r : 0] = rpl; rpu_[CACHE_RP ? r : 0] = rpu; }
         rp_part = fmax(rp_part, fmax(fabs(rpl), fabs(rpu)));
@@ -456,8 +472,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     const double score = fmax(fmax(rd_eff / (1.0 + qn), rr.c / (1.0 + bnorm)), mu);
     bool restart_now = false;
     if (!done) {
-      iters = iter;
-      if (score < best_score) { best_score = score; best_it = iter; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
+      iters = eit;
+      if (score < best_score) { best_score = score; best_it = eit; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
 #ifndef ABL_FIXED
       // stop: converged; at the round-off floor (best < 1e-5, 3 iterations without progress); diverging or
       // infeasible (stall_len iterations without progress after the first stall_start); not finite.  A warm-started group
@@ -465,9 +481,9 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // needs about 5, a cold start 8-14; below 1e-4 the method is in its fast final phase), or is still running
       // after 24, is restarted once from the cold start: a bad guess must neither turn a solvable candidate
       // into a failure nor cost more than a bounded number of iterations.
-      const bool stalled = (iter - it0 >= a.stall_start && iter - best_it >= a.stall_len) || !(score < 1e299);
-      if (score < eps || (best_score < 1e-5 && iter - best_it >= 3)) done = true;
-      else if (WARM && !restarted && (stalled || (iter - it0 >= 12 && best_score > 1e-4) || iter - it0 >= 24)) restart_now = true;
+      const bool stalled = (eit - it0 >= a.stall_start && eit - best_it >= a.stall_len) || !(score < 1e299);
+      if (score < eps || (best_score < 1e-5 && eit - best_it >= 3)) done = true;
+      else if (WARM && !restarted && (stalled || (eit - it0 >= 12 && best_score > 1e-4) || eit - it0 >= 24)) restart_now = true;
       else if (stalled) done = true;
 #endif
     }
@@ -477,8 +493,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // restarts as a whole (the score is group-uniform), so the DPP reads inside cold_start stay in the group.
       if (restart_now) {
         cold_start();
-        best_score = 1e300; best_it = iter + 1; it0 = iter + 1; restarted = true;
+        best_score = 1e300; best_it = eit + 1; it0 = eit + 1; restarted = true;
         Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2];
+      } else {
+        ++skipped;   // this group did not take a step in this pass
       }
       continue;
     }
@@ -505,11 +523,21 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         const double ll = LL(r), lu = LU(r);
         lds[L_ISL + r][lane] = isl; lds[L_ISU + r][lane] = isu;
         const double wl = ll * isl, wu = lu * isu;
-        row_outer<r>(wl + wu, t2, H);
         double rpl, rpu;
         if constexpr (CACHE_RP) { rpl = rpl_[CACHE_RP ? r : 0]; rpu = rpu_[CACHE_RP ? r : 0]; }
-        else { const double gcr = row_dot<r>(c, t); rpl = gcr - sl[r] - LO(r); rpu = gcr + su[r] - UP(r); }
-        row_scatter<r>(wl * (sl[r] + rpl) - wu * (su[r] - rpu), t, hp);
+        else {
+          double gcr = row_dot<r>(c, t);
+          if constexpr (ELASTIC) gcr -= edelta * (lu - ll);
+          rpl = gcr - sl[r] - LO(r); rpu = gcr + su[r] - UP(r);
+        }
+        if constexpr (ELASTIC) {
+          const double ef = rcp(1.0 + edelta * (wl + wu));
+          row_outer<r>((wl + wu) * ef, t2, H);
+          row_scatter<r>((wl * (sl[r] + rpl) - wu * (su[r] - rpu)) * ef, t, hp);
+        } else {
+          row_outer<r>(wl + wu, t2, H);
+          row_scatter<r>(wl * (sl[r] + rpl) - wu * (su[r] - rpu), t, hp);
+        }
       END_ROWS
       reduce_rhs(hp, up);
       double w0[3], w1[3], w2[3], col[3], M00[6];
@@ -663,7 +691,13 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       }                                                                                             \
       double rpl, rpu;                                                                              \
       if constexpr (CACHE_RP) { rpl = rpl_[r < 18 && CACHE_RP ? r : 0]; rpu = rpu_[r < 18 && CACHE_RP ? r : 0]; }      \
-      else { const double gcr = row_dot<r>(c, t); rpl = gcr - sl[r] - LO(r); rpu = gcr + su[r] - UP(r); }
+      else {                                                                                        \
+        double gcr = row_dot<r>(c, t);                                                              \
+        if constexpr (ELASTIC) gcr -= edelta * (lu - ll);                                           \
+        rpl = gcr - sl[r] - LO(r); rpu = gcr + su[r] - UP(r);                                       \
+      }
+    // elastic rows: the step of the row value, g' dc -> (g' dc - delta b) / (1 + delta w)
+#define ROW_STEP(gd, b) (ELASTIC ? ((gd) - edelta * (b)) * rcp(1.0 + edelta * (ll * isl + lu * isu)) : (gd))
 
     double dca[6], dX[3];
     double sigma_mu;
@@ -678,7 +712,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       ROW_PREFETCH();
       FOR_ROWS(r)
         ROW_BASE(r)
-        const double gd = row_dot<r>(dca, t);
+        const double gd = ROW_STEP(row_dot<r>(dca, t), (ll - lu) + (ll * isl) * rpl + (lu * isu) * rpu);
         const double dsl = gd + rpl, dsu = -gd - rpu;
         const double ql = dsl * isl, qu = dsu * isu;
         qmin = fmin(qmin, fmin(ql, qu)); qmax = fmax(qmax, fmax(ql, qu));
@@ -695,7 +729,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     {
       // corrector.  rc = s*lambda + ds_aff*dlambda_aff - sigma*mu , dlambda_aff = -lambda (1 + ds_aff/s)
 #define ROW_CORR(r)                                                                               \
-      const double ga = row_dot<r>(dca, t);                                                         \
+      const double ga = ROW_STEP(row_dot<r>(dca, t), (ll - lu) + (ll * isl) * rpl + (lu * isu) * rpu); \
       const double dsa = ga + rpl, dua = -ga - rpu;                                                 \
       const double rcl = __builtin_fma(sl[r], ll, -sigma_mu) - (ll * dsa) * (1.0 + dsa * isl);      \
       const double rcu = __builtin_fma(su[r], lu, -sigma_mu) - (lu * dua) * (1.0 + dua * isu);      \
@@ -709,7 +743,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         ROW_BASE(r)
         ROW_CORR(r)
         el_[r] = el; eu_[r] = eu;
-        row_scatter<r>((el - eu) + (wl * rpl + wu * rpu), t, h);
+        if constexpr (ELASTIC) row_scatter<r>(((el - eu) + (wl * rpl + wu * rpu)) * rcp(1.0 + edelta * (wl + wu)), t, h);
+        else row_scatter<r>((el - eu) + (wl * rpl + wu * rpu), t, h);
       END_ROWS
       solve_dc(h, dX, dc);
       // step to the boundary: ratios -ds/s and -dlambda/lambda (seed reciprocal is enough here)
@@ -718,7 +753,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       ROW_PREFETCH();
       FOR_ROWS(r)
         ROW_BASE(r)
-        const double gd = row_dot<r>(dc, t);
+        const double gd = ROW_STEP(row_dot<r>(dc, t), (el_[r] - eu_[r]) + (ll * isl) * rpl + (lu * isu) * rpu);
         const double dsl = gd + rpl, dsu = -gd - rpu;
         const double dll = -el_[r] - (ll * isl) * dsl, dlu = -eu_[r] - (lu * isu) * dsu;
         pr = fmax(pr, fmax(-dsl * isl, -dsu * isu));
@@ -728,7 +763,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // m = largest ratio -ds/s, -dlambda/lambda: the boundary is 1/m away.  A long step may go almost all the way
       // (fewer iterations); a blocked one keeps 0.5 % distance, or the iterates lose centrality and crawl.
       const double m_ = fmax(ra.b, ra.c);
-      const double tau = (m_ * a.tau_thr <= 1.0 && iter - it0 < a.tau_iters) ? a.tau : fmin(a.tau, 0.995);
+      const double tau = (m_ * a.tau_thr <= 1.0 && eit - it0 < a.tau_iters) ? a.tau : fmin(a.tau, 0.995);
       const double alpha = fmin(1.0, tau / fmax(m_, tau));
       // a finished group keeps its state (a branch, not alpha = 0: 0 * inf would poison it); a step that is
       // not finite is not taken either -- the score of the unchanged iterate then stalls and the group stops
@@ -738,7 +773,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         ROW_PREFETCH();
         FOR_ROWS(r)
           ROW_BASE(r)
-          const double gd = row_dot<r>(dc, t);
+          const double gd = ROW_STEP(row_dot<r>(dc, t), (el_[r] - eu_[r]) + (ll * isl) * rpl + (lu * isu) * rpu);
           const double dsl = gd + rpl, dsu = -gd - rpu;
           sl[r] += alpha * dsl; su[r] += alpha * dsu;
           LL(r) = ll + alpha * (-el_[r] - (ll * isl) * dsl); LU(r) = lu + alpha * (-eu_[r] - (lu * isu) * dsu);
@@ -747,6 +782,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 #undef ROW_CORR
     }
 #undef ROW_BASE
+#undef ROW_STEP
 #undef ROW_PREFETCH
   }
 
@@ -769,7 +805,15 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       UNROLL for (int j = 0; j < 6; j++) s += HSYM(Pm, i, j) * c[j];
       obj += c[i] * (0.5 * s + q[i]);
     }
-    const Red4 ro = group_reduce<0, 1, 1, 1>(lds, lane, gbase, k, S, obj, 0.0, 0.0, 0.0);
+    // rescue pass: largest violation of an original row by the returned control points
+    double viol = 0.0;
+    if constexpr (ELASTIC) {
+      FOR_ROWS(r)
+        const double gcr = row_dot<r>(c, t);
+        viol = fmax(viol, fmax(LO(r) - gcr, gcr - UP(r)));
+      END_ROWS
+    }
+    const Red4 ro = group_reduce<0, 1, 1, 1>(lds, lane, gbase, k, S, obj, viol, 0.0, 0.0);
     if (valid) {
       // control points in the reference's order: s axis (6 S), then l axis (6 S); rows are 12*seg_stride apart
       double *dst = a.ctrl + (size_t)b * 12 * a.seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
@@ -780,9 +824,14 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         else if (best_score < 1e-7) st = BTRAPZ_SOLVED;
         else if (best_score < 1e-5) st = BTRAPZ_SOLVED_INACCURATE;
         else st = BTRAPZ_MAX_ITER_REACHED;
+        if constexpr (ELASTIC) {
+          // converged on the relaxed problem: feasible after all (rows kept to 1e-7) -> as solved; least violation
+          // within the caller's tolerance -> the reference's "solved inaccurate"; beyond it -> infeasible
+          if (st > 0 && ro.b > 1e-7 * (1.0 + bnorm)) st = ro.b <= a.elastic_tol ? BTRAPZ_SOLVED_INACCURATE : BTRAPZ_PRIMAL_INFEASIBLE;
+        }
         a.axis_obj[prob] = ro.a;
         a.axis_status[prob] = st;
-        a.axis_iters[prob] = iters;
+        a.axis_iters[prob] = ELASTIC ? iters + a.axis_iters[prob] + 1 : iters;   // rescue: on top of the first attempt's
       }
     }
   }
@@ -801,6 +850,57 @@ __global__ __launch_bounds__(64) void ipm_solve_warm_kernel(const KernelArgs a, 
 }
 __global__ __launch_bounds__(64) void ipm_solve_warm_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   ipm_solve_body<true, true>(a, mqm);
+}
+// Rescue pass (btrapz_options.elastic): the stalled axis problems, listed per axis, with elastic rows.
+__global__ __launch_bounds__(64) void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  ipm_solve_body<false, true, true>(a, mqm);
+}
+// keys of the rescue lists: key[axis][b] = segment count of candidate b when that axis problem stalled, else 0
+__global__ void rescue_keys_kernel(int B, int S, const int *seg_count, const int *axis_status, int *keys, int all) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int s = seg_count ? seg_count[b] : S;
+  const bool usable = s >= 1 && s <= 64 && s <= S;
+  keys[b] = usable && (all || axis_status[2 * b] == BTRAPZ_MAX_ITER_REACHED) ? s : 0;
+  keys[B + b] = usable && (all || axis_status[2 * b + 1] == BTRAPZ_MAX_ITER_REACHED) ? s : 0;
+}
+// elastic solve of every candidate without a first attempt: per-axis records start empty (iters -1: the rescue kernel
+// adds its own count + 1), candidates without a usable corridor are marked as the bucket kernel of a ragged solve does
+__global__ void rescue_init_kernel(int B, int S, const int *seg_count, double *axis_obj, int *axis_status, int *axis_iters) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int s = seg_count ? seg_count[b] : S;
+  const bool usable = s >= 1 && s <= 64 && s <= S;
+  for (int ax = 0; ax < 2; ax++) {
+    axis_obj[2 * b + ax] = 0.0; axis_status[2 * b + ax] = usable ? BTRAPZ_MAX_ITER_REACHED : BTRAPZ_NO_CORRIDOR;
+    axis_iters[2 * b + ax] = usable ? -1 : 0;
+  }
+}
+
+// ---- batch-invariant table M' pQp_d M (solve_3d.cc:87-143), built in stream order whenever the weights change --------
+// thread = (axis, derivative d, packed upper-triangle entry): out[axis][d][SYM(i, j)].  pQp_d(a, b) = w_d * prod_{r<d}
+// (a - r)(b - r) / (a + b - 2d + 1) for a, b >= d (:87-113); M = Bernstein -> monomial (:122-127).
+__global__ void mqm_table_kernel(MqmWeights w, double *out) {
+  const int id = threadIdx.x;
+  if (id >= 168) return;
+  const int axis = id / 84, d = (id % 84) / 21, e = id % 21;
+  int j = 0;
+  while ((j + 1) * (j + 2) / 2 <= e) ++j;
+  const int i = e - j * (j + 1) / 2;
+  const double M[6][6] = {{1, 0, 0, 0, 0, 0},      {-5, 5, 0, 0, 0, 0},      {10, -20, 10, 0, 0, 0},
+                          {-10, 30, -30, 10, 0, 0}, {5, -20, 30, -20, 5, 0}, {-1, 5, -10, 10, -5, 1}};
+  const double wd = w.w[axis][d];
+  double acc = 0.0;
+  for (int a = d; a < 6; a++) {
+    double t = 0.0;   // (M' pQp)(i, b) summed against M(b, j)
+    for (int b = d; b < 6; b++) {
+      double num = wd;
+      for (int r = 0; r < d; r++) num *= (double)((a - r) * (b - r));
+      t += num / (double)(a + b - 2 * d + 1) * M[b][j];
+    }
+    acc += M[a][i] * t;
+  }
+  out[id] = acc;
 }
 
 __global__ void finalize_kernel(int B, const double *axis_obj, const int *axis_status, const int *axis_iters,

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(int B, int seg_stri
   if (i < B) {
     s = fixed_S ? hint_class(seg_count[i]) : seg_count[i];
     usable = s >= 1 && s <= 64 && (fixed_S || s <= seg_stride);
-    if (!usable) {  // no usable corridor: the reference's find_traj fails here (empty selection / CHECK)
+    if (!usable && axis_status) {  // no usable corridor: the reference's find_traj fails here (empty selection / CHECK)
       axis_obj[2 * i] = 0.0; axis_obj[2 * i + 1] = 0.0;
       axis_status[2 * i] = BTRAPZ_NO_CORRIDOR; axis_status[2 * i + 1] = BTRAPZ_NO_CORRIDOR;
       axis_iters[2 * i] = 0; axis_iters[2 * i + 1] = 0;

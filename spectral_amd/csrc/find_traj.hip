@@ -48,6 +48,15 @@ btrapz_ctx *shared_ctx() {
 
 bool verbose() { const char *v = getenv("BTRAPZ_VERBOSE"); return v && *v && *v != '0'; }
 
+// BTRAPZ_ELASTIC=0 turns the rescue pass of find_traj off; BTRAPZ_ELASTIC_TOL overrides btrapz_options.elastic_tol.
+struct ElasticEnv { bool on; double tol; };
+ElasticEnv elastic_env() {
+  const char *e = getenv("BTRAPZ_ELASTIC"), *t = getenv("BTRAPZ_ELASTIC_TOL");
+  ElasticEnv r = {!(e && *e == '0'), 0.0};
+  if (t) { const double v = atof(t); if (v > 0) r.tol = v; }
+  return r;
+}
+
 int clampi(int i, int hi) { return i < 0 ? 0 : (i > hi ? hi : i); }
 
 // a_cost of trp_wrapper.cpp:207-286 / cub_wrapper.cpp:201-262.  Reads of x_ref[i] past N
@@ -188,6 +197,8 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   // A btrapz_ctx is not thread-safe (its per-axis workspace is shared by every launch): concurrent callers of
   // find_traj queue here.  The reference's own calls only ever race on the output file.
   std::lock_guard<std::mutex> run_lock(g_run_mutex);
+  // the scratch block below must live on the context's device whatever the calling thread's current device is
+  if (hipSetDevice(btrapz_ctx_device(ctx)) != hipSuccess) return FAIL;
   // One persistent device block and one pinned-size host block, laid out as doubles:
   //   in : seg[17 S] init[6] ref_end[2] dl[10] sel[1]            (one H2D copy)
   //   out: cost[1] status,iters[1] np[1] ctrl[12 S] traj[6 max_points]   (one D2H copy)
@@ -214,19 +225,29 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   const long long sel0 = 0;
   memcpy(&h_in[n_in - 1], &sel0, 8);
   if (hipMemcpy(d_in, h_in.data(), n_in * 8, hipMemcpyHostToDevice) != hipSuccess) return FAIL;
-  if (btrapz_solve_batch_device(ctx, &sh, nullptr, 1, S, d_seg, d_init, d_re, d_dl, d_ctrl, d_cost, d_status, d_status + 1,
-                                nullptr) != BTRAPZ_OK ||
-      btrapz_sample_device(ctx, 1, S, in.delta, d_seg, d_init, d_ctrl, 1, d_sel, max_points, d_traj, d_np, nullptr) !=
-          BTRAPZ_OK) {
-    fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
-    return FAIL;
-  }
-  // (a blocking copy on the null stream waits for the two launches before it)
-  if (hipMemcpy(h_out.data(), d_out_blk, n_out * 8, hipMemcpyDeviceToHost) != hipSuccess) return FAIL;
   int h_status[2] = {0, 0}, h_np = 0;
-  double h_cost = h_out[0];
-  memcpy(h_status, &h_out[1], 8);
-  memcpy(&h_np, &h_out[2], 4);
+  double h_cost = 0.0;
+  // Second attempt only when the first one stalled (no solution to converge to: a marginally infeasible corridor):
+  // the rescue pass of btrapz_options.elastic, the counterpart of the reference accepting OSQP's status 2.
+  const ElasticEnv el = elastic_env();
+  for (int attempt = 0; attempt < 2; attempt++) {
+    btrapz_options opt = {};
+    opt.elastic = attempt; opt.elastic_tol = el.tol;
+    if (btrapz_solve_batch_device(ctx, &sh, &opt, 1, S, d_seg, d_init, d_re, d_dl, d_ctrl, d_cost, d_status, d_status + 1,
+                                  nullptr) != BTRAPZ_OK ||
+        btrapz_sample_device(ctx, 1, S, in.delta, d_seg, d_init, d_ctrl, 1, d_sel, max_points, d_traj, d_np, nullptr) !=
+            BTRAPZ_OK) {
+      fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
+      return FAIL;
+    }
+    // (a blocking copy on the null stream waits for the launches before it)
+    if (hipMemcpy(h_out.data(), d_out_blk, n_out * 8, hipMemcpyDeviceToHost) != hipSuccess) return FAIL;
+    h_cost = h_out[0];
+    memcpy(h_status, &h_out[1], 8);
+    memcpy(&h_np, &h_out[2], 4);
+    if (h_status[0] != BTRAPZ_MAX_ITER_REACHED || !el.on) break;
+    if (verbose() && attempt == 0) fprintf(stderr, "btrapz: S=%d stalled after %d iterations, rescue pass\n", S, h_status[1]);
+  }
   std::vector<double> out(h_out.begin() + 3 + 12 * S, h_out.end());
   if (verbose()) fprintf(stderr, "btrapz: S=%d status=%d iters=%d obj=%.9g\n", S, h_status[0], h_status[1], h_cost);
   // acceptance: solve_3d.cc:1251-1277

@@ -41,7 +41,14 @@ class CShared(C.Structure):
 
 
 class COptions(C.Structure):
-    _fields_ = [("max_iter", C.c_int), ("eps", C.c_double), ("step_fraction", C.c_double), ("step_threshold", C.c_double)]
+    _fields_ = [("max_iter", C.c_int), ("eps", C.c_double), ("step_fraction", C.c_double), ("step_threshold", C.c_double),
+                ("elastic", C.c_int), ("elastic_tol", C.c_double), ("elastic_delta", C.c_double)]
+
+
+def _options(max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, elastic_delta=0.0):
+    return COptions(int(max_iter), float(eps), float(os.environ.get("BTRAPZ_STEP_FRACTION", "0")),
+                    float(os.environ.get("BTRAPZ_STEP_THRESHOLD", "0")), int(elastic), float(elastic_tol),
+                    float(elastic_delta))
 
 
 class CWarm(C.Structure):
@@ -182,7 +189,7 @@ class Context:
             raise BtrapzError("%s failed (%d): %s" % (what, rc, lib().btrapz_last_error(self._h).decode()))
 
     # ---- host-pointer path (numpy in, numpy out) ------------------------------------------
-    def solve_host(self, batch, shared, max_iter=0, eps=0.0):
+    def solve_host(self, batch, shared, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0):
         B, S = batch.B, batch.S
         seg = np.ascontiguousarray(batch.seg, dtype=np.float64)
         init = np.ascontiguousarray(batch.init, dtype=np.float64)
@@ -191,7 +198,7 @@ class Context:
         assert seg.shape == (L.NUM_SEG_FIELDS, B, S)
         ctrl = np.empty((B, 12 * S)); cost = np.empty(B)
         status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32)
-        sh = CShared.from_shared(shared); opt = COptions(int(max_iter), float(eps), float(os.environ.get("BTRAPZ_STEP_FRACTION", "0")), float(os.environ.get("BTRAPZ_STEP_THRESHOLD", "0")))
+        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         self._check(lib().btrapz_solve_batch_host(self._h, C.byref(sh), C.byref(opt), B, S, p(seg), p(init),
                                                   p(ref_end), p(dlb), p(ctrl), p(cost), p(status), p(iters)),
@@ -200,8 +207,8 @@ class Context:
 
     # ---- device-pointer path (torch tensors only carry the memory) --------------------------
     def solve_device(self, B, S, shared, seg, init, ref_end, dl_bounds, ctrl, cost, status, iters=None,
-                     stream=None, max_iter=0, eps=0.0):
-        sh = CShared.from_shared(shared); opt = COptions(int(max_iter), float(eps), float(os.environ.get("BTRAPZ_STEP_FRACTION", "0")), float(os.environ.get("BTRAPZ_STEP_THRESHOLD", "0")))
+                     stream=None, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0):
+        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self._check(lib().btrapz_solve_batch_device(self._h, C.byref(sh), C.byref(opt), B, S, ptr(seg), ptr(init),
                                                     ptr(ref_end), ptr(dl_bounds), ptr(ctrl), ptr(cost),
@@ -209,8 +216,8 @@ class Context:
                     "btrapz_solve_batch_device")
 
     def solve_ragged_device(self, B, seg_stride, shared, seg, seg_count, init, ref_end, dl_bounds, ctrl, cost,
-                            status, iters=None, stream=None, max_iter=0, eps=0.0):
-        sh = CShared.from_shared(shared); opt = COptions(int(max_iter), float(eps), float(os.environ.get("BTRAPZ_STEP_FRACTION", "0")), float(os.environ.get("BTRAPZ_STEP_THRESHOLD", "0")))
+                            status, iters=None, stream=None, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0):
+        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self._check(lib().btrapz_solve_ragged_device(self._h, C.byref(sh), C.byref(opt), B, seg_stride, ptr(seg),
                                                      ptr(seg_count), ptr(init), ptr(ref_end), ptr(dl_bounds),
@@ -219,9 +226,9 @@ class Context:
 
     def solve_warm_device(self, B, seg_stride, shared, seg, seg_count, init, ref_end, dl_bounds, ctrl, cost, status,
                           iters=None, x0=None, lam0=None, lam_out=None, mu0=0.0, smin=0.0, stream=None, max_iter=0,
-                          eps=0.0, hint=None):
+                          eps=0.0, hint=None, elastic=0, elastic_tol=0.0):
         """btrapz_solve_warm_device: seg_count None = uniform batch; x0 / lam0 / lam_out optional."""
-        sh = CShared.from_shared(shared); opt = COptions(int(max_iter), float(eps), float(os.environ.get("BTRAPZ_STEP_FRACTION", "0")), float(os.environ.get("BTRAPZ_STEP_THRESHOLD", "0")))
+        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol)
         raw = lambda t: t.data_ptr() if t is not None else None
         warm = CWarm(raw(x0), raw(lam0), raw(lam_out), float(mu0), float(smin), raw(hint))
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None

@@ -39,19 +39,21 @@ class BatchSolver:
                                   iters=torch.empty(B, dtype=torch.int32, device=d))
         return self._out[key]
 
-    def solve(self, dbatch, shared, max_iter=0, eps=0.0, out=None, warm=None, keep_multipliers=False):
+    def solve(self, dbatch, shared, max_iter=0, eps=0.0, out=None, warm=None, keep_multipliers=False, elastic=0,
+              elastic_tol=0.0):
         """Launches the solve on torch's current stream; returns dict of device tensors.
 
         warm: dict with optional "x0" ([B,2,S,3] joint states, e.g. from eval_states) and "lam" ([2,36,B,S]
         multipliers kept by an earlier solve) plus optional "mu0", "smin" and "hint" ([B] int32 expected difficulty,
         e.g. the previous step's iters: scheduling only) -- btrapz_warm.  keep_multipliers
-        adds this solve's multipliers to the result as "lam"."""
+        adds this solve's multipliers to the result as "lam".  elastic: btrapz_options.elastic (0 off, 1 rescue pass
+        over stalled candidates, 2 elastic rows for every candidate)."""
         o = out if out is not None else self._buffers(dbatch.B, dbatch.S)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if warm is None and not keep_multipliers:
             self.ctx.solve_device(dbatch.B, dbatch.S, shared, dbatch.seg, dbatch.init, dbatch.ref_end,
                                   dbatch.dl_bounds, o["ctrl"], o["cost"], o["status"], o["iters"], stream=stream,
-                                  max_iter=max_iter, eps=eps)
+                                  max_iter=max_iter, eps=eps, elastic=elastic, elastic_tol=elastic_tol)
             return o
         warm = warm or {}
         x0, lam0, hint = warm.get("x0"), warm.get("lam"), warm.get("hint")
@@ -70,7 +72,8 @@ class BatchSolver:
         self.ctx.solve_warm_device(dbatch.B, dbatch.S, shared, dbatch.seg, None, dbatch.init, dbatch.ref_end,
                                    dbatch.dl_bounds, o["ctrl"], o["cost"], o["status"], o["iters"], x0=x0, lam0=lam0,
                                    lam_out=lam_out, mu0=warm.get("mu0", 0.0), smin=warm.get("smin", 0.0),
-                                   stream=stream, max_iter=max_iter, eps=eps, hint=hint)
+                                   stream=stream, max_iter=max_iter, eps=eps, hint=hint, elastic=elastic,
+                                   elastic_tol=elastic_tol)
         return o
 
     def eval_states(self, dbatch, ctrl, times):
@@ -101,7 +104,7 @@ class BatchSolver:
         rec["_inputs"] = ins  # keep the knot arrays alive until the launch has run
         return rec
 
-    def solve_ragged(self, rec, shared, max_iter=0, eps=0.0):
+    def solve_ragged(self, rec, shared, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0):
         """Solve a ragged batch record (from corridor_batch); outputs stay on the device."""
         d = self.device
         B, st = rec["B"], rec["seg_stride"]
@@ -111,7 +114,7 @@ class BatchSolver:
         stream = torch.cuda.current_stream(d).cuda_stream
         self.ctx.solve_ragged_device(B, st, shared, rec["seg"], rec["seg_count"], rec["init"], rec["ref_end"],
                                      rec["dl_bounds"], o["ctrl"], o["cost"], o["status"], o["iters"], stream=stream,
-                                     max_iter=max_iter, eps=eps)
+                                     max_iter=max_iter, eps=eps, elastic=elastic, elastic_tol=elastic_tol)
         return o
 
     def argmin(self, cost, group=None, index_base=0):

@@ -1,0 +1,130 @@
+"""Acceptance parity: which inputs return a trajectory and which the 1e11 sentinel.
+
+The reference accepts OSQP's status 1 and 2 (solve_3d.cc:1251-1253, trp_wrapper.cpp:191-200).
+tests/golden/acceptance_table.json (tests/golden/make_acceptance_table.py) lists, for every bundled input x variant,
+the decision of the oracle's OSQP port and the decision the product must take: accept when the QP has an optimum,
+or when the exact solve stalls and the least-squares violation of the rows is within elastic_tol (the rescue pass,
+btrapz_options.elastic) -- the counterpart of the reference returning a status-2 ADMM iterate on a marginally
+infeasible corridor such as src/c7.txt."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import O
+from spectral_amd import knots, native, trp_wrapper
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+W = np.loadtxt(os.path.join(GOLD, "inputs", "weights.txt"))
+TABLE = json.load(open(os.path.join(GOLD, "acceptance_table.json")))
+ROWS = [(r["input"], r["variant"]) for r in TABLE["rows"]]
+BY_KEY = {(r["input"], r["variant"]): r for r in TABLE["rows"]}
+SENTINEL = 100000000000.0
+
+
+def oracle_qp(name, variant):
+    inp = O.ParsedInput(os.path.join(GOLD, "inputs", name + ".txt"))
+    n, cubes = O.pipeline(variant, inp)
+    return O.AssembledQp(variant, cubes, O.params_from_weights(W), inp)
+
+
+@pytest.mark.parametrize("name,variant", ROWS)
+def test_decision_and_trajectory_of_every_bundled_input(name, variant, tmp_path, monkeypatch):
+    """find_traj through the drop-in library: accept / reject as the table says; an accepted trajectory is the QP's
+    optimum, or -- for a rescued input -- the least-violation solution the oracle computes for the same relaxed QP."""
+    rec = BY_KEY[(name, variant)]
+    monkeypatch.setenv("BTRAPZ_INPUT", os.path.join(GOLD, "inputs", name + ".txt"))
+    monkeypatch.setenv("BTRAPZ_OUTPUT_PREFIX", str(tmp_path / "t_"))
+    lib = C.CDLL(os.path.join(native.LIB_DIR, "libtrp.so" if variant == 0 else "libcub.so"))
+    lib.find_traj.argtypes = (C.POINTER(trp_wrapper.Params),); lib.find_traj.restype = C.c_double
+    cost = lib.find_traj(trp_wrapper.Params(*W, 9))
+    assert (cost != SENTINEL) == rec["hip_accepts"], (cost, rec)
+    assert os.path.exists(str(tmp_path / "t_9.txt")) == rec["hip_accepts"]
+    if not rec["hip_accepts"]:
+        return
+    params = native.CParams(*[float(v) for v in W], 9)
+    cost_mem, traj, ctrl = native.find_traj_mem(variant, params, knots.parse_corridor_file(os.path.join(GOLD, "inputs", name + ".txt")))
+    assert cost_mem == cost
+    qp = oracle_qp(name, variant)
+    if rec["hip_status"] == 1:
+        x, _, info = qp.solve_exact()
+        assert info.status == 1
+    else:
+        x, _, info, viol = qp.solve_elastic()
+        assert info.status in (1, 2) and abs(viol - rec["least_violation"]) < 1e-6
+        Ax = qp.dense()[1] @ ctrl
+        ineq = (qp.u - qp.l) > 1e-12
+        got_viol = np.abs(Ax - np.clip(Ax, qp.l, qp.u))[ineq].max()
+        assert abs(got_viol - viol) <= 1e-5                                   # the same least violation
+        assert np.abs((Ax - qp.l)[~ineq]).max() <= 1e-9 * (1 + np.abs(qp.l).max())   # equalities stay exact
+    assert ctrl.shape == x.shape and np.abs(ctrl - x).max() <= 1e-5 * np.abs(x).max()
+
+
+def test_rescue_can_be_turned_off(tmp_path, monkeypatch):
+    """BTRAPZ_ELASTIC=0: a stalled solve is a failure, as in round 1."""
+    monkeypatch.setenv("BTRAPZ_ELASTIC", "0")
+    p = native.CParams(*[float(v) for v in W], 1)
+    assert native.find_traj_native(0, p, os.path.join(GOLD, "inputs", "c7.txt"), str(tmp_path / "o.txt")) == SENTINEL
+    monkeypatch.setenv("BTRAPZ_ELASTIC", "1")
+    monkeypatch.setenv("BTRAPZ_ELASTIC_TOL", "0.05")                          # below c7's 0.091: rejected as infeasible
+    assert native.find_traj_native(0, p, os.path.join(GOLD, "inputs", "c7.txt"), str(tmp_path / "o.txt")) == SENTINEL
+    monkeypatch.delenv("BTRAPZ_ELASTIC_TOL")
+    assert native.find_traj_native(0, p, os.path.join(GOLD, "inputs", "c7.txt"), str(tmp_path / "o.txt")) < 1e10
+
+
+def _c7_like_batch(B=24):
+    """Batch records of c7.txt (marginally infeasible l axis) and c2-like feasible candidates of the same shape."""
+    import torch
+    from spectral_amd import synth
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    kb = knots.jittered(knots.parse_corridor_file(os.path.join(GOLD, "inputs", "c7.txt")), B, seed=3, s_shift=0.2, l_shift=0.01)
+    rec = solver.corridor_batch(kb, 0, seg_stride=16)
+    sh = synth.shared_params(0)
+    h = kb.header
+    sh.ds_ref, sh.dl_ref, sh.dds, sh.ddds, sh.ddl, sh.dddl = h["ds_ref"], h["dl_ref"], h["dds"], h["ddds"], h["ddl"], h["dddl"]
+    return solver, rec, sh, torch
+
+
+def test_batched_rescue_touches_only_stalled_candidates():
+    """elastic = 1 on a ragged batch: candidates that were solved keep their result bit for bit; stalled ones come
+    back with status 2 and the least-violation control points of the oracle."""
+    solver, rec, sh, torch = _c7_like_batch()
+    plain = {k: v.clone() for k, v in solver.solve_ragged(rec, sh).items()}
+    resc = solver.solve_ragged(rec, sh, elastic=1)
+    torch.cuda.synchronize()
+    st0, st1 = plain["status"].cpu().numpy(), resc["status"].cpu().numpy()
+    assert (st0 == -2).any(), "the jittered c7 batch should contain stalled candidates"
+    ok = st0 > 0
+    assert np.array_equal(st1[ok], st0[ok])
+    assert torch.equal(plain["ctrl"][torch.from_numpy(ok)], resc["ctrl"][torch.from_numpy(ok)])
+    assert torch.equal(plain["cost"][torch.from_numpy(ok)], resc["cost"][torch.from_numpy(ok)])
+    stalled = np.nonzero(st0 == -2)[0]
+    assert (st1[stalled] == 2).all()
+    assert np.isfinite(resc["cost"].cpu().numpy()[stalled]).all()
+    # candidate 0 is the file itself
+    if st0[0] == -2:
+        S = int(rec["seg_count"][0].item())
+        got = resc["ctrl"][0, :12 * S].cpu().numpy()
+        x, _, info, viol = oracle_qp("c7", 0).solve_elastic()
+        assert np.abs(got - x).max() <= 1e-5 * np.abs(x).max()
+
+
+def test_elastic_on_every_candidate_agrees_with_the_plain_solve_where_it_is_feasible():
+    """elastic = 2 (no first attempt): a feasible candidate's relaxed optimum is x* up to delta * multipliers."""
+    import torch
+    from spectral_amd import synth
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    batch, sh = synth.make_batch(70, 10, config=2)
+    db = solver.upload(batch)
+    a = {k: v.clone() for k, v in solver.solve(db, sh).items()}
+    b = solver.solve(db, sh, elastic=2)
+    torch.cuda.synchronize()
+    assert (a["status"] == 1).all() and (b["status"] == 1).all()
+    x, y = a["ctrl"].cpu().numpy(), b["ctrl"].cpu().numpy()
+    assert np.abs(x - y).max() <= 1e-4 * np.abs(x).max()
+    assert np.abs(a["cost"].cpu().numpy() - b["cost"].cpu().numpy()).max() <= 1e-6 * np.abs(a["cost"].cpu().numpy()).max()

@@ -15,7 +15,8 @@ W = np.loadtxt(os.path.join(GOLD, "inputs", "weights.txt"))
 PRINT = 5.0e-4 + 2e-5
 FEASIBLE = [("c1", 0), ("c1", 1), ("c2", 0), ("c2", 1), ("c3", 0), ("c3", 1), ("c4", 0), ("c4", 1), ("c6", 0), ("c6", 1),
             ("c_road_s1", 0), ("c_road_s1", 1), ("c_road_s1_3", 0)]
-FAILING = [("c7", 0), ("c7_7", 1), ("c_road_s1_2", 0), ("c_road_s1_2", 1), ("c_road_s1_3", 1)]
+# (the c7 family is marginally infeasible: rescued since round 2, see tests/test_gpu_acceptance.py)
+FAILING = [("c_road_s1_2", 0), ("c_road_s1_2", 1), ("c_road_s1_3", 1)]
 
 
 def call(lib, params, inp, prefix, monkeypatch):
@@ -82,7 +83,7 @@ def test_python_mirrors(tmp_path, monkeypatch):
     monkeypatch.setenv("BTRAPZ_OUTPUT_PREFIX", str(tmp_path / "m_"))
     assert trp_wrapper.find_traj() is True and os.path.exists(str(tmp_path / "m_3.txt"))
     assert cub_wrapper.find_traj() is True
-    monkeypatch.setenv("BTRAPZ_INPUT", os.path.join(GOLD, "inputs", "c7.txt"))
+    monkeypatch.setenv("BTRAPZ_INPUT", os.path.join(GOLD, "inputs", "c_road_s1_2.txt"))
     assert trp_wrapper.find_traj() is False                   # infeasible corridor -> 1e11 -> False
 
 
