@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- trajectory-QP solves/sec of the HIP hot path on N MI355X GPUs.
 
-A "step" is one pass of the hot path over one batch of synthetic candidate corridors that
-is already resident in HBM: per-candidate QP assembly + solve (one launch), the per-rank
-arg-min, and -- for N > 1 -- the RCCL all-gather of the (cost, index) pairs that picks the
-global winner.  Workload: BASELINE.json config 3 (batch = 65536 scenario_1-shaped corridors,
-20 segments, order 5, trapezoid constraints) on every GPU (weak scaling: candidates are
-independent, each rank owns its shard).
+A "step" is one pass of the hot path over one batch of synthetic candidate corridors that is already resident in HBM:
+per-candidate QP assembly + solve (one launch), the per-rank arg-min, and -- for N > 1 -- the RCCL all-gather of the
+(cost, index) pairs that picks the global winner.  Workload: BASELINE.json config 3 -- batch = 65536 scenario_1-shaped
+corridors (src/c1.txt's corridor tiled to 20 one-second segments with per-candidate jitter, spectral_amd.synth.
+make_scenario1_batch), order 5, trapezoid constraints -- per GPU (weak scaling, default) or in total (--scaling strong:
+rank r owns the contiguous shard spectral_amd.dist.shard_bounds gives it).  The generic, feasible-by-construction
+family of round 1 is timed beside it as a second figure.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus 8                      # spawns the 8 ranks itself (torch.distributed.run, RCCL) ...
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W   # ... or runs as one of them
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,10 +39,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=65536, help="candidates per GPU")
+    ap.add_argument("--batch", type=int, default=65536, help="candidates per GPU (weak) / in total (strong)")
     ap.add_argument("--segments", type=int, default=20)
     ap.add_argument("--variant", type=int, default=0, help="0 trapezoid (config 3), 1 cuboid (config 4)")
+    ap.add_argument("--workload", default="scenario1", choices=["scenario1", "generic"],
+                    help="scenario1: src/c1.txt's corridor tiled (BASELINE configs 3/4); generic: the random family of round 1")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the second figure on the other workload")
     ap.add_argument("--latency-reps", type=int, default=200,
                     help="B=1 launches for the p50 latency (0 skips them, e.g. under rocprofv3 so that the "
                          "kernel's average duration is the batch launch alone)")
@@ -47,70 +54,124 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
                     help="dry run of the N > 1 flow on a 1-GPU box: every rank uses device 0 (use with --backend gloo)")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0: pick a free one)")
     return ap.parse_args()
 
 
-def measured_traffic(B, S, variant):
-    """HBM bytes per launch from the committed PMC profile of this workload (FETCH_SIZE + WRITE_SIZE,
-    separate rocprofv3 --pmc passes, profiles/*_pmc_hbm.json); None when no profile matches."""
+def self_launch(a):
+    """--gpus N without a torchrun environment: become the launcher.  Runs BEFORE anything touches the GPU (counting
+    devices does not initialise it); the ranks are children of torch.distributed.run, this process only waits."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus and not a.share_device:
+        sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) visible\n" % (a.gpus, have))
+        return 3
+    port = a.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def kernel_stamp():
+    from spectral_amd import native
+    return native.kernel_source_hash()
+
+
+def measured_profile(kind, B, S, variant, workload):
+    """Counter profile of THIS kernel build on THIS workload (profiles/r*_pmc_<kind>.json, tools/collect_profiles.sh).
+    A profile is used only when it carries the hash of the kernel sources it was collected with and that hash is the
+    current one: numbers of an older kernel are not passed on as measurements of this one."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")), reverse=True):
+    stamp = kernel_stamp()
+    stale = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % kind)), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         w = d.get("workload", {})
-        if (w.get("batch_per_gpu", w.get("batch")), w.get("segments"), w.get("variant")) == (B, S, variant):
-            return float(d["bytes_per_launch_raw"]), os.path.basename(f)
-    return None, None
-
-
-def measured_sq(B, S, variant):
-    """Executed FP64 flops per launch and VALU-busy share from the committed SQ counter profile of this
-    workload (profiles/*_pmc_sq.json, tools/collect_profiles.sh); None when no profile matches."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.json")), reverse=True):
-        try:
-            d = json.load(open(f))
-        except Exception:
+        if (w.get("batch_per_gpu", w.get("batch")), w.get("segments"), w.get("variant"), w.get("workload", "generic")) != (B, S, variant, workload):
             continue
-        w = d.get("workload", {})
-        if (w.get("batch_per_gpu"), w.get("segments"), w.get("variant")) == (B, S, variant):
-            dv = d.get("derived", {})
-            return dv.get("fp64_flops_per_launch_all_lanes"), dv.get("frac_of_wave_cycles:SQ_ACTIVE_INST_VALU"), os.path.basename(f)
-    return None, None, None
+        if d.get("kernel_source_hash") == stamp:
+            return d, os.path.basename(f)
+        stale = stale or os.path.basename(f)
+    return None, ("stale: %s was collected with other kernel sources" % stale) if stale else None
+
+
+def make_workload(name, B, S, variant, seed_offset):
+    from spectral_amd import synth
+    if name == "scenario1":
+        return synth.make_scenario1_batch(B, S, variant, seed=synth.SEED_BASE + 3 + variant + 1000 * seed_offset)
+    config = 3 if variant == 0 else 4
+    return synth.make_batch(B, S, config=config, variant=variant, seed=synth.SEED_BASE + config + 1000 * seed_offset)
+
+
+def workload_label(name, B, S, variant, world, scaling):
+    what = ("scenario_1-shaped corridors (src/c1.txt's lane corridors, 3 m/s upper and 5 m/s lower obstacle ramps and lane "
+            "change tiled to %d one-second segments; onset -1/0/+1 s, speed +-1 m/s, v0 ~ U(5,9) per candidate)" % S
+            if name == "scenario1" else "generic corridors (smooth random speed profile, random margins and ramps, one lane change; "
+            "feasible by construction)")
+    return "BASELINE.json config %d: batch=%d %s%s, %d segments, order 5, %s constraints, arg-min over all candidates" % (
+        3 if variant == 0 else 4, B, what, " per GPU" if scaling == "weak" else " in total over %d GPU(s)" % world, S,
+        "trapezoid-prism" if variant == 0 else "cuboid")
 
 
 def cpu_baseline(batch, shared, seconds):
-    """The reference's algorithm (oracle OSQP port) on the host cores, bounded sample."""
+    """The reference's algorithm (oracle OSQP port at the reference's settings) on the host cores, bounded sample of
+    the same batch: 1 thread, 8 threads and all schedulable cores, threads inside the C library."""
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0))
-    n0 = min(batch.B, 8 * cores)
-    t0 = time.perf_counter(); O.batch_solve(batch, shared, 0, n0, threads=cores); dt = time.perf_counter() - t0
-    rate = n0 / dt
-    n = int(max(n0, min(batch.B, rate * seconds)))
-    t0 = time.perf_counter(); _, _, st, it = O.batch_solve(batch, shared, 0, n, threads=cores); dt = time.perf_counter() - t0
-    t1 = time.perf_counter(); O.batch_solve(batch, shared, 0, min(n, 64), threads=1); dt1 = time.perf_counter() - t1
-    return {"value": n / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": "first %d candidates of the same batch, oracle OSQP port (eps 1e-5, max_iter 5000), "
-                      "%d threads; median ADMM iterations %d, accepted %.3f" % (n, cores, int(np.median(it)),
-                                                                                 float(np.mean((st == 1) | (st == 2)))),
-            "single_thread_solves_per_s": min(n, 64) / dt1,
-            "single_thread_ms_per_solve": 1e3 * dt1 / min(n, 64)}
+    host = O.host_cpu_info()
+    cores = host["effective_cores"]
+    O.fast_lib()
+    t0 = time.perf_counter(); O.batch_solve(batch, shared, 0, 4, threads=1, fast=True); r1 = 4 / (time.perf_counter() - t0)
+    n1 = int(max(4, min(batch.B, r1 * seconds * 0.25)))
+    t0 = time.perf_counter(); _, _, st1, it1 = O.batch_solve(batch, shared, 0, n1, threads=1, fast=True); dt1 = time.perf_counter() - t0
+    rates = {"1": n1 / dt1}
+    n_all, dt_all, st, it = n1, dt1, st1, it1
+    for th in sorted({min(8, cores), cores} - {1}):
+        n = int(max(4 * th, min(batch.B, rates["1"] * th * seconds * (0.25 if th != cores else 0.5))))
+        t0 = time.perf_counter(); _, _, st, it = O.batch_solve(batch, shared, 0, n, threads=th, fast=True); dt = time.perf_counter() - t0
+        rates[str(th)] = n / dt
+        n_all, dt_all = n, dt
+    osqp = "not found"
+    try:
+        import ctypes
+        ctypes.CDLL("libosqp.so")
+        osqp = "present (not timed: its version, hence its struct layout, is unknown)"
+    except OSError:
+        pass
+    return {"value": n_all / dt_all, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": "first %d candidates of the same batch, oracle OSQP port (eps 1e-5, max_iter 5000; gcc -O3 -march=native), "
+                      "%d POSIX threads drawing candidates from a shared counter; mean ADMM iterations %.0f, accepted %.3f"
+                      % (n_all, cores, float(np.mean(it)), float(np.mean((st == 1) | (st == 2)))),
+            "solves_per_s_by_threads": rates,
+            "scaling_efficiency_all_cores": rates[str(cores)] / (cores * rates["1"]) if cores > 1 else 1.0,
+            "host": host, "single_thread_solves_per_s": rates["1"], "single_thread_ms_per_solve": 1e3 / rates["1"],
+            "libosqp_so": osqp}
 
 
 def main():
     a = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if a.gpus > 1 and world_env is None:
+        raise SystemExit(self_launch(a))
     import torch
     import torch.distributed as dist
-    from spectral_amd import native, synth
-    from spectral_amd.dist import global_argmin
+    from spectral_amd import native
+    from spectral_amd.dist import global_argmin, shard_bounds
     from spectral_amd.solver import BatchSolver
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not os.path.exists(native.LIB_PATH):
         native.build()
@@ -118,6 +179,8 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     if a.share_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: local rank %d but %d HIP device(s)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         if a.backend == "nccl":
@@ -127,11 +190,18 @@ def main():
     solver = BatchSolver(local_rank)
     dev = solver.device
 
-    B, S = a.batch, a.segments
-    config = 3 if a.variant == 0 else 4
-    batch, shared = synth.make_batch(B, S, config=config, variant=a.variant, seed=synth.SEED_BASE + config + 1000 * rank)
+    S = a.segments
+    if a.scaling == "weak":
+        B, index_base = a.batch, rank * a.batch
+        batch, shared = make_workload(a.workload, B, S, a.variant, rank)
+        total_candidates = world * B
+    else:
+        # strong scaling: ONE batch (every rank draws the same one), rank r solves its contiguous shard
+        full, shared = make_workload(a.workload, a.batch, S, a.variant, 0)
+        lo, hi = shard_bounds(a.batch, world, rank)
+        batch, B, index_base = full.slice(lo, hi), hi - lo, lo
+        total_candidates = a.batch
     db = solver.upload(batch)
-    index_base = rank * B
 
     def step():
         o = solver.solve(db, shared)                                   # assembly + solve: one launch
@@ -151,45 +221,57 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     t0 = time.perf_counter()
     for i in range(a.steps):
-        ev[i][0].record()
+        ev[i][0].record()                       # torch's current stream == the stream the solve is launched on
         o = solver.solve(db, shared)
         ev[i][1].record()
         bi, bc = solver.argmin(o["cost"], index_base=index_base)
         wc, wi = global_argmin(bc, bi)
         win_idx, win_cost = wi[0], wc[0]
     sync()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    rank_ms = [1e3 * elapsed_local / a.steps]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        cdev = dev if a.backend == "nccl" else "cpu"
+        tt = torch.tensor([elapsed_local], dtype=torch.float64, device=cdev)
+        allt = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        rank_ms = [1e3 * float(t.item()) / a.steps for t in allt]
+        elapsed = max(float(t.item()) for t in allt)
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
 
     status = o["status"].cpu().numpy(); iters = o["iters"].cpu().numpy()
     solved = float(np.mean((status == 1) | (status == 2)))
-    mean_iters = float(np.mean(iters)) + 1.0  # iters holds the index of the last iteration
+    it1 = iters + 1                                         # iters holds the index of the last iteration
+    mean_iters = float(np.mean(it1))
 
     out = None
     if rank == 0:
-        total = world * B * a.steps
-        value = total / elapsed
+        value = total_candidates * a.steps / elapsed
         alg_bytes = batch.algorithmic_bytes() * B
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         flops = 2.0 * B * S * mean_iters * FLOPS_PER_SEGMENT_ITER
-        traffic, traffic_src = measured_traffic(B, S, a.variant)
-        sq_flops, valu_busy, sq_src = measured_sq(B, S, a.variant)
+        hbm, hbm_src = measured_profile("hbm", B, S, a.variant, a.workload)
+        sq, sq_src = measured_profile("sq", B, S, a.variant, a.workload)
+        sq_flops = sq["derived"].get("fp64_flops_per_launch_all_lanes") if sq else None
+        hist = np.bincount(it1[(status == 1) | (status == 2)].astype(np.int64), minlength=1)
         out = {
             "metric": "trajectory QP solves/sec (20-seg order-5 corridor)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json config %d: batch=%d scenario_1-shaped corridors per GPU, %d segments, "
-                                   "order 5, %s constraints, arg-min over all candidates" %
-                                   (config, B, S, "trapezoid-prism" if a.variant == 0 else "cuboid"),
-                       "batch_per_gpu": B, "segments": S, "variant": a.variant, "parallelism": "shard%d" % world,
-                       "collective": "none" if world == 1 else "%s all_gather of (cost,index), 16 B per rank" % ("rccl" if a.backend == "nccl" else a.backend)},
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload_label(a.workload, a.batch, S, a.variant, world, a.scaling),
+                       "generator": a.workload, "batch_per_gpu": B if a.scaling == "weak" else None,
+                       "batch_total": total_candidates, "segments": S, "variant": a.variant,
+                       "parallelism": "shard%d" % world,
+                       "collective": "none" if world == 1 else "%s all_gather of one (cost, index) pair = 16 B per rank and step"
+                                     % ("rccl" if a.backend == "nccl" else a.backend)},
+            "ms_per_step_by_rank": rank_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "btrapz::ipm_solve_kernel", "kernel_ms": kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # HBM bytes per launch from the PMC passes (FETCH_SIZE doubled as the guide prescribes for wide
+                         # coalesced reads + WRITE_SIZE) of THIS kernel build on THIS workload, else null
+                         "traffic": hbm["bytes_per_launch"] if hbm else None, "traffic_source": hbm_src,
+                         "kernel": "btrapz::ipm_solve_kernel", "kernel_ms": kernel_ms, "kernel_source_hash": kernel_stamp(),
                          "algorithmic_bytes_per_solve": batch.algorithmic_bytes(),
                          "note": "on-chip solve: the binding resource is FP64 VALU issue + dependent sweeps, not HBM "
                                  "(SURVEY 8d); see fp64_valu",
@@ -198,13 +280,38 @@ def main():
                                        "model": "%.0f useful flops per segment per iteration x %.2f mean iterations" %
                                                 (FLOPS_PER_SEGMENT_ITER, mean_iters),
                                        # what the SIMDs actually executed (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 x 64
-                                       # lanes, FMA = 2), from the committed counter profile of this workload
+                                       # lanes, FMA = 2), from the counter profile of this kernel build and workload
                                        "executed_tflops": None if sq_flops is None else sq_flops / (kernel_ms * 1e-3) / 1e12,
                                        "executed_frac": None if sq_flops is None else sq_flops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                                       "valu_busy_frac_of_wave_cycles": valu_busy, "counter_source": sq_src}},
+                                       "valu_busy_frac_of_wave_cycles": sq["derived"].get("frac_of_wave_cycles:SQ_ACTIVE_INST_VALU") if sq else None,
+                                       "counter_source": sq_src}},
             "solved_fraction": solved, "mean_ipm_iterations": mean_iters,
+            "ipm_iteration_histogram": {str(i): int(c) for i, c in enumerate(hist) if c},
+            "status_counts": {str(int(k)): int((status == k).sum()) for k in np.unique(status)},
             "winner": {"index": int(win_idx.item()), "cost": float(win_cost.item())},
         }
+        # second figure: the other workload family, same shape, a short run (not the headline)
+        if world == 1 and not a.no_secondary:
+            other = "generic" if a.workload == "scenario1" else "scenario1"
+            b2, sh2 = make_workload(other, B, S, a.variant, 0)
+            d2 = solver.upload(b2)
+            for _ in range(2):
+                solver.solve(d2, sh2)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = max(3, min(10, a.steps))
+            e0.record()
+            for _ in range(reps):
+                o2 = solver.solve(d2, sh2)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms2 = e0.elapsed_time(e1) / reps
+            st2 = o2["status"].cpu().numpy()
+            out["secondary"] = {"workload": workload_label(other, B, S, a.variant, 1, "weak"), "generator": other,
+                                "kernel_ms": ms2, "solves_per_s_kernel_only": B / (ms2 * 1e-3),
+                                "solved_fraction": float(np.mean((st2 == 1) | (st2 == 2))),
+                                "mean_ipm_iterations": float(np.mean(o2["iters"].cpu().numpy() + 1))}
+            del d2
         # p50 latency of ONE solve (B = 1), inputs resident, including the sync
         if a.latency_reps > 0:
             one = solver.upload(batch.slice(0, 1))

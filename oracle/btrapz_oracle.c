@@ -1533,3 +1533,54 @@ int orc_batch_solve(int variant, int B, int S, const double *seg, const double *
   free(x_ref); free(y_ref); free(dxb); free(dyb); free(cubes); free(x);
   return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* orc_batch_solve over [b0,b1) on `threads` POSIX threads.  Candidates are     */
+/* independent; their cost is not uniform (ADMM takes 200 .. 5000 iterations), */
+/* so the threads draw candidates from a shared counter instead of owning a    */
+/* fixed slice; every thread has its own buffers and output rows are disjoint. */
+/* bench.py's cpu_baseline leg.                                               */
+/* ------------------------------------------------------------------------ */
+#include <pthread.h>
+#include <stdatomic.h>
+typedef struct {
+  int variant, B, S, exact, b1, rc;
+  atomic_int *next;
+  const double *seg, *init, *ref_end, *dl_bounds, *shared; const orc_settings *settings;
+  double *ctrl, *obj; int *status, *iters;
+} orc_mt_job;
+static void *orc_mt_run(void *p) {
+  orc_mt_job *j = (orc_mt_job *)p;
+  for (;;) {
+    const int b = atomic_fetch_add(j->next, 1);
+    if (b >= j->b1) break;
+    const int rc = orc_batch_solve(j->variant, j->B, j->S, j->seg, j->init, j->ref_end, j->dl_bounds, j->shared,
+                                   j->settings, j->exact, b, b + 1, j->ctrl, j->obj, j->status, j->iters);
+    if (rc != 0) j->rc = rc;
+  }
+  return NULL;
+}
+int orc_batch_solve_mt(int variant, int B, int S, const double *seg, const double *init, const double *ref_end,
+                       const double *dl_bounds, const double *shared, const orc_settings *settings, int exact,
+                       int b0, int b1, int threads, double *ctrl, double *obj, int *status, int *iters) {
+  if (S < 1 || S > 64 || b0 < 0 || b1 > B) return -1;
+  if (threads < 1) threads = 1;
+  if (threads > b1 - b0) threads = b1 - b0 > 0 ? b1 - b0 : 1;
+  if (threads == 1) return orc_batch_solve(variant, B, S, seg, init, ref_end, dl_bounds, shared, settings, exact, b0, b1, ctrl, obj, status, iters);
+  orc_mt_job *jobs = (orc_mt_job *)calloc(threads, sizeof(orc_mt_job));
+  pthread_t *tid = (pthread_t *)calloc(threads, sizeof(pthread_t));
+  atomic_int next; atomic_init(&next, b0);
+  int rc = 0;
+  for (int t = 0; t < threads; t++) {
+    orc_mt_job *j = &jobs[t];
+    j->variant = variant; j->B = B; j->S = S; j->exact = exact; j->seg = seg; j->init = init; j->ref_end = ref_end;
+    j->dl_bounds = dl_bounds; j->shared = shared; j->settings = settings; j->ctrl = ctrl; j->obj = obj; j->status = status; j->iters = iters;
+    j->b1 = b1; j->next = &next;
+    if (t + 1 < threads) { if (pthread_create(&tid[t], NULL, orc_mt_run, j) != 0) tid[t] = 0; }
+    else orc_mt_run(j);                                   /* the calling thread works too */
+  }
+  for (int t = 0; t + 1 < threads; t++) if (tid[t]) pthread_join(tid[t], NULL);
+  for (int t = 0; t < threads; t++) if (jobs[t].rc != 0) rc = jobs[t].rc;
+  free(jobs); free(tid);
+  return rc;
+}

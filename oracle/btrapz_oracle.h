@@ -198,6 +198,11 @@ int orc_batch_solve(int variant, int B, int S, const double *seg, const double *
                     const orc_settings *settings, int exact, int b0, int b1, double *ctrl,
                     double *obj, int *status, int *iters);
 
+/* The same over `threads` POSIX threads (candidates drawn from a shared counter: their cost is not uniform). */
+int orc_batch_solve_mt(int variant, int B, int S, const double *seg, const double *init, const double *ref_end,
+                       const double *dl_bounds, const double *shared, const orc_settings *settings, int exact,
+                       int b0, int b1, int threads, double *ctrl, double *obj, int *status, int *iters);
+
 #ifdef __cplusplus
 }
 #endif

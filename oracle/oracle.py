@@ -146,8 +146,46 @@ def lib():
             [C.POINTER(Settings), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
              C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_batch_solve.restype = C.c_int
+        _bind_mt(L)
         _lib = L
     return _lib
+
+
+def _bind_mt(L):
+    L.orc_batch_solve_mt.argtypes = [C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 5 + \
+        [C.POINTER(Settings), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+         C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_batch_solve_mt.restype = C.c_int
+    L.orc_settings_reference.argtypes = [C.POINTER(Settings)]
+
+
+_fast = None
+
+
+def fast_lib():
+    """The same source at -O3 -march=native for the CPU this runs on (bench.py's cpu_baseline leg only).  Built on
+    first use, one file per CPU model so that a library built in the container is not run on the GPU box's host."""
+    global _fast
+    if _fast is None:
+        import hashlib
+        model = ""
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith(("model name", "flags")):
+                    model += line
+                    if line.startswith("flags"):
+                        break
+        except OSError:
+            pass
+        name = "libbtrapz_oracle_fast_%s.so" % hashlib.sha256(model.encode()).hexdigest()[:10]
+        path = os.path.join(_HERE, name)
+        src = os.path.join(_HERE, "btrapz_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "fast", "FAST=" + name], stdout=subprocess.DEVNULL)
+        L = C.CDLL(path)
+        _bind_mt(L)
+        _fast = L
+    return _fast
 
 
 def _dp(a):
@@ -345,9 +383,10 @@ def find_traj(variant, input_path, output_path, params, settings=None):
     return cost, s, ctrl[:12 * max(s, 0)].copy(), [cubes[i] for i in range(max(min(s, 64), 0))], info
 
 
-def batch_solve(batch, shared, b0=0, b1=None, exact=False, settings=None, threads=1):
+def batch_solve(batch, shared, b0=0, b1=None, exact=False, settings=None, threads=1, fast=False):
     """Solve candidates [b0,b1) of a spectral_amd.layout.Batch with the oracle (OSQP port, or
-    x* when exact).  threads>1 partitions the range over Python threads (ctypes drops the GIL)."""
+    x* when exact).  threads > 1: POSIX threads inside the C library drawing candidates from a shared
+    counter (orc_batch_solve_mt).  fast: the -O3 -march=native build (timing only; same arithmetic)."""
     B, S = batch.B, batch.S
     b1 = B if b1 is None else b1
     seg = np.ascontiguousarray(batch.seg, dtype=np.float64); init = np.ascontiguousarray(batch.init, dtype=np.float64)
@@ -357,14 +396,34 @@ def batch_solve(batch, shared, b0=0, b1=None, exact=False, settings=None, thread
     ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
     sp = C.byref(settings) if settings is not None else None
 
-    def run(lo, hi):
-        return lib().orc_batch_solve(shared.variant, B, S, _dp(seg), _dp(init), _dp(ref_end), _dp(dlb), _dp(sh), sp,
-                                     1 if exact else 0, lo, hi, _dp(ctrl), _dp(obj), ip(status), ip(iters))
-    if threads <= 1:
-        run(b0, b1)
-    else:
-        from concurrent.futures import ThreadPoolExecutor
-        edges = np.linspace(b0, b1, threads + 1).astype(int)
-        with ThreadPoolExecutor(threads) as ex:
-            list(ex.map(lambda i: run(int(edges[i]), int(edges[i + 1])), range(threads)))
+    L = fast_lib() if fast else lib()
+    rc = L.orc_batch_solve_mt(shared.variant, B, S, _dp(seg), _dp(init), _dp(ref_end), _dp(dlb), _dp(sh), sp,
+                              1 if exact else 0, int(b0), int(b1), int(max(1, threads)), _dp(ctrl), _dp(obj), ip(status),
+                              ip(iters))
+    if rc != 0:
+        raise RuntimeError("orc_batch_solve_mt -> %d" % rc)
     return ctrl[b0:b1], obj[b0:b1], status[b0:b1], iters[b0:b1]
+
+
+def host_cpu_info():
+    """What bounds the CPU baseline on this host: schedulable cores and the cgroup's CPU quota."""
+    info = {"sched_affinity": len(os.sched_getaffinity(0)), "cgroup_cpu_max": None}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            info["cgroup_cpu_max"] = open(path).read().strip()
+            break
+        except OSError:
+            continue
+    q = info["cgroup_cpu_max"]
+    eff = info["sched_affinity"]
+    if q:
+        parts = q.split()
+        try:
+            if len(parts) == 2 and parts[0] != "max":
+                eff = min(eff, max(1, int(float(parts[0]) / float(parts[1]) + 0.5)))
+            elif len(parts) == 1 and int(parts[0]) > 0:
+                eff = min(eff, max(1, int(int(parts[0]) / 100000 + 0.5)))
+        except ValueError:
+            pass
+    info["effective_cores"] = eff
+    return info

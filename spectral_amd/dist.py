@@ -19,24 +19,36 @@ def shard_bounds(B, world, rank):
 
 
 def global_argmin(best_cost, best_idx, group=None):
-    """best_cost [n] float64, best_idx [n] int64 (global indices, -1 = none) of this rank.
-    Returns (cost [n], idx [n]) of the winners over all ranks; identical on every rank."""
+    """best_cost [n] float64, best_idx [n] int64 (global candidate indices, -1 = none) of this rank.
+    Returns (cost [n], idx [n]) of the winners over all ranks; identical on every rank.
+
+    Layout contract: entry g of EVERY rank must belong to the same arg-min group, i.e. each of the n groups is spread
+    over the ranks and every rank reports its local winner of it (BASELINE configs 3/4: n = 1, the whole batch sharded
+    contiguously).  Groups that live entirely on one rank -- config 5 sharded by agent, 16 agents per GPU -- need no
+    collective at all: their local winner IS the winner; do not call this for them (merging rank r's group g with rank
+    0's group g would merge unrelated agents).  The entry count must be the same on every rank (checked).
+
+    One all_gather of n x 16 bytes per rank: the cost travels as its float64 bit pattern next to the int64 index in one
+    int64 tensor, so indices are exact (no float round trip) and there is a single collective per step."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return best_cost, best_idx
-    pair = torch.stack([best_cost.to(torch.float64), best_idx.to(torch.float64)], dim=-1).contiguous()
+    assert best_cost.shape == best_idx.shape and best_cost.dim() == 1
+    pair = torch.stack([best_cost.to(torch.float64).view(torch.int64), best_idx.to(torch.int64)], dim=-1).contiguous()
     dev = pair.device
     if dist.get_backend(group) == "gloo" and pair.is_cuda:   # CPU dry runs of the multi-rank flow
         pair = pair.cpu()
     gathered = [torch.empty_like(pair) for _ in range(world)]
-    dist.all_gather(gathered, pair, group=group)
-    allp = torch.stack(gathered).to(dev)             # [world, n, 2]
-    cost, idx = allp[..., 0], allp[..., 1]
-    idx_key = torch.where(idx < 0, torch.full_like(idx, float("inf")), idx)
-    # lexicographic min over ranks: cost first, then global index (a handful of small launches whatever the
-    # world size: this runs once per step, next to a ~7 ms solve)
+    dist.all_gather(gathered, pair, group=group)             # raises on a size mismatch: same n on every rank
+    allp = torch.stack(gathered).to(dev)                     # [world, n, 2] int64
+    cost = allp[..., 0].contiguous().view(torch.float64)
+    idx = allp[..., 1]
+    big = torch.iinfo(torch.int64).max
+    idx_key = torch.where(idx < 0, torch.full_like(idx, big), idx)
+    # lexicographic min over ranks: cost first (NaN never wins), then the lowest global index
+    cost = torch.where(torch.isnan(cost), torch.full_like(cost, float("inf")), cost)
     out_c = cost.min(dim=0).values
     tied = cost == out_c[None]
-    out_k = torch.where(tied, idx_key, torch.full_like(idx_key, float("inf"))).min(dim=0).values
-    out_i = torch.where(torch.isinf(out_k), torch.full_like(out_k, -1.0), out_k).to(torch.int64)
+    out_k = torch.where(tied, idx_key, torch.full_like(idx_key, big)).min(dim=0).values
+    out_i = torch.where(out_k == big, torch.full_like(out_k, -1), out_k)
     return out_c, out_i

@@ -102,6 +102,17 @@ def build(verbose=False):
     return LIB_PATH
 
 
+def kernel_source_hash():
+    """Identifies the kernel build a counter profile belongs to: sha256 over the sources and flags that determine
+    the solve kernel's code (profiles/*.json carry it; bench.py refuses profiles of other kernel sources)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("btrapz_kernels.hip", "btrapz_device.h", "Makefile", os.path.join("..", "..", "include", "btrapz_hip.h")):
+        with open(os.path.join(CSRC_DIR, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 ROCM_HIP_RUNTIME = "/opt/rocm/lib/libamdhip64.so"
 

@@ -12,6 +12,7 @@ What is committed and where it comes from:
   corridors.json      new_corridor lists of the oracle's pipeline for every bundled input.
   scenario_xstar.npz  oracle x* (dense interior point) + OSQP-port solution per scenario.
   synthetic_xstar.npz oracle x* for the first candidates of the synthetic configs.
+  scenario1_xstar.npz oracle x* for the first candidates of the scenario_1-shaped batches (configs 3 / 4).
 The reference itself cannot be run here (needs Eigen + OSQP), so the last three are produced by
 this repo's oracle; the parity tests compare the HIP path with them on the GPU box, where
 /root/reference does not exist.
@@ -67,7 +68,21 @@ def main():
         syn["cfg%d/meta" % cfg] = np.array([256, S, variant, nb])
     np.savez_compressed(os.path.join(HERE, "synthetic_xstar.npz"), **syn)
     print("wrote corridors.json, scenario_xstar.npz, synthetic_xstar.npz")
+    scenario1()
+
+
+def scenario1():
+    """x* of the first candidates of the scenario_1-shaped batches (BASELINE configs 3 and 4, synth.make_scenario1_batch)."""
+    s1 = {}
+    for S, variant, nb in [(20, 0, 48), (20, 1, 48), (10, 0, 24)]:
+        batch, sh = synth.make_scenario1_batch(256, S, variant)
+        ctrl, obj, st, it = O.batch_solve(batch, sh, 0, nb, exact=True, threads=8)
+        key = "S%d_v%d" % (S, variant)
+        s1[key + "/xstar"] = ctrl; s1[key + "/obj"] = obj; s1[key + "/status"] = st
+        s1[key + "/meta"] = np.array([256, S, variant, nb])
+    np.savez_compressed(os.path.join(HERE, "scenario1_xstar.npz"), **s1)
+    print("wrote scenario1_xstar.npz")
 
 
 if __name__ == "__main__":
-    main()
+    scenario1() if "--scenario1" in sys.argv else main()

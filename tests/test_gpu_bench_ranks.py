@@ -1,0 +1,37 @@
+"""bench.py's multi-rank flow on ONE GPU: `--gpus 2 --backend gloo --share-device` makes bench.py spawn two ranks
+(torch.distributed.run) that share device 0 and exchange the (cost, index) pairs over gloo -- the code path of an
+N-GPU run with RCCL swapped for gloo.  Strong scaling: the two ranks split ONE batch, so the winner must be the
+1-rank winner of that batch."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(*args):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "6000",
+                        "--no-cpu-baseline", "--latency-reps", "0", "--no-secondary", *args],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                      # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_two_ranks_on_one_gpu_pick_the_single_rank_winner():
+    one = run("--gpus", "1", "--scaling", "strong")
+    two = run("--gpus", "2", "--scaling", "strong", "--backend", "gloo", "--share-device")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["winner"] == one["winner"]                  # same batch, sharded: same arg-min, bit for bit
+    assert two["config"]["batch_total"] == one["config"]["batch_total"] == 6000
+    assert len(two["ms_per_step_by_rank"]) == 2 and "gloo" in two["config"]["collective"]
+    weak = run("--gpus", "2", "--scaling", "weak", "--backend", "gloo", "--share-device")
+    assert weak["config"]["batch_total"] == 12000 and weak["scaling"] == "weak"
+    for line in (one, two, weak):
+        assert line["roofline"]["frac"] > 0 and "cpu_baseline" in line and line["value"] > 0

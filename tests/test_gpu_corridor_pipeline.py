@@ -224,3 +224,50 @@ def test_hard_jittered_candidates_agree_with_oracle_on_solvability_and_optimum(n
             c = ctrl[idx][:, :12 * S]
             assert (np.abs(c[m] - xs[m]).max(axis=1) <= 1e-5 * np.abs(xs[m]).max(axis=1)).all(), (name, S)
     assert both >= 0.5 * B and disagree <= 2, (name, variant, both, disagree)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_scenario1_knots_through_the_device_corridor_stage(variant):
+    """BASELINE config 3's scene at knot level (synth.scenario1_knots: c1.txt's obstacle events tiled over 20 s):
+    the device corridor stage returns the oracle pipeline's segments field by field -- a ragged batch, because the
+    pipeline cuts 0.1-s slivers where a ramp ends (as it does on c1.txt itself) -- and where a candidate's events
+    fall on whole seconds the selected corridor is the one make_scenario1_batch writes down directly."""
+    import torch
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    kb = synth.scenario1_knots(48, 20)
+    rec = solver.corridor_batch(kb, variant, seg_stride=32)
+    torch.cuda.synchronize()
+    seg = rec["seg"].cpu().numpy(); cnt = rec["seg_count"].cpu().numpy()
+    counts = set()
+    for b in range(kb.B):
+        n, cubes = oracle_pipeline(kb, b, variant)
+        assert cnt[b] == n, (b, cnt[b], n)
+        counts.add(n)
+        for k, c in enumerate(cubes):
+            for f, attr in FIELDS:
+                assert seg[f, b, k] == getattr(c, attr), (b, k, attr)
+    assert len(counts) >= 3 and min(counts) >= 17 and max(counts) <= 26
+    # same random draws as the segment-level batch: the lanes and ramps of the one-second segments agree
+    if variant == 0:
+        batch, _ = synth.make_scenario1_batch(48, 20, 0)
+        same = compared = 0
+        for b in range(kb.B):
+            n, cubes = oracle_pipeline(kb, b, variant)
+            for k, c in enumerate(cubes):
+                if c.beg_t % 10 != 0 or c.end_t - c.beg_t != 10:
+                    continue                                   # slivers and the segments they displace by one knot
+                q = c.beg_t // 10
+                compared += 1
+                same += (seg[L.F_BEG_L, b, k] == batch.seg[L.F_BEG_L, b, q] and seg[L.F_END_L, b, k] == batch.seg[L.F_END_L, b, q]
+                         and abs(seg[L.F_UPP_SKEW, b, k] - batch.seg[L.F_UPP_SKEW, b, q]) <= 1e-9
+                         and abs(seg[L.F_UPP_BIAS, b, k] - batch.seg[L.F_UPP_BIAS, b, q]) <= 1e-9
+                         and abs(seg[L.F_DOWN_SKEW, b, k] - batch.seg[L.F_DOWN_SKEW, b, q]) <= 1e-9)
+        # (the exceptions: CollisionCheck stays in the second lane one segment longer when its lower ramp is active there)
+        assert compared >= 5 * kb.B and same >= 0.95 * compared
+    # and the ragged solve runs on it
+    sh = synth.make_scenario1_batch(1, 20, variant)[1]
+    out = solver.solve_ragged(rec, sh)
+    torch.cuda.synchronize()
+    st = out["status"].cpu().numpy()
+    assert ((st == 1) | (st == 2)).mean() >= 0.5

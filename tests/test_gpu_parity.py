@@ -45,6 +45,29 @@ def test_against_committed_xstar(ctx, cfg, S, variant):
     assert iters.max() < 30
 
 
+@pytest.mark.parametrize("S,variant", [(20, 0), (20, 1), (10, 0)])
+def test_scenario1_batches_against_committed_xstar(ctx, S, variant):
+    """BASELINE configs 3 / 4 on the workload bench.py times: scenario_1-shaped corridors (synth.make_scenario1_batch).
+    Solvable candidates agree with the oracle's x*; the others (a late slow obstacle in front of a fast ego; empty
+    inscribed intervals of the cuboid variant) are flagged by both."""
+    g = np.load(os.path.join(GOLD, "scenario1_xstar.npz"))
+    key = "S%d_v%d" % (S, variant)
+    B, S_, v_, nb = g[key + "/meta"]
+    batch, sh = synth.make_scenario1_batch(int(B), S, variant)
+    ctrl, cost, status, iters = ctx.solve_host(batch, sh)
+    xs, obj, st = g[key + "/xstar"], g[key + "/obj"], g[key + "/status"]
+    n = 0
+    for b in range(int(nb)):
+        if st[b] == 1:
+            n += 1
+            assert status[b] in (1, 2), (b, status[b])
+            assert rel(ctrl[b], xs[b]) <= RTOL, (b, rel(ctrl[b], xs[b]))
+            assert abs(cost[b] - obj[b]) <= 1e-7 * abs(obj[b])
+        else:
+            assert status[b] < 0 and np.isinf(cost[b]), (b, status[b], st[b])
+    assert n >= nb // 2
+
+
 @pytest.mark.parametrize("S,variant,B", [(1, 0, 5), (2, 0, 33), (3, 1, 64), (5, 0, 17), (16, 0, 9), (21, 1, 7), (32, 0, 5),
                                          (33, 0, 3), (64, 0, 2)])
 def test_ragged_shapes_against_live_oracle(ctx, S, variant, B):

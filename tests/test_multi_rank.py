@@ -69,3 +69,61 @@ def test_shard_bounds_cover_the_batch():
 def test_all_failed_group_reports_minus_one():
     c, i = global_argmin(torch.tensor([float("inf")], dtype=torch.float64), torch.tensor([-1]))
     assert int(i[0]) == -1
+
+
+def _worker_edge(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    base = (1 << 60) + 12345                                   # indices beyond 2^53: exact only as integers
+    # group 0: a tie between the ranks -> lowest index; group 1: rank 0 failed, rank 1 solved; group 2: nobody solved;
+    # group 3: a NaN cost (never produced by the kernels, must still not win)
+    bc = torch.tensor([[-7.5, float("inf"), float("inf"), float("nan")], [-7.5, 3.0, float("inf"), 5.0]][rank], dtype=torch.float64)
+    bi = torch.tensor([[base + 9, -1, -1, base + 1], [base + 2, base + 77, -1, base + 3]][rank], dtype=torch.int64)
+    c, i = global_argmin(bc, bi)
+    q.put((rank, c.numpy().copy(), i.numpy().copy()))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_global_argmin_edge_cases_and_exact_indices():
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_worker_edge, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in range(2)]
+    [p.join(timeout=60) for p in procs]
+    base = (1 << 60) + 12345
+    for rank, c, i in res:
+        assert i.tolist() == [base + 2, base + 77, -1, base + 3]
+        assert c[0] == -7.5 and c[1] == 3.0 and np.isinf(c[2]) and c[3] == 5.0
+
+
+def test_strong_scaling_shards_are_the_one_batch():
+    """bench.py --scaling strong: every rank draws the same batch and solves its contiguous shard."""
+    import bench
+    from spectral_amd import layout as L
+    full, sh = bench.make_workload("scenario1", 1000, 20, 0, 0)
+    again, _ = bench.make_workload("scenario1", 1000, 20, 0, 0)
+    assert np.array_equal(full.seg, again.seg) and np.array_equal(full.init, again.init)      # deterministic
+    parts = []
+    for r in range(3):
+        lo, hi = shard_bounds(1000, 3, r)
+        parts.append(full.slice(lo, hi))
+    assert sum(p.B for p in parts) == 1000
+    assert np.array_equal(np.concatenate([p.seg for p in parts], axis=1), full.seg)
+    assert np.array_equal(np.concatenate([p.init for p in parts]), full.init)
+    other, _ = bench.make_workload("scenario1", 1000, 20, 0, 1)                               # weak: a batch per rank
+    assert not np.array_equal(other.init, full.init)
+    assert full.seg.shape == (L.NUM_SEG_FIELDS, 1000, 20)
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """python bench.py --gpus N without a torchrun environment launches the N ranks itself, and says so loudly when
+    the box has fewer devices instead of benchmarking one GPU under the wrong label."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 3 and "HIP device" in p.stderr and p.stdout.strip() == ""

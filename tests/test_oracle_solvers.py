@@ -167,3 +167,20 @@ def test_synthetic_goldens(cfg, S, variant):
     qp = oracle_qp_from_batch(batch, sh, 2)
     x, y, info = qp.solve_exact()
     assert np.abs(x - ctrl[2]).max() <= 1e-9 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("S,variant", [(20, 0), (20, 1), (10, 0)])
+def test_scenario1_goldens(S, variant):
+    g = np.load(os.path.join(GOLD, "scenario1_xstar.npz"))
+    key = "S%d_v%d" % (S, variant)
+    batch, sh = synth.make_scenario1_batch(256, S, variant)
+    ctrl, obj, st, it = O.batch_solve(batch, sh, 0, 4, exact=True)
+    assert np.array_equal(st, g[key + "/status"][:4])
+    ok = st == 1
+    assert np.abs(ctrl[ok] - g[key + "/xstar"][:4][ok]).max() <= 1e-9 * np.abs(ctrl[ok]).max()
+    # the batch is c1.txt's corridor: lane (1,3), then (3,4.5) from t = 4 s, with the file's header limits
+    assert (sh.dds, sh.ddl, sh.ds_ref) == ((-3.0, 2.0), (-2.0, 2.0), 10.0)
+    from spectral_amd import layout as L
+    assert (batch.seg[L.F_BEG_L][:, :4] == 1.0).all() and (batch.seg[L.F_BEG_L][:, 4:min(S, 14)] == 3.0).all()
+    ramp = batch.seg[L.F_UPP_SKEW] != 0
+    assert ramp.any(axis=1).all() and (np.abs(batch.seg[L.F_UPP_SKEW][ramp] - (3.0 if variant == 0 or S < 17 else 3.0 * 95 / (20 * 40 / 7))) <= 1.0 + 1e-9).all()

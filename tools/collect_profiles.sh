@@ -1,44 +1,76 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
-# then locally:  python tools/summarize_profiles.py r01
-# Counter passes are separate runs with --pmc only (never combined with tracing), as the pool requires.
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
+# then locally:  python tools/summarize_profiles.py r02
+# Counter passes are separate runs with --pmc only (never combined with tracing), as the pool requires; the program
+# follows `--` directly (python3 / a binary, no wrapper).  Every step's exit status is recorded: a failed step leaves a
+# line in $OUT/failed.txt (and its stderr in $OUT/*.err), and tools/summarize_profiles.py refuses to summarise a
+# failed or empty run.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+QUICK=${2:-}                      # "quick": bench + trace + counters only
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
+rm -f "$OUT/failed.txt"
 export TMPDIR=/tmp
 BENCH="$ROOT/bench.py"
 cd /tmp
 
-python3 "$BENCH" > "$OUT/bench.json" 2> "$OUT/bench.err"
+step() {   # step <name> <stdout file> <command...>: run, keep stderr, record failures and empty outputs
+  local name=$1 out=$2; shift 2
+  if ! "$@" > "$out" 2> "$OUT/$name.err"; then echo "FAILED ($?): $name: $*" >> "$OUT/failed.txt"; return 1; fi
+  if [ ! -s "$out" ]; then echo "EMPTY OUTPUT: $name: $*" >> "$OUT/failed.txt"; return 1; fi
+  return 0
+}
 
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
-  python3 "$BENCH" --latency-reps 0 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); from spectral_amd import native; print(native.kernel_source_hash())" \
+  > "$OUT/kernel_source_hash.txt" 2> "$OUT/hash.err" || echo "FAILED: kernel_source_hash" >> "$OUT/failed.txt"
 
-PMC_ARGS="--steps 3 --warmup 1 --latency-reps 0 --no-cpu-baseline"
+step bench "$OUT/bench.json" python3 "$BENCH"
+
+step trace "$OUT/bench_under_rocprof.json" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
+  python3 "$BENCH" --latency-reps 0 --no-cpu-baseline --no-secondary
+
+PMC_ARGS="--steps 3 --warmup 1 --latency-reps 0 --no-cpu-baseline --no-secondary"
 for group in \
   "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
   "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
   "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SMEM SQ_INSTS_VALU_INT32" \
   "GRBM_GUI_ACTIVE" ; do
-  name=$(echo "$group" | tr ' ' '+' | cut -c1-60)
+  name=pmc_$(echo "$group" | tr ' ' '+' | cut -c1-60)
   # shellcheck disable=SC2086
-  rocprofv3 --pmc $group --output-format csv -d "$OUT/pmc_$name" -- python3 "$BENCH" $PMC_ARGS \
-    > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" || echo "pmc group failed: $group" >> "$OUT/failed.txt"
+  step "$name" "$OUT/$name.json" rocprofv3 --pmc $group --output-format csv -d "$OUT/$name" -- python3 "$BENCH" $PMC_ARGS
 done
-# the other tools: BASELINE config 5 (receding horizon), knots -> control points, configs 2 and 4 through bench.py
-python3 "$ROOT/tools/mpc_bench.py" > "$OUT/mpc_warm.json" 2> /dev/null
-python3 "$ROOT/tools/mpc_bench.py" --cold > "$OUT/mpc_cold.json" 2> /dev/null
-python3 "$ROOT/tools/mpc_bench.py" --min-first 0.5 > "$OUT/mpc_warm_minfirst05.json" 2> /dev/null
-python3 "$ROOT/tools/mpc_bench.py" --cold --min-first 0.5 > "$OUT/mpc_cold_minfirst05.json" 2> /dev/null
-python3 "$ROOT/tools/pipeline_bench.py" > "$OUT/pipeline.json" 2> /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_pipeline" -- \
-  python3 "$ROOT/tools/pipeline_bench.py" > "$OUT/pipeline_under_rocprof.json" 2> "$OUT/trace_pipeline.err"
-python3 "$BENCH" --segments 10 --batch 4096 --no-cpu-baseline > "$OUT/bench_config2.json" 2> /dev/null
-python3 "$BENCH" --variant 1 --no-cpu-baseline > "$OUT/bench_config4.json" 2> /dev/null
+
+# FETCH_SIZE / WRITE_SIZE calibration in the solve kernel's access widths (tools/fetch_calib.hip)
+if /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/fetch_calib "$ROOT/tools/fetch_calib.hip" 2> "$OUT/calib_build.err"; then
+  for mode in 8 16; do
+    step "calib_fetch_$mode" "$OUT/calib_fetch_$mode.json" rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/calib_fetch_$mode" -- /tmp/fetch_calib $mode
+  done
+  step calib_write_48 "$OUT/calib_write_48.json" rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/calib_write_48" -- /tmp/fetch_calib 48
+else
+  echo "FAILED: build of tools/fetch_calib.hip" >> "$OUT/failed.txt"
+fi
+
+if [ "$QUICK" != "quick" ]; then
+  # the other tools: BASELINE config 5 (receding horizon), knots -> control points, the other configs through bench.py
+  step mpc_warm "$OUT/mpc_warm.json" python3 "$ROOT/tools/mpc_bench.py"
+  step mpc_cold "$OUT/mpc_cold.json" python3 "$ROOT/tools/mpc_bench.py" --cold
+  step mpc_warm_minfirst05 "$OUT/mpc_warm_minfirst05.json" python3 "$ROOT/tools/mpc_bench.py" --min-first 0.5
+  step mpc_cold_minfirst05 "$OUT/mpc_cold_minfirst05.json" python3 "$ROOT/tools/mpc_bench.py" --cold --min-first 0.5
+  step pipeline "$OUT/pipeline.json" python3 "$ROOT/tools/pipeline_bench.py"
+  step pipeline_s1 "$OUT/pipeline_scenario1.json" python3 "$ROOT/tools/pipeline_bench.py" --scenario1
+  step trace_pipeline "$OUT/pipeline_under_rocprof.json" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_pipeline" -- \
+    python3 "$ROOT/tools/pipeline_bench.py"
+  step bench_config2 "$OUT/bench_config2.json" python3 "$BENCH" --segments 10 --batch 4096 --no-cpu-baseline
+  step bench_config4 "$OUT/bench_config4.json" python3 "$BENCH" --variant 1 --no-cpu-baseline
+  step bench_generic "$OUT/bench_generic.json" python3 "$BENCH" --workload generic --no-cpu-baseline
+  step bench_2rank "$OUT/bench_2rank_gloo_strong.json" python3 "$BENCH" --gpus 2 --backend gloo --share-device --scaling strong --no-cpu-baseline --latency-reps 0
+fi
 # keep only the CSVs (the merge-back limit is 64 MiB)
 find "$OUT" -name "*.db" -delete 2>/dev/null
 du -sh "$OUT"
+if [ -s "$OUT/failed.txt" ]; then echo "SOME STEPS FAILED:"; cat "$OUT/failed.txt"; exit 1; fi
+echo "all steps ok"

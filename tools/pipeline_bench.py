@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--seg-stride", type=int, default=16)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--scenario1", action="store_true",
+                    help="BASELINE config 3 at knot level: synth.scenario1_knots (src/c1.txt's scene tiled over 20 s, N = 201, "
+                         "18-24 segments per candidate) instead of jittered copies of a bundled file")
     a = ap.parse_args()
     import torch
     from spectral_amd import knots, synth, layout as L
@@ -34,7 +37,13 @@ def main():
     solver = BatchSolver(0)
     d = solver.device
     B, st = a.batch, a.seg_stride
-    kb = knots.jittered(knots.parse_corridor_file(os.path.join(gold, a.input + ".txt")), B, seed=3)
+    if a.scenario1:
+        kb = synth.scenario1_knots(B, 20)
+        st = max(st, 32)
+        label = "%d scenario_1-shaped candidates at knot level (synth.scenario1_knots: c1.txt's scene tiled over 20 s)" % B
+    else:
+        kb = knots.jittered(knots.parse_corridor_file(os.path.join(gold, a.input + ".txt")), B, seed=3)
+        label = "%d jittered copies of %s.txt" % (B, a.input)
     sh = synth.shared_params(a.variant, weights=W)
     sh.ds_ref, sh.dl_ref = kb.header["ds_ref"], kb.header["dl_ref"]
     sh.dds, sh.ddds, sh.ddl, sh.dddl = kb.header["dds"], kb.header["ddds"], kb.header["ddl"], kb.header["dddl"]
@@ -65,8 +74,8 @@ def main():
     out_bytes = int(B * (L.NUM_SEG_FIELDS * mean_cnt * 8 + 4 + 16 + 80))
     c_ms, s_ms = float(np.median(tc)), float(np.median(ts))
     print(json.dumps({
-        "workload": "%d jittered copies of %s.txt (N = %d knots, %d obstacles), %s constraints" %
-                    (B, a.input, kb.N, kb.num_obs, "trapezoid" if a.variant == 0 else "cuboid"),
+        "workload": "%s (N = %d knots, %d obstacles), %s constraints" %
+                    (label, kb.N, kb.num_obs, "trapezoid" if a.variant == 0 else "cuboid"),
         "corridor_ms": c_ms, "ragged_solve_ms": s_ms, "end_to_end_candidates_per_s": B / (c_ms + s_ms) * 1e3,
         "segments_per_candidate": {int(k): int(v) for k, v in zip(*np.unique(cnt, return_counts=True))},
         "solved_fraction": float(np.mean((status == 1) | (status == 2))),

@@ -16,11 +16,11 @@ import sys
 KERNEL = "ipm_solve_kernel"
 
 
-def counter_means(root):
-    """{counter: (mean over launches of KERNEL, launches, resource columns)} over every pmc_* directory."""
+def counter_means(root, pattern="pmc_*", kernel=KERNEL):
+    """{counter: (mean over launches of the kernel, launches, resource columns)} over every matching directory."""
     out = {}
     newest = {}   # gpurun's merge keeps earlier runs' files: take the newest CSV of every counter group
-    for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for path in glob.glob(os.path.join(root, pattern, "**", "*counter_collection.csv"), recursive=True):
         group = os.path.relpath(path, root).split(os.sep)[0]
         if group not in newest or os.path.getmtime(path) > os.path.getmtime(newest[group]):
             newest[group] = path
@@ -28,7 +28,7 @@ def counter_means(root):
         acc = {}
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
-                if KERNEL not in row["Kernel_Name"]:
+                if kernel not in row["Kernel_Name"]:
                     continue
                 acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
                 acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
@@ -41,9 +41,16 @@ def counter_means(root):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src, dst = os.path.join(here, "gpurun_out", tag), os.path.join(here, "profiles")
+    failed = os.path.join(src, "failed.txt")
+    if os.path.exists(failed) and os.path.getsize(failed) and "--allow-failed" not in sys.argv:
+        sys.exit("collect_profiles.sh recorded failures (pass --allow-failed to summarise what is there):\n" + open(failed).read())
+    for need in ("bench.json", "bench_under_rocprof.json", "kernel_source_hash.txt"):
+        if not os.path.exists(os.path.join(src, need)) or not os.path.getsize(os.path.join(src, need)):
+            sys.exit("missing or empty %s under %s" % (need, src))
+    stamp = open(os.path.join(src, "kernel_source_hash.txt")).read().strip()
     shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
     shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
@@ -52,13 +59,28 @@ def main():
     pstats = glob.glob(os.path.join(src, "trace_pipeline", "**", "*kernel_stats.csv"), recursive=True)
     if pstats:
         shutil.copy(max(pstats, key=os.path.getmtime), os.path.join(dst, f"{tag}_pipeline_kernel_stats.csv"))
-    for name in ("mpc_warm", "mpc_cold", "mpc_warm_minfirst05", "mpc_cold_minfirst05", "pipeline", "bench_config2",
-                 "bench_config4"):
+    for name in ("mpc_warm", "mpc_cold", "mpc_warm_minfirst05", "mpc_cold_minfirst05", "pipeline", "pipeline_scenario1",
+                 "bench_config2", "bench_config4", "bench_generic", "bench_2rank_gloo_strong"):
         if os.path.exists(os.path.join(src, name + ".json")):
             shutil.copy(os.path.join(src, name + ".json"), os.path.join(dst, f"{tag}_{name}.json"))
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-    wl = bench["config"]
+    wl = dict(bench["config"]); wl["workload"] = wl.get("generator", "generic")      # the key bench.py matches on
+    wl["label"] = bench["config"]["workload"]
+    if wl.get("batch_per_gpu") is None:
+        wl["batch_per_gpu"] = wl.get("batch_total")
     c = counter_means(src)
+    if not c:
+        sys.exit("no counter CSVs under %s/pmc_*" % src)
+
+    # calibration of FETCH_SIZE / WRITE_SIZE in the solve kernel's access widths (tools/fetch_calib.hip)
+    calib = {}
+    for mode, counter, kern in (("fetch_8", "FETCH_SIZE", "read8"), ("fetch_16", "FETCH_SIZE", "read16"), ("write_48", "WRITE_SIZE", "write48")):
+        cc = counter_means(src, "calib_" + mode, kern)
+        js = os.path.join(src, "calib_%s.json" % mode)
+        if counter in cc and os.path.exists(js):
+            known = json.loads([l for l in open(js).read().splitlines() if l.startswith("{")][-1])["bytes_per_launch"]
+            calib[mode] = dict(known_bytes_per_launch=known, counter_KB=cc[counter]["mean"], launches=cc[counter]["launches"],
+                               bytes_per_counted_byte=known / (cc[counter]["mean"] * 1024.0))
 
     hbm = {}
     for k in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -67,11 +89,20 @@ def main():
                           **{r: c[k][r] for r in ("vgpr", "agpr", "sgpr", "lds", "scratch", "grid")})
     if len(hbm) == 2:
         hbm["workload"] = wl
+        hbm["kernel_source_hash"] = stamp
+        hbm["calibration"] = calib
         hbm["bytes_per_launch_raw"] = (hbm["FETCH_SIZE"]["mean_KB"] + hbm["WRITE_SIZE"]["mean_KB"]) * 1024.0
-        hbm["note"] = ("FETCH_SIZE/WRITE_SIZE in KB, separate --pmc passes (TCC slot limit).  WRITE_SIZE matches the "
-                       "stored bytes.  FETCH_SIZE is uncalibrated for this access width (8 B/lane loads; the guide "
-                       "calibrates only 16 B/lane streams, where it reads 1/2): the raw figure is reported; the true "
-                       "read traffic lies between it and twice it.")
+        # corrected as MI355X_MICROARCH.md (HBM) prescribes: counters times the factor measured on a known byte count in
+        # the kernel's own access width (8 B per lane reads; 8 B stores at a 48 B lane stride); without a calibration
+        # run the guide's factor for wide coalesced reads (2) and 1 for the stores
+        kf = calib.get("fetch_8", {}).get("bytes_per_counted_byte", 2.0)
+        kw = calib.get("write_48", {}).get("bytes_per_counted_byte", 1.0)
+        hbm["fetch_factor"], hbm["write_factor"] = kf, kw
+        hbm["bytes_per_launch"] = (kf * hbm["FETCH_SIZE"]["mean_KB"] + kw * hbm["WRITE_SIZE"]["mean_KB"]) * 1024.0
+        hbm["note"] = ("FETCH_SIZE/WRITE_SIZE in KB, separate --pmc passes (TCC slot limit), means over the launches of "
+                       "btrapz::ipm_solve_kernel.  bytes_per_launch = fetch_factor x FETCH_SIZE + write_factor x WRITE_SIZE with the "
+                       "factors measured by tools/fetch_calib.hip on known byte counts in the kernel's access widths "
+                       "(calibration); bytes_per_launch_raw is the uncorrected sum.")
         json.dump(hbm, open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 
     sq = {k: v["mean"] for k, v in c.items() if k.startswith("SQ_") or k.startswith("GRBM")}
@@ -96,7 +127,7 @@ def main():
                             f64.get("SQ_INSTS_VALU_ADD_F64", 0) + f64.get("SQ_INSTS_VALU_TRANS_F64", 0))
             derived["fp64_flops_per_launch_all_lanes"] = flops
             derived["fp64_share_of_valu_instructions"] = sum(f64.values()) / sq["SQ_INSTS_VALU"]
-        json.dump(dict(kernel=KERNEL, workload=wl, per_launch=sq, derived=derived,
+        json.dump(dict(kernel=KERNEL, workload=wl, kernel_source_hash=stamp, per_launch=sq, derived=derived,
                        note="rocprofv3 --pmc passes (tools/collect_profiles.sh), means over the launches of one "
                             "bench.py --steps 3 --warmup 1 run; SQ cycle counters are in units of 4 clock cycles."),
                   open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)
