@@ -89,7 +89,9 @@ __global__ void mqm_table_kernel(MqmWeights w, double *out);
 __global__ void finalize_kernel(int B, const double *axis_obj, const int *axis_status, const int *axis_iters,
                                 double *cost, int *status, int *iters);
 __global__ void argmin_kernel(int group, long long index_base, const double *cost, long long *best_idx,
-                              double *best_cost);
+                              double *best_cost, double *part_cost, long long *part_idx);
+__global__ void argmin_final_kernel(int chunks, long long index_base, const double *part_cost, const long long *part_idx,
+                                    long long *best_idx, double *best_cost);
 __global__ void eval_states_kernel(int B, int seg_stride, const int *seg_count, const double *seg, const double *ctrl,
                                    int n_times, const double *times, double *x);
 __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, double delta, const double *seg,

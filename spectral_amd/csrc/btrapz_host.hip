@@ -57,6 +57,7 @@ struct btrapz_ctx {
   // The workspaces above serve one launch sequence at a time.  Launches of one context issued on DIFFERENT streams are
   // ordered behind each other with this event (recorded after every sequence, waited for when the stream changes).
   hipEvent_t ws_free = nullptr; hipStream_t ws_stream = nullptr; bool ws_used = false;
+  double *d_argmin_cost = nullptr; long long *d_argmin_idx = nullptr; size_t argmin_cap = 0;   // partial arg-mins
   int *d_rescue = nullptr; size_t rescue_cap = 0;
   int *d_rescue_meta = nullptr;
   // staging for the host-pointer wrapper
@@ -101,7 +102,7 @@ BTRAPZ_EXPORT int btrapz_destroy(btrapz_ctx *c) {
   (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters);
   (void)hipFree(c->d_mqm); (void)hipFree(c->d_stage); (void)hipFree(c->d_istage);
   (void)hipFree(c->d_order); (void)hipFree(c->d_meta); (void)hipFree(c->d_retry);
-  (void)hipFree(c->d_rescue); (void)hipFree(c->d_rescue_meta);
+  (void)hipFree(c->d_rescue); (void)hipFree(c->d_rescue_meta); (void)hipFree(c->d_argmin_cost); (void)hipFree(c->d_argmin_idx);
   if (c->ws_free) (void)hipEventDestroy(c->ws_free);
   delete c;
   return BTRAPZ_OK;
@@ -348,8 +349,30 @@ BTRAPZ_EXPORT int btrapz_argmin_device(btrapz_ctx *c, int B, int group, long lon
   if (!c) return BTRAPZ_EINVAL;
   if (B < 1 || group < 1 || B % group != 0 || !cost || !best_idx || !best_cost) { c->err = "invalid argument"; return BTRAPZ_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
-  hipLaunchKernelGGL(argmin_kernel, dim3(B / group), dim3(256), 0, (hipStream_t)stream_, group, index_base, cost,
-                     best_idx, best_cost);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int groups = B / group;
+  // large groups are split over several blocks (a single block over 65 536 costs is latency-bound)
+  int chunks = group >= 8192 ? (group + 1023) / 1024 : 1;
+  if (chunks > 256) chunks = 256;
+  if (chunks > 1) {
+    const size_t need = (size_t)groups * chunks;
+    if (need > c->argmin_cap) {
+      (void)hipFree(c->d_argmin_cost); (void)hipFree(c->d_argmin_idx);
+      c->d_argmin_cost = nullptr; c->d_argmin_idx = nullptr; c->argmin_cap = 0;
+      HIPCHK(c, hipMalloc(&c->d_argmin_cost, sizeof(double) * need));
+      HIPCHK(c, hipMalloc(&c->d_argmin_idx, sizeof(long long) * need));
+      c->argmin_cap = need;
+    }
+    if (c->ws_used && stream != c->ws_stream) HIPCHK(c, hipStreamWaitEvent(stream, c->ws_free, 0));
+  }
+  hipLaunchKernelGGL(argmin_kernel, dim3(chunks, groups), dim3(256), 0, stream, group, index_base, cost, best_idx, best_cost,
+                     c->d_argmin_cost, c->d_argmin_idx);
+  if (chunks > 1) {
+    hipLaunchKernelGGL(argmin_final_kernel, dim3(groups), dim3(256), 0, stream, chunks, index_base,
+                       (const double *)c->d_argmin_cost, (const long long *)c->d_argmin_idx, best_idx, best_cost);
+    c->ws_stream = stream; c->ws_used = true;
+    HIPCHK(c, hipEventRecord(c->ws_free, stream));
+  }
   HIPCHK(c, hipGetLastError());
   return BTRAPZ_OK;
 }

@@ -147,6 +147,10 @@ enum { L_LL = 0, L_LU = 18, L_ISL = 36, L_ISU = 54, L_RED = 72, L_ROWS = 76 };
 struct Red4 { double a, b, c, d; };
 enum { RB = 10 };   // entries read per batch (pairs of lanes, see group_reduce): 20 segments = 1 batch
 template <int OP> __device__ __forceinline__ double red_init() { return OP == 0 ? 0.0 : OP == 1 ? -1e300 : 1e300; }
+// (max / min of values that come back from LDS or a DPP move carry a v_max_f64 x, x, x each -- IEEE-mode
+// canonicalisation the compiler cannot prove away, ~90 instructions per iteration.  Writing the instruction as inline
+// asm removes them and costs far more: the "v" constraints pin operands that now live in AGPRs and the allocator
+// answers with 476 B of scratch per lane, 5.57 -> 8.27 ms.  Measured, rejected.)
 template <int OP> __device__ __forceinline__ double red_op(double acc, double v, bool in_range) {
   if constexpr (OP == 0) return acc + (in_range ? v : 0.0);   // padded slots repeat entry S-1: harmless for max/min
   else if constexpr (OP == 1) return fmax(acc, v);
@@ -918,32 +922,58 @@ __global__ void finalize_kernel(int B, const double *axis_obj, const int *axis_s
   if (iters) iters[b] = axis_iters[2 * b] > axis_iters[2 * b + 1] ? axis_iters[2 * b] : axis_iters[2 * b + 1];
 }
 
-// ---- arg-min over contiguous groups: one block per group, ties -> lowest index -------------
+// ---- arg-min over contiguous groups, ties -> lowest index ----------------------------------------------
+// One block per (group, chunk of the group): a group of 65 536 candidates read by ONE block is latency-bound (68 us);
+// split over 64 blocks and finished by argmin_final_kernel it takes a few.  The result does not depend on the split:
+// the comparison (cost, then lowest index) is a total order.
+__device__ __forceinline__ bool argmin_better(double c2, long long i2, double c1, long long i1) {
+  return c2 < c1 || (c2 == c1 && i2 >= 0 && (i1 < 0 || i2 < i1));
+}
+__device__ __forceinline__ void argmin_block_reduce(double &bc, long long &bi, double *sc, long long *si) {
+  sc[threadIdx.x] = bc; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s && argmin_better(sc[threadIdx.x + s], si[threadIdx.x + s], sc[threadIdx.x], si[threadIdx.x])) {
+      sc[threadIdx.x] = sc[threadIdx.x + s]; si[threadIdx.x] = si[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  bc = sc[0]; bi = si[0];
+}
+// grid = (chunks, groups); chunks == 1: writes the result; else partial results part_cost / part_idx [groups][chunks]
 __global__ __launch_bounds__(256) void argmin_kernel(int group, long long index_base, const double *cost,
-                                                      long long *best_idx, double *best_cost) {
+                                                      long long *best_idx, double *best_cost, double *part_cost,
+                                                      long long *part_idx) {
+  __shared__ double sc[256];
+  __shared__ long long si[256];
+  const long long g = blockIdx.y;
+  const int chunks = gridDim.x, per = (group + chunks - 1) / chunks;
+  const int lo = blockIdx.x * per, hi = lo + per < group ? lo + per : group;
+  double bc = __builtin_huge_val();
+  long long bi = -1;
+  for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+    const double c = cost[g * group + j];
+    if (c < bc) { bc = c; bi = g * group + j; }
+  }
+  argmin_block_reduce(bc, bi, sc, si);
+  if (threadIdx.x == 0) {
+    if (chunks == 1) { best_idx[g] = bi >= 0 ? bi + index_base : -1; best_cost[g] = bc; }
+    else { part_cost[g * chunks + blockIdx.x] = bc; part_idx[g * chunks + blockIdx.x] = bi; }
+  }
+}
+__global__ __launch_bounds__(256) void argmin_final_kernel(int chunks, long long index_base, const double *part_cost,
+                                                            const long long *part_idx, long long *best_idx, double *best_cost) {
   __shared__ double sc[256];
   __shared__ long long si[256];
   const long long g = blockIdx.x;
   double bc = __builtin_huge_val();
   long long bi = -1;
-  for (int j = threadIdx.x; j < group; j += blockDim.x) {
-    const double c = cost[g * group + j];
-    if (c < bc) { bc = c; bi = g * group + j; }
+  for (int j = threadIdx.x; j < chunks; j += blockDim.x) {
+    const double c = part_cost[g * chunks + j]; const long long i = part_idx[g * chunks + j];
+    if (argmin_better(c, i, bc, bi)) { bc = c; bi = i; }
   }
-  sc[threadIdx.x] = bc; si[threadIdx.x] = bi;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-      const double c2 = sc[threadIdx.x + s]; const long long i2 = si[threadIdx.x + s];
-      const double c1 = sc[threadIdx.x]; const long long i1 = si[threadIdx.x];
-      if (c2 < c1 || (c2 == c1 && i2 >= 0 && (i1 < 0 || i2 < i1))) { sc[threadIdx.x] = c2; si[threadIdx.x] = i2; }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    best_idx[g] = si[0] >= 0 ? si[0] + index_base : -1;
-    best_cost[g] = sc[0];
-  }
+  argmin_block_reduce(bc, bi, sc, si);
+  if (threadIdx.x == 0) { best_idx[g] = bi >= 0 ? bi + index_base : -1; best_cost[g] = bc; }
 }
 
 // ---- state of solved trajectories at arbitrary times (warm start of the next replanning step) ----------
