@@ -98,8 +98,17 @@ __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, doubl
                               const double *init, const double *ctrl, int nsel, const long long *sel, int max_points,
                               double *out, int *npoints);
 
+__global__ void single_candidate_kernel(const KernelArgs a, const double *__restrict__ mqm, double delta, int max_points,
+                                        double *out);
+
 }  // namespace btrapz
 
 // library-internal: the HIP device a context lives on
 int btrapz_ctx_device(const btrapz_ctx *ctx);
+// library-internal: find_traj's single-candidate path.  One launch on the null stream; in and out may be host memory
+// mapped into the device.  in: seg[17 S] init[6] ref_end[2] dl[10] mqm[168]; out: cost, status|iters, np, ctrl[12 S],
+// traj[6 max_points].  The M'QM table comes from the caller (btrapz_mqm_table_host).
+int btrapz_launch_single(btrapz_ctx *ctx, const btrapz_shared *shared, const btrapz_options *opt, int S, const double *in,
+                         double *out, int max_points);
+void btrapz_mqm_table_host(const btrapz_shared *shared, double *table /* [2][4][21] */);
 #endif

@@ -62,6 +62,7 @@ struct btrapz_ctx {
   int *d_rescue_meta = nullptr;
   // staging for the host-pointer wrapper
   double *d_stage = nullptr; size_t stage_cap = 0;
+  double *d_single = nullptr;       // control points of the single-candidate launch (find_traj)
   int *d_istage = nullptr; size_t istage_cap = 0;
 };
 
@@ -100,7 +101,7 @@ BTRAPZ_EXPORT int btrapz_destroy(btrapz_ctx *c) {
   if (!c) return BTRAPZ_EINVAL;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters);
-  (void)hipFree(c->d_mqm); (void)hipFree(c->d_stage); (void)hipFree(c->d_istage);
+  (void)hipFree(c->d_mqm); (void)hipFree(c->d_stage); (void)hipFree(c->d_istage); (void)hipFree(c->d_single);
   (void)hipFree(c->d_order); (void)hipFree(c->d_meta); (void)hipFree(c->d_retry);
   (void)hipFree(c->d_rescue); (void)hipFree(c->d_rescue_meta); (void)hipFree(c->d_argmin_cost); (void)hipFree(c->d_argmin_idx);
   if (c->ws_free) (void)hipEventDestroy(c->ws_free);
@@ -118,6 +119,77 @@ static int ensure_axis_ws(btrapz_ctx *c, size_t nprob) {
   HIPCHK(c, hipMalloc(&c->d_axis_status, sizeof(int) * nprob));
   HIPCHK(c, hipMalloc(&c->d_axis_iters, sizeof(int) * nprob));
   c->axis_cap = nprob;
+  return BTRAPZ_OK;
+}
+
+// Weights, limits and iteration parameters of a launch (everything of KernelArgs that is not a pointer or a size).
+static void fill_parameters(KernelArgs &a, const btrapz_shared *sh, const btrapz_options *opt, const btrapz_warm *warm) {
+  memcpy(a.sh.w_s, sh->w_s, sizeof(a.sh.w_s)); memcpy(a.sh.w_l, sh->w_l, sizeof(a.sh.w_l));
+  a.sh.weight_end_s = sh->weight_end_s; a.sh.weight_end_l = sh->weight_end_l;
+  a.sh.ds_ref = sh->ds_ref; a.sh.dl_ref = sh->dl_ref;
+  a.sh.acc_s[0] = fmax(sh->dds[0], -1000.0); a.sh.acc_s[1] = fmin(sh->dds[1], 1000.0);  // solve_3d.cc:836,843-844
+  a.sh.acc_l[0] = sh->ddl[0]; a.sh.acc_l[1] = sh->ddl[1];
+  a.sh.jerk_s[0] = sh->ddds[0]; a.sh.jerk_s[1] = sh->ddds[1];
+  a.sh.jerk_l[0] = sh->dddl[0]; a.sh.jerk_l[1] = sh->dddl[1];
+  a.sh.variant = sh->variant;
+  a.eps = (opt && opt->eps > 0) ? opt->eps : 1e-9;
+  a.max_iter = (opt && opt->max_iter > 0) ? opt->max_iter : 60;
+  a.tau = (opt && opt->step_fraction > 0 && opt->step_fraction < 1) ? opt->step_fraction : BTRAPZ_DEFAULT_STEP_FRACTION;
+  a.tau_iters = BTRAPZ_AGGRESSIVE_ITERATIONS;
+  a.stall_start = BTRAPZ_STALL_START; a.stall_len = BTRAPZ_STALL_LENGTH;
+  a.tau_thr = (opt && opt->step_threshold > 0) ? opt->step_threshold : BTRAPZ_DEFAULT_STEP_THRESHOLD;
+  a.x0 = warm ? warm->x0 : nullptr; a.lam0 = warm ? warm->lam0 : nullptr; a.lam_out = warm ? warm->lam_out : nullptr;
+  a.mu0 = (warm && warm->mu0 > 0) ? warm->mu0 : 1e-4;
+  a.smin = (warm && warm->smin > 0) ? warm->smin : 1e-2;
+  a.elastic_delta = (opt && opt->elastic_delta > 0) ? opt->elastic_delta : BTRAPZ_DEFAULT_ELASTIC_DELTA;
+  a.elastic_tol = (opt && opt->elastic_tol > 0) ? opt->elastic_tol : BTRAPZ_DEFAULT_ELASTIC_TOL;
+  a.bucket_S = 0;
+}
+
+// M' pQp_d M on the host (solve_3d.cc:87-143): the single-candidate path hands the table over with its inputs.
+void btrapz_mqm_table_host(const btrapz_shared *sh, double *table) {
+  static const double M[6][6] = {{1, 0, 0, 0, 0, 0},      {-5, 5, 0, 0, 0, 0},      {10, -20, 10, 0, 0, 0},
+                                 {-10, 30, -30, 10, 0, 0}, {5, -20, 30, -20, 5, 0}, {-1, 5, -10, 10, -5, 1}};
+  for (int axis = 0; axis < 2; axis++) {
+    const double *w = axis == 0 ? sh->w_s : sh->w_l;
+    for (int d = 0; d < 4; d++)
+      for (int j = 0; j < 6; j++)
+        for (int i = 0; i <= j; i++) {
+          double acc = 0.0;
+          for (int a = d; a < 6; a++) {
+            double t = 0.0;
+            for (int b = d; b < 6; b++) {
+              double num = w[d];
+              for (int r = 0; r < d; r++) num *= double((a - r) * (b - r));
+              t += num / double(a + b - 2 * d + 1) * M[b][j];
+            }
+            acc += M[a][i] * t;
+          }
+          table[(axis * 4 + d) * 21 + j * (j + 1) / 2 + i] = acc;
+        }
+  }
+}
+
+int btrapz_launch_single(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int S, const double *in,
+                         double *out, int max_points) {
+  if (!c || !sh || S < 1 || S > BTRAPZ_MAX_SEGMENTS || !in || !out || max_points < 1) return BTRAPZ_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  KernelArgs a;
+  fill_parameters(a, sh, opt, nullptr);
+  a.B = 1; a.S = S; a.seg_stride = S; a.order = nullptr; a.seg_count = nullptr; a.cand_prefix = nullptr; a.wave_prefix = nullptr;
+  const double *mqm = in + (size_t)BTRAPZ_NUM_SEG_FIELDS * S + 18;
+  a.seg = in; a.init = in + (size_t)BTRAPZ_NUM_SEG_FIELDS * S; a.ref_end = a.init + 6; a.dl_bounds = a.ref_end + 2; a.mqm = mqm;
+  // what the kernel reads back stays in device memory: the context's per-axis records and a control-point block
+  int rc = ensure_axis_ws(c, 2);
+  if (rc != BTRAPZ_OK) return rc;
+  if (!c->d_single) HIPCHK(c, hipMalloc(&c->d_single, sizeof(double) * 12 * BTRAPZ_MAX_SEGMENTS));
+  if (c->ws_used && c->ws_stream != nullptr) HIPCHK(c, hipStreamWaitEvent(nullptr, c->ws_free, 0));
+  a.axis_obj = c->d_axis_obj; a.axis_status = c->d_axis_status; a.axis_iters = c->d_axis_iters;
+  a.ctrl = c->d_single;
+  hipLaunchKernelGGL(single_candidate_kernel, dim3(1), dim3(128), 0, (hipStream_t) nullptr, a, mqm, sh->delta, max_points, out);
+  c->ws_stream = nullptr; c->ws_used = true;
+  HIPCHK(c, hipEventRecord(c->ws_free, nullptr));
+  HIPCHK(c, hipGetLastError());
   return BTRAPZ_OK;
 }
 
@@ -149,33 +221,14 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     memcpy(c->h_mqm_w, wkey, sizeof(wkey));
   }
   KernelArgs a;
+  fill_parameters(a, sh, opt, warm);
   a.B = B; a.S = S; a.seg_stride = S; a.order = nullptr; a.seg_count = nullptr; a.cand_prefix = nullptr; a.wave_prefix = nullptr;
   a.seg = seg; a.init = init; a.ref_end = ref_end; a.dl_bounds = dl_bounds; a.mqm = c->d_mqm;
   a.ctrl = ctrl; a.axis_obj = c->d_axis_obj; a.axis_status = c->d_axis_status; a.axis_iters = c->d_axis_iters;
-  memcpy(a.sh.w_s, sh->w_s, sizeof(a.sh.w_s)); memcpy(a.sh.w_l, sh->w_l, sizeof(a.sh.w_l));
-  a.sh.weight_end_s = sh->weight_end_s; a.sh.weight_end_l = sh->weight_end_l;
-  a.sh.ds_ref = sh->ds_ref; a.sh.dl_ref = sh->dl_ref;
-  a.sh.acc_s[0] = fmax(sh->dds[0], -1000.0); a.sh.acc_s[1] = fmin(sh->dds[1], 1000.0);  // solve_3d.cc:836,843-844
-  a.sh.acc_l[0] = sh->ddl[0]; a.sh.acc_l[1] = sh->ddl[1];
-  a.sh.jerk_s[0] = sh->ddds[0]; a.sh.jerk_s[1] = sh->ddds[1];
-  a.sh.jerk_l[0] = sh->dddl[0]; a.sh.jerk_l[1] = sh->dddl[1];
-  a.sh.variant = sh->variant;
-  a.eps = (opt && opt->eps > 0) ? opt->eps : 1e-9;
-  a.max_iter = (opt && opt->max_iter > 0) ? opt->max_iter : 60;
-  a.tau = (opt && opt->step_fraction > 0 && opt->step_fraction < 1) ? opt->step_fraction : BTRAPZ_DEFAULT_STEP_FRACTION;
-  a.tau_iters = BTRAPZ_AGGRESSIVE_ITERATIONS;
-  a.stall_start = BTRAPZ_STALL_START; a.stall_len = BTRAPZ_STALL_LENGTH;
-  a.tau_thr = (opt && opt->step_threshold > 0) ? opt->step_threshold : BTRAPZ_DEFAULT_STEP_THRESHOLD;
-  a.x0 = warm ? warm->x0 : nullptr; a.lam0 = warm ? warm->lam0 : nullptr; a.lam_out = warm ? warm->lam_out : nullptr;
-  a.mu0 = (warm && warm->mu0 > 0) ? warm->mu0 : 1e-4;
-  a.smin = (warm && warm->smin > 0) ? warm->smin : 1e-2;
   const int elastic = opt ? opt->elastic : 0;
   if (elastic < 0 || elastic > 2) { c->err = "invalid argument: btrapz_options.elastic"; return BTRAPZ_EINVAL; }
-  a.elastic_delta = (opt && opt->elastic_delta > 0) ? opt->elastic_delta : BTRAPZ_DEFAULT_ELASTIC_DELTA;
-  a.elastic_tol = (opt && opt->elastic_tol > 0) ? opt->elastic_tol : BTRAPZ_DEFAULT_ELASTIC_TOL;
   unsigned blocks;
   const int *hint = (warm && !seg_count) ? warm->hint : nullptr;   // uniform batches only
-  a.bucket_S = 0;
   if (seg_count || hint) {
     if ((size_t)B > c->order_cap) {
       (void)hipFree(c->d_order); c->d_order = nullptr; c->order_cap = 0;

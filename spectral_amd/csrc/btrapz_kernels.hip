@@ -204,15 +204,15 @@ __device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gb
 // lambda_l)) leaves the same iteration with three changes per row: the row value is g'c - delta (lambda_u - lambda_l),
 // the row's weight in the Newton matrix is w / (1 + delta w), and the step of the row value is
 // (g'dc - delta b) / (1 + delta w), b the row's entry of the right-hand side.  delta = 0 is the plain method.
+// wave_id: the wavefront's number in the launch (wavefront w solves axis w & 1 of the candidates of pair w >> 1);
+// lds: this wavefront's private [L_ROWS][64] block of LDS; lane: 0..63.
 template <bool WARM, bool ORDERED, bool ELASTIC = false>
-__device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double *__restrict__ mqm) {
+__device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double *__restrict__ mqm, double (*lds)[64],
+                                               const int wave_id, const int lane) {
   constexpr bool CACHE_RP = !WARM && !ELASTIC;   // see the main loop
-  __shared__ double lds[L_ROWS][64];
-
-  const int lane = threadIdx.x;
-  // wave w solves axis (w & 1) of gpw consecutive candidates: the axis is wave-uniform
-  const int axis = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 1));
-  int S, pair = (int)(blockIdx.x >> 1), ncand = a.B, cand0 = 0;
+  // the axis is wave-uniform
+  const int axis = __builtin_amdgcn_readfirstlane(wave_id & 1);
+  int S, pair = wave_id >> 1, ncand = a.B, cand0 = 0;
   if constexpr (ORDERED) {
     // ragged batch: candidates are bucketed by segment count; find this wave's bucket (wave-uniform)
     // (rescue pass: one set of tables and one candidate list per axis, the stalled axis problems only)
@@ -844,20 +844,25 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 // Four instantiations: {cold, warm start} x {candidates in memory order, candidates through a.order (ragged batches
 // and scheduling hints)}.  The bench path is the first; keeping the others out of it keeps its register allocation.
 __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const double *__restrict__ mqm) {
-  ipm_solve_body<false, false>(a, mqm);
+  __shared__ double lds[L_ROWS][64];
+  ipm_solve_body<false, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 __global__ __launch_bounds__(64) void ipm_solve_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
-  ipm_solve_body<false, true>(a, mqm);
+  __shared__ double lds[L_ROWS][64];
+  ipm_solve_body<false, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 __global__ __launch_bounds__(64) void ipm_solve_warm_kernel(const KernelArgs a, const double *__restrict__ mqm) {
-  ipm_solve_body<true, false>(a, mqm);
+  __shared__ double lds[L_ROWS][64];
+  ipm_solve_body<true, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 __global__ __launch_bounds__(64) void ipm_solve_warm_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
-  ipm_solve_body<true, true>(a, mqm);
+  __shared__ double lds[L_ROWS][64];
+  ipm_solve_body<true, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 // Rescue pass (btrapz_options.elastic): the stalled axis problems, listed per axis, with elastic rows.
 __global__ __launch_bounds__(64) void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm) {
-  ipm_solve_body<false, true, true>(a, mqm);
+  __shared__ double lds[L_ROWS][64];
+  ipm_solve_body<false, true, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 // keys of the rescue lists: key[axis][b] = segment count of candidate b when that axis problem stalled, else 0
 __global__ void rescue_keys_kernel(int B, int S, const int *seg_count, const int *axis_status, int *keys, int all) {
@@ -1015,23 +1020,15 @@ __global__ void eval_states_kernel(int B, int seg_stride, const int *seg_count, 
 }
 
 // ---- Bernstein sampling of selected candidates (solve_3d.cc:1279-1392) ---------------------
-// one block per selected candidate; thread = sample point.
-__global__ void sample_kernel(int B, int seg_stride, const int *seg_count, double delta, const double *seg,
-                              const double *init, const double *ctrl, int nsel, const long long *sel, int max_points,
-                              double *out, int *npoints) {
-  const int j = blockIdx.x;
-  if (j >= nsel) return;
-  const long long b = sel[j];
-  double *o = out + (size_t)j * 6 * max_points;
-  if (b < 0 || b >= B) { if (threadIdx.x == 0) npoints[j] = 0; return; }
-  const int S = seg_count ? seg_count[b] : seg_stride;
-  if (S < 1 || S > seg_stride) { if (threadIdx.x == 0) npoints[j] = 0; return; }
+// Samples of candidate b, written by threads tid, tid + nthreads, ...; returns the sample count.
+__device__ __forceinline__ int sample_candidate(int B, int seg_stride, int S, double delta, const double *seg,
+                                                const double *init, const double *ctrl, long long b, int max_points,
+                                                double *o, int tid, int nthreads) {
   const size_t BS = (size_t)B * seg_stride;
   // num_of_points_: int accumulated with += double (solve_3d.cc:1279-1282)
   int np = 1;
   for (int k = 0; k < S; k++) np = (int)((double)np + seg[BTRAPZ_F_T * BS + b * seg_stride + k] / delta);
-  if (threadIdx.x == 0) npoints[j] = np;
-  if (threadIdx.x == 0 && max_points > 0) {
+  if (tid == 0 && max_points > 0) {
     UNROLL for (int a = 0; a < 6; a++) o[(size_t)a * max_points] = init[b * 6 + a];
   }
   const double bc0[6] = {1, 5, 10, 10, 5, 1}, bc1[5] = {1, 4, 6, 4, 1}, bc2[4] = {1, 3, 3, 1};
@@ -1039,7 +1036,7 @@ __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, doubl
   for (int k = 0; k < S; k++) {
     const double t = seg[BTRAPZ_F_T * BS + b * seg_stride + k];
     const int linter = (int)(t / delta);  // :1351
-    for (int l = 1 + (int)threadIdx.x; l <= linter; l += blockDim.x) {
+    for (int l = 1 + tid; l <= linter; l += nthreads) {
       const int vi = base + l - 1;
       if (vi >= max_points) continue;
       const double tau = (double)l / (double)linter, om = 1.0 - tau;
@@ -1058,6 +1055,53 @@ __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, doubl
       }
     }
     base += linter;
+  }
+  return np;
+}
+// one block per selected candidate; thread = sample point.
+__global__ void sample_kernel(int B, int seg_stride, const int *seg_count, double delta, const double *seg,
+                              const double *init, const double *ctrl, int nsel, const long long *sel, int max_points,
+                              double *out, int *npoints) {
+  const int j = blockIdx.x;
+  if (j >= nsel) return;
+  const long long b = sel[j];
+  double *o = out + (size_t)j * 6 * max_points;
+  if (b < 0 || b >= B) { if (threadIdx.x == 0) npoints[j] = 0; return; }
+  const int S = seg_count ? seg_count[b] : seg_stride;
+  if (S < 1 || S > seg_stride) { if (threadIdx.x == 0) npoints[j] = 0; return; }
+  const int np = sample_candidate(B, seg_stride, S, delta, seg, init, ctrl, b, max_points, o, (int)threadIdx.x, (int)blockDim.x);
+  if (threadIdx.x == 0) npoints[j] = np;
+}
+
+// ---- ONE candidate, ONE launch (find_traj: the reference's call pattern, cart_frenet.py:1567) ---------------------
+// Two wavefronts solve the two axes side by side, then the workgroup merges their status, evaluates the acceptance
+// test and samples the trajectory: what btrapz_solve_batch_device + finalize_kernel + sample_kernel do in three
+// launches.  The inputs (a.seg, a.init, ..., mqm) and out may be host memory mapped into the device -- inputs are read
+// once, results written once -- so the call needs no copy either; what the kernel reads back (control points, per-axis
+// records) lives in device memory (a.ctrl, a.axis_*).  out: [0] cost, [1] status and iterations (two ints), [2]
+// sample count (int), [3 .. 3 + 12 S) control points, then traj [6][max_points].
+__global__ __launch_bounds__(128) void single_candidate_kernel(const KernelArgs a, const double *__restrict__ mqm,
+                                                               double delta, int max_points, double *out) {
+  double *res = out, *traj = out + 3 + 12 * a.S;
+  __shared__ double lds[2][L_ROWS][64];
+  const int w = (int)threadIdx.x >> 6;
+  ipm_solve_body<false, false>(a, mqm, lds[w], w, (int)threadIdx.x & 63);
+  __threadfence_block();
+  __syncthreads();
+  const int s0 = a.axis_status[0], s1 = a.axis_status[1];
+  int st;
+  if (s0 == BTRAPZ_SOLVED && s1 == BTRAPZ_SOLVED) st = BTRAPZ_SOLVED;
+  else if (s0 > 0 && s1 > 0) st = BTRAPZ_SOLVED_INACCURATE;
+  else st = s0 < s1 ? s0 : s1;
+  const double c = a.axis_obj[0] + a.axis_obj[1];
+  int np = 0;
+  if (st > 0) np = sample_candidate(1, a.seg_stride, a.S, delta, a.seg, a.init, a.ctrl, 0, max_points, traj, (int)threadIdx.x, 128);
+  for (int i = (int)threadIdx.x; i < 12 * a.S; i += 128) out[3 + i] = a.ctrl[i];
+  if (threadIdx.x == 0) {
+    res[0] = (st > 0 && c == c) ? c : __builtin_huge_val();
+    int *ri = reinterpret_cast<int *>(res + 1);
+    ri[0] = st; ri[1] = a.axis_iters[0] > a.axis_iters[1] ? a.axis_iters[0] : a.axis_iters[1];
+    reinterpret_cast<int *>(res + 2)[0] = np;
   }
 }
 

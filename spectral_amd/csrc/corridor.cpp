@@ -4,7 +4,8 @@
 #include "corridor_core.h"
 
 #include <algorithm>
-#include <fstream>
+#include <cstdio>
+#include <cstdlib>
 
 namespace btrapz {
 
@@ -13,16 +14,38 @@ namespace btrapz {
 // extraction every later one is a no-op that leaves its target untouched
 // (src/c_road_s1_2.txt has a short last row and relies on this).  TokenReader mirrors it.
 namespace {
+// The whole file is read at once and scanned with strtod / strtol (the stream extraction it replaces spent 0.1 ms on
+// the ~1000 tokens of a corridor file -- as long as the solve).
 class TokenReader {
  public:
-  explicit TokenReader(const std::string &path) : in_(path) {}
-  bool open() const { return in_.is_open(); }
-  void get(double &v) { double t; if (!failed_ && (in_ >> t)) v = t; else failed_ = true; }
-  void get(int &v) { int t; if (!failed_ && (in_ >> t)) v = t; else failed_ = true; }
+  explicit TokenReader(const std::string &path) {
+    if (FILE *f = fopen(path.c_str(), "rb")) {
+      open_ = true;
+      char chunk[1 << 14];
+      size_t n;
+      while ((n = fread(chunk, 1, sizeof(chunk), f)) > 0) buf_.append(chunk, n);
+      fclose(f);
+    }
+    p_ = buf_.c_str();
+  }
+  bool open() const { return open_; }
+  void get(double &v) {
+    if (failed_) return;
+    char *end = nullptr;
+    const double t = strtod(p_, &end);
+    if (end == p_) failed_ = true; else { v = t; p_ = end; }
+  }
+  void get(int &v) {
+    if (failed_) return;
+    char *end = nullptr;
+    const long t = strtol(p_, &end, 10);
+    if (end == p_) failed_ = true; else { v = (int)t; p_ = end; }
+  }
   bool failed() const { return failed_; }
  private:
-  std::ifstream in_;
-  bool failed_ = false;
+  std::string buf_;
+  const char *p_ = nullptr;
+  bool open_ = false, failed_ = false;
 };
 }  // namespace
 

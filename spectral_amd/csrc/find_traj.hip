@@ -34,7 +34,10 @@ const char *kDefaultOutputPrefix[2] = {"/home/srujan_d/RISS/code/btrapz/src/s1_s
 std::mutex g_ctx_mutex;
 std::mutex g_run_mutex;  // the shared context's workspace serves one find_traj at a time
 btrapz_ctx *g_ctx = nullptr;
-void *g_scratch = nullptr;        // device block of find_traj's single-candidate launches (under g_run_mutex)
+// (all under g_run_mutex)
+void *g_pinned = nullptr, *g_pinned_dev = nullptr;   // pinned host block of the single-candidate launch and its device mapping
+size_t g_pinned_bytes = 0;
+void *g_scratch = nullptr;        // device block of the rescue attempt
 size_t g_scratch_bytes = 0;
 
 btrapz_ctx *shared_ctx() {
@@ -197,58 +200,76 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   // A btrapz_ctx is not thread-safe (its per-axis workspace is shared by every launch): concurrent callers of
   // find_traj queue here.  The reference's own calls only ever race on the output file.
   std::lock_guard<std::mutex> run_lock(g_run_mutex);
-  // the scratch block below must live on the context's device whatever the calling thread's current device is
+  // the buffers below must belong to the context's device whatever the calling thread's current device is
   if (hipSetDevice(btrapz_ctx_device(ctx)) != hipSuccess) return FAIL;
-  // One persistent device block and one pinned-size host block, laid out as doubles:
-  //   in : seg[17 S] init[6] ref_end[2] dl[10] sel[1]            (one H2D copy)
-  //   out: cost[1] status,iters[1] np[1] ctrl[12 S] traj[6 max_points]   (one D2H copy)
-  const size_t n_in = (size_t)BTRAPZ_NUM_SEG_FIELDS * S + 6 + 2 + 10 + 1;
+  // One pinned host block, mapped into the device, laid out as doubles:
+  //   in : seg[17 S] init[6] ref_end[2] dl[10] mqm[168]
+  //   out: cost[1] status,iters[1] np[1] ctrl[12 S] traj[6 max_points]
+  // First attempt: ONE launch that reads the inputs and writes the results through the mapping -- no copy calls, no
+  // second and third launch (btrapz_launch_single).  Only a stalled solve takes the batched entry points below.
+  const size_t n_in = (size_t)BTRAPZ_NUM_SEG_FIELDS * S + 6 + 2 + 10 + 168;
   const size_t n_out = 3 + (size_t)12 * S + (size_t)6 * max_points;
-  if ((n_in + n_out) * 8 > g_scratch_bytes) {
-    if (g_scratch) (void)hipFree(g_scratch);
-    g_scratch = nullptr; g_scratch_bytes = 0;
+  if ((n_in + n_out) * 8 > g_pinned_bytes) {
+    if (g_pinned) (void)hipHostFree(g_pinned);
+    g_pinned = nullptr; g_pinned_dev = nullptr; g_pinned_bytes = 0;
     const size_t want = (n_in + n_out) * 8 * 2;
-    if (hipMalloc(&g_scratch, want) != hipSuccess) return FAIL;
-    g_scratch_bytes = want;
+    if (hipHostMalloc(&g_pinned, want, hipHostMallocMapped) != hipSuccess) return FAIL;
+    if (hipHostGetDevicePointer(&g_pinned_dev, g_pinned, 0) != hipSuccess) { (void)hipHostFree(g_pinned); g_pinned = nullptr; return FAIL; }
+    g_pinned_bytes = want;
   }
-  double *d_in = static_cast<double *>(g_scratch), *d_out_blk = d_in + n_in;
-  double *d_seg = d_in, *d_init = d_seg + (size_t)BTRAPZ_NUM_SEG_FIELDS * S, *d_re = d_init + 6, *d_dl = d_re + 2;
-  long long *d_sel = reinterpret_cast<long long *>(d_dl + 10);
-  double *d_cost = d_out_blk;
-  int *d_status = reinterpret_cast<int *>(d_out_blk + 1), *d_np = reinterpret_cast<int *>(d_out_blk + 2);
-  double *d_ctrl = d_out_blk + 3, *d_traj = d_ctrl + (size_t)12 * S;
-  std::vector<double> h_in(n_in), h_out(n_out);
-  std::copy(h_seg.begin(), h_seg.end(), h_in.begin());
-  std::copy(h_init.begin(), h_init.end(), h_in.begin() + (d_init - d_in));
-  std::copy(h_ref_end.begin(), h_ref_end.end(), h_in.begin() + (d_re - d_in));
-  std::copy(h_dl.begin(), h_dl.end(), h_in.begin() + (d_dl - d_in));
-  const long long sel0 = 0;
-  memcpy(&h_in[n_in - 1], &sel0, 8);
-  if (hipMemcpy(d_in, h_in.data(), n_in * 8, hipMemcpyHostToDevice) != hipSuccess) return FAIL;
+  double *h_in = static_cast<double *>(g_pinned), *h_out = h_in + n_in;
+  double *d_in = static_cast<double *>(g_pinned_dev), *d_out = d_in + n_in;
+  std::copy(h_seg.begin(), h_seg.end(), h_in);
+  double *p_init = h_in + (size_t)BTRAPZ_NUM_SEG_FIELDS * S;
+  std::copy(h_init.begin(), h_init.end(), p_init);
+  std::copy(h_ref_end.begin(), h_ref_end.end(), p_init + 6);
+  std::copy(h_dl.begin(), h_dl.end(), p_init + 8);
+  btrapz_mqm_table_host(&sh, p_init + 18);
   int h_status[2] = {0, 0}, h_np = 0;
   double h_cost = 0.0;
-  // Second attempt only when the first one stalled (no solution to converge to: a marginally infeasible corridor):
-  // the rescue pass of btrapz_options.elastic, the counterpart of the reference accepting OSQP's status 2.
   const ElasticEnv el = elastic_env();
-  for (int attempt = 0; attempt < 2; attempt++) {
+  if (btrapz_launch_single(ctx, &sh, nullptr, S, d_in, d_out, max_points) != BTRAPZ_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
+    fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
+    return FAIL;
+  }
+  h_cost = h_out[0];
+  memcpy(h_status, &h_out[1], 8);
+  memcpy(&h_np, &h_out[2], 4);
+  if (h_status[0] == BTRAPZ_MAX_ITER_REACHED && el.on) {
+    // Second attempt (no solution to converge to: a marginally infeasible corridor): the rescue pass of
+    // btrapz_options.elastic, the counterpart of the reference accepting OSQP's status 2.  Rare, so it simply goes
+    // through the batched entry points on a device copy of the inputs.
+    if (verbose()) fprintf(stderr, "btrapz: S=%d stalled after %d iterations, rescue pass\n", S, h_status[1]);
+    const size_t n_dev = n_in + n_out + 1;
+    if (n_dev * 8 > g_scratch_bytes) {
+      if (g_scratch) (void)hipFree(g_scratch);
+      g_scratch = nullptr; g_scratch_bytes = 0;
+      if (hipMalloc(&g_scratch, n_dev * 8 * 2) != hipSuccess) return FAIL;
+      g_scratch_bytes = n_dev * 8 * 2;
+    }
+    double *s_in = static_cast<double *>(g_scratch), *s_out = s_in + n_in + 1;
+    double *s_init = s_in + (size_t)BTRAPZ_NUM_SEG_FIELDS * S;
+    long long *s_sel = reinterpret_cast<long long *>(s_in + n_in);
+    int *s_status = reinterpret_cast<int *>(s_out + 1), *s_np = reinterpret_cast<int *>(s_out + 2);
+    const long long sel0 = 0;
+    if (hipMemcpy(s_in, h_in, n_in * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(s_sel, &sel0, 8, hipMemcpyHostToDevice) != hipSuccess) return FAIL;
     btrapz_options opt = {};
-    opt.elastic = attempt; opt.elastic_tol = el.tol;
-    if (btrapz_solve_batch_device(ctx, &sh, &opt, 1, S, d_seg, d_init, d_re, d_dl, d_ctrl, d_cost, d_status, d_status + 1,
-                                  nullptr) != BTRAPZ_OK ||
-        btrapz_sample_device(ctx, 1, S, in.delta, d_seg, d_init, d_ctrl, 1, d_sel, max_points, d_traj, d_np, nullptr) !=
-            BTRAPZ_OK) {
+    opt.elastic = 1; opt.elastic_tol = el.tol;
+    if (btrapz_solve_batch_device(ctx, &sh, &opt, 1, S, s_in, s_init, s_init + 6, s_init + 8, s_out + 3, s_out, s_status,
+                                  s_status + 1, nullptr) != BTRAPZ_OK ||
+        btrapz_sample_device(ctx, 1, S, in.delta, s_in, s_init, s_out + 3, 1, s_sel, max_points, s_out + 3 + 12 * S, s_np,
+                             nullptr) != BTRAPZ_OK) {
       fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
       return FAIL;
     }
     // (a blocking copy on the null stream waits for the launches before it)
-    if (hipMemcpy(h_out.data(), d_out_blk, n_out * 8, hipMemcpyDeviceToHost) != hipSuccess) return FAIL;
+    if (hipMemcpy(h_out, s_out, n_out * 8, hipMemcpyDeviceToHost) != hipSuccess) return FAIL;
     h_cost = h_out[0];
     memcpy(h_status, &h_out[1], 8);
     memcpy(&h_np, &h_out[2], 4);
-    if (h_status[0] != BTRAPZ_MAX_ITER_REACHED || !el.on) break;
-    if (verbose() && attempt == 0) fprintf(stderr, "btrapz: S=%d stalled after %d iterations, rescue pass\n", S, h_status[1]);
   }
-  std::vector<double> out(h_out.begin() + 3 + 12 * S, h_out.end());
+  std::vector<double> out(h_out + 3 + 12 * S, h_out + n_out);
   if (verbose()) fprintf(stderr, "btrapz: S=%d status=%d iters=%d obj=%.9g\n", S, h_status[0], h_status[1], h_cost);
   // acceptance: solve_3d.cc:1251-1277
   if (h_status[0] != BTRAPZ_SOLVED && h_status[0] != BTRAPZ_SOLVED_INACCURATE) return FAIL;
@@ -259,7 +280,7 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   const double cost = trajectory_cost(variant, *p, in, max_points, s, ds, dds, l, dl, ddl);
 
   res.S = S; res.np = max_points; res.out = std::move(out);
-  res.ctrl.assign(h_out.begin() + 3, h_out.begin() + 3 + 12 * S);
+  res.ctrl.assign(h_out + 3, h_out + 3 + 12 * S);
   return cost;
 }
 
@@ -290,8 +311,15 @@ BTRAPZ_EXPORT double btrapz_find_traj(int variant, const char *input_path, const
 
   // trajectory file: trp_wrapper.cpp:288-301 (fixed, 3 decimals)
   if (FILE *f = fopen(out_path.c_str(), "w")) {
-    for (int i = 0; i < max_points; i++)
-      fprintf(f, "%.3f %.3f %.3f %.3f %.3f %.3f %.3f\n", i * in.delta, s[i], l[i], ds[i], dl[i], dds[i], ddl[i]);
+    std::string text;
+    text.reserve((size_t)max_points * 64);
+    char line[256];
+    for (int i = 0; i < max_points; i++) {
+      const int n = snprintf(line, sizeof(line), "%.3f %.3f %.3f %.3f %.3f %.3f %.3f\n", i * in.delta, s[i], l[i], ds[i], dl[i],
+                             dds[i], ddl[i]);
+      if (n > 0) text.append(line, (size_t)n < sizeof(line) ? (size_t)n : sizeof(line) - 1);
+    }
+    fwrite(text.data(), 1, text.size(), f);
     fclose(f);
   } else if (verbose()) {
     fprintf(stderr, "btrapz: cannot write '%s'\n", out_path.c_str());
