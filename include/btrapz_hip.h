@@ -234,6 +234,28 @@ int btrapz_corridor_batch_device(btrapz_ctx *ctx, int variant, int B, int N, int
                                  double *seg, int *seg_count, double *ref_end, double *dl_bounds,
                                  void *stream);
 
+/* ---- obstacle prisms -> per-knot bounds -------------------------------------------------------
+ * The scene logic in front of the corridor text file, for B scenes at once: Car.getCar + get_bounds of the reference's
+ * harness (src/cart_frenet.py:664-1030, lineFromPoints :818-830).  A car is a prism in (s, l, t): centre (s0, l0, t0),
+ * constant velocities, duration T, grown by l_safe / w_safe (:694-700); the cars' lateral extents cut the road into
+ * strips, every strip becomes one "obstacle corridor" of btrapz_corridor_batch_device: per knot, the rear face of a car
+ * that starts at t0 = 0 bounds s from above, the front face of any other car from below, inside the car's window.
+ * Where lateral extents overlap the reference's result depends on the order the cars were constructed in; here the
+ * geometry has one definition (spectral_amd/csrc/prism_kernels.hip, oracle/prism_oracle.py), equal to the reference's
+ * own output on every scene where that output is a proper partition of the road (tests/test_prism_bounds.py).
+ *   prisms   [B][P][8]  s0, l0, t0, vel_s, vel_l, T, active (0 = slot unused), reserved;  P <= 16
+ *   outputs  s_bounds, l_bounds [B][O][N][2] (lower, upper) -- the layout btrapz_corridor_batch_device reads with
+ *            num_obs = O; strips beyond the scene's count are corridors no reference can enter
+ *            n_strips [B]: strips of the scene, -1 when it has more than O (at most 2 P + 1)                      */
+typedef struct btrapz_road {
+  double s_lo, s_hi;        /* s_l_l, s_u_l  (cart_frenet.py:54-55) */
+  double l_lo, l_hi;        /* d_l_l, d_u_l  (:57-58) */
+  double l_safe, w_safe;    /* 5/3 + 5/3, 2/3 + 2/3 (:698-699) */
+  double knots_per_second;  /* 10 (the reference writes `i/10`, `t0*10`) */
+} btrapz_road;
+int btrapz_prism_bounds_device(btrapz_ctx *ctx, int B, int P, int N, const btrapz_road *road, const double *prisms,
+                               int O, double *s_bounds, double *l_bounds, int *n_strips, void *stream);
+
 /* btrapz_sample_device for ragged batches (seg_count may be NULL: every candidate has seg_stride). */
 int btrapz_sample_ragged_device(btrapz_ctx *ctx, int B, int seg_stride, const int *seg_count,
                                 double delta, const double *seg, const double *init,

@@ -88,11 +88,21 @@ class CSegment(C.Structure):
                 ("count", C.c_int)]
 
 
+class CRoad(C.Structure):
+    """btrapz_road: road limits and safety margins of the prism -> bounds stage (cart_frenet.py:54-58, 698-699)."""
+    _fields_ = [("s_lo", C.c_double), ("s_hi", C.c_double), ("l_lo", C.c_double), ("l_hi", C.c_double),
+                ("l_safe", C.c_double), ("w_safe", C.c_double), ("knots_per_second", C.c_double)]
+
+    @classmethod
+    def reference(cls):
+        return cls(0.0, 50.0, -2.0, 8.0, 5.0 / 3 + 5.0 / 3, 2.0 / 3 + 2.0 / 3, 10.0)
+
+
 EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "btrapz_destroy", "btrapz_last_error",
            "btrapz_device_count", "btrapz_solve_batch_device", "btrapz_argmin_device",
            "btrapz_sample_device", "btrapz_solve_batch_host", "btrapz_solve_ragged_device",
            "btrapz_corridor_batch_device", "btrapz_sample_ragged_device", "btrapz_solve_warm_device",
-           "btrapz_eval_states_device", "btrapz_find_traj_mem")
+           "btrapz_eval_states_device", "btrapz_find_traj_mem", "btrapz_prism_bounds_device")
 
 
 def build(verbose=False):
@@ -169,6 +179,7 @@ def lib():
         l.btrapz_solve_warm_device.argtypes = [vp, C.POINTER(CShared), C.POINTER(COptions), C.POINTER(CWarm), C.c_int,
                                                C.c_int, dp, ip, dp, dp, dp, dp, dp, ip, ip, vp]
         l.btrapz_eval_states_device.argtypes = [vp, C.c_int, C.c_int, ip, dp, dp, C.c_int, dp, dp, vp]
+        l.btrapz_prism_bounds_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(CRoad), dp, C.c_int, dp, dp, ip, vp]
         _lib = l
     return _lib
 
@@ -262,6 +273,12 @@ class Context:
                                                        ptr(dl_bounds_knots), ptr(s_ref), ptr(l_ref), seg_stride,
                                                        ptr(seg), ptr(seg_count), ptr(ref_end), ptr(dl_bounds),
                                                        C.c_void_p(stream or 0)), "btrapz_corridor_batch_device")
+
+    def prism_bounds_device(self, B, P, N, road, prisms, O, s_bounds, l_bounds, n_strips, stream=None):
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        self._check(lib().btrapz_prism_bounds_device(self._h, B, P, N, C.byref(road), ptr(prisms), O, ptr(s_bounds),
+                                                     ptr(l_bounds), ptr(n_strips), C.c_void_p(stream or 0)),
+                    "btrapz_prism_bounds_device")
 
     def sample_ragged_device(self, B, seg_stride, seg_count, delta, seg, init, ctrl, sel, max_points, out, npoints,
                              stream=None):

@@ -104,6 +104,38 @@ class BatchSolver:
         rec["_inputs"] = ins  # keep the knot arrays alive until the launch has run
         return rec
 
+    def prism_bounds(self, prisms, N, O, road=None):
+        """Obstacle prisms [B, P, 8] (s0, l0, t0, vel_s, vel_l, T, active, -) -> per-knot bounds of the lateral strips
+        (btrapz_prism_bounds_device): s_bounds, l_bounds [B, O, N, 2] and n_strips [B], on the device."""
+        from .native import CRoad
+        d = self.device
+        prisms = prisms.to(d, dtype=torch.float64).contiguous()
+        B, P = prisms.shape[0], prisms.shape[1]
+        sb = torch.empty((B, O, N, 2), dtype=torch.float64, device=d); lb = torch.empty_like(sb)
+        n = torch.empty(B, dtype=torch.int32, device=d)
+        stream = torch.cuda.current_stream(d).cuda_stream
+        self.ctx.prism_bounds_device(B, P, N, road or CRoad.reference(), prisms, O, sb, lb, n, stream=stream)
+        return sb, lb, n
+
+    def corridor_batch_tensors(self, variant, N, delta, s_bounds, l_bounds, ds_bounds, dl_bounds, s_ref, l_ref, init,
+                               seg_stride=16):
+        """corridor_batch on device tensors (e.g. the output of prism_bounds): s_bounds, l_bounds [B, O, N, 2],
+        ds_bounds, dl_bounds [B, N, 2], s_ref, l_ref [B, N], init [B, 6]."""
+        d = self.device
+        B, O = s_bounds.shape[0], s_bounds.shape[1]
+        c = lambda t: t.to(d, dtype=torch.float64).contiguous()
+        ins = [c(s_bounds), c(l_bounds), c(ds_bounds), c(dl_bounds), c(s_ref), c(l_ref)]
+        rec = dict(B=B, seg_stride=seg_stride,
+                   seg=torch.zeros((L.NUM_SEG_FIELDS, B, seg_stride), dtype=torch.float64, device=d),
+                   seg_count=torch.zeros(B, dtype=torch.int32, device=d), init=c(init),
+                   ref_end=torch.zeros((B, 2), dtype=torch.float64, device=d),
+                   dl_bounds=torch.zeros((B, 10), dtype=torch.float64, device=d))
+        stream = torch.cuda.current_stream(d).cuda_stream
+        self.ctx.corridor_batch_device(variant, B, N, O, delta, *ins, seg_stride, rec["seg"], rec["seg_count"],
+                                       rec["ref_end"], rec["dl_bounds"], stream=stream)
+        rec["_inputs"] = ins
+        return rec
+
     def solve_ragged(self, rec, shared, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0):
         """Solve a ragged batch record (from corridor_batch); outputs stay on the device."""
         d = self.device

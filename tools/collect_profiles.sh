@@ -62,6 +62,7 @@ if [ "$QUICK" != "quick" ]; then
   step mpc_cold_minfirst05 "$OUT/mpc_cold_minfirst05.json" python3 "$ROOT/tools/mpc_bench.py" --cold --min-first 0.5
   step pipeline "$OUT/pipeline.json" python3 "$ROOT/tools/pipeline_bench.py"
   step pipeline_s1 "$OUT/pipeline_scenario1.json" python3 "$ROOT/tools/pipeline_bench.py" --scenario1
+  step pipeline_prisms "$OUT/pipeline_prisms.json" python3 "$ROOT/tools/pipeline_bench.py" --prisms
   step trace_pipeline "$OUT/pipeline_under_rocprof.json" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_pipeline" -- \
     python3 "$ROOT/tools/pipeline_bench.py"
   step bench_config2 "$OUT/bench_config2.json" python3 "$BENCH" --segments 10 --batch 4096 --no-cpu-baseline

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--scenario1", action="store_true",
                     help="BASELINE config 3 at knot level: synth.scenario1_knots (src/c1.txt's scene tiled over 20 s, N = 201, "
                          "18-24 segments per candidate) instead of jittered copies of a bundled file")
+    ap.add_argument("--prisms", action="store_true",
+                    help="start one stage earlier (SURVEY 8f rank 4): B scenes of two obstacle prisms (the harness's "
+                         "constellation, cart_frenet.py:1536-1546, jittered) -> btrapz_prism_bounds_device -> corridors -> QP")
     a = ap.parse_args()
     import torch
     from spectral_amd import knots, synth, layout as L
@@ -37,7 +40,32 @@ def main():
     solver = BatchSolver(0)
     d = solver.device
     B, st = a.batch, a.seg_stride
-    if a.scenario1:
+    prism_ms = None
+    if a.prisms:
+        from spectral_amd.knots import KnotBatch
+        rng = np.random.default_rng(11)
+        N, O = 71, 5
+        pr = np.zeros((B, 2, 8))
+        pr[:, 0, :7] = np.stack([rng.uniform(18, 30, B), np.full(B, 1.2), np.zeros(B), rng.uniform(3, 5, B), np.zeros(B), np.full(B, 4.0), np.ones(B)], 1)
+        pr[:, 1, :7] = np.stack([rng.uniform(5, 15, B), np.full(B, 4.2), np.zeros(B), rng.uniform(5, 7, B), np.zeros(B), np.full(B, 4.0), np.ones(B)], 1)
+        d_pr = torch.from_numpy(pr).to(d)
+        for _ in range(2):
+            sb, lb, ns = solver.prism_bounds(d_pr, N, O)
+        torch.cuda.synchronize()
+        tp = []
+        for _ in range(a.reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); sb, lb, ns = solver.prism_bounds(d_pr, N, O); e1.record()
+            torch.cuda.synchronize(); tp.append(e0.elapsed_time(e1))
+        prism_ms = float(np.median(tp))
+        tt = np.arange(N) * 0.1
+        kb = KnotBatch(B, N, O, 0.1, sb.cpu().numpy(), lb.cpu().numpy(), np.tile(np.array([0.0, 20.0]), (B, N, 1)),
+                       np.tile(np.array([-3.0, 3.0]), (B, N, 1)), np.tile(40.0 / 7.0 * tt, (B, 1)),
+                       np.tile(np.clip(1.2 + 0.0825 * (np.arange(N) - 15), 1.2, 4.5), (B, 1)),
+                       np.tile(np.array([0.0, 6.0, 0.0, 1.2, 0.0, 0.0]), (B, 1)), dict(synth.C1_HEADER))
+        st = max(st, 24)
+        label = "%d scenes of two obstacle prisms -> strips (btrapz_prism_bounds_device)" % B
+    elif a.scenario1:
         kb = synth.scenario1_knots(B, 20)
         st = max(st, 32)
         label = "%d scenario_1-shaped candidates at knot level (synth.scenario1_knots: c1.txt's scene tiled over 20 s)" % B
@@ -73,7 +101,15 @@ def main():
     in_bytes = sum(t.numel() * 8 for t in ins)
     out_bytes = int(B * (L.NUM_SEG_FIELDS * mean_cnt * 8 + 4 + 16 + 80))
     c_ms, s_ms = float(np.median(tc)), float(np.median(ts))
-    print(json.dumps({
+    extra = {}
+    if prism_ms is not None:
+        pb = B * 5 * 71 * 32 + B * 2 * 64
+        extra["prism_roofline"] = {"bound": "hbm", "kernel": "btrapz::prism_bounds_kernel", "kernel_ms": prism_ms,
+                                   "algorithmic_bytes_per_scene": pb / B, "achieved": pb / (prism_ms * 1e-3) / 1e9, "peak": 8000.0,
+                                   "unit": "GB/s", "frac": pb / (prism_ms * 1e-3) / 1e9 / 8000.0}
+        extra["prism_ms"] = prism_ms
+        extra["end_to_end_scenes_per_s"] = B / (prism_ms + float(np.median(tc)) + float(np.median(ts))) * 1e3
+    print(json.dumps({**extra,
         "workload": "%s (N = %d knots, %d obstacles), %s constraints" %
                     (label, kb.N, kb.num_obs, "trapezoid" if a.variant == 0 else "cuboid"),
         "corridor_ms": c_ms, "ragged_solve_ms": s_ms, "end_to_end_candidates_per_s": B / (c_ms + s_ms) * 1e3,

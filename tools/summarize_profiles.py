@@ -59,7 +59,7 @@ def main():
     pstats = glob.glob(os.path.join(src, "trace_pipeline", "**", "*kernel_stats.csv"), recursive=True)
     if pstats:
         shutil.copy(max(pstats, key=os.path.getmtime), os.path.join(dst, f"{tag}_pipeline_kernel_stats.csv"))
-    for name in ("mpc_warm", "mpc_cold", "mpc_warm_minfirst05", "mpc_cold_minfirst05", "pipeline", "pipeline_scenario1",
+    for name in ("mpc_warm", "mpc_cold", "mpc_warm_minfirst05", "mpc_cold_minfirst05", "pipeline", "pipeline_scenario1", "pipeline_prisms",
                  "bench_config2", "bench_config4", "bench_generic", "bench_2rank_gloo_strong"):
         if os.path.exists(os.path.join(src, name + ".json")):
             shutil.copy(os.path.join(src, name + ".json"), os.path.join(dst, f"{tag}_{name}.json"))
