@@ -99,8 +99,26 @@ __device__ __forceinline__ void opaque6(double (&v)[6]) {
 template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
   if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
 }
-#define FOR_ROWS(r) static_for<18>([&](auto r##_c) { constexpr int r = decltype(r##_c)::value;
+// Rows kept by a solve.  FULL: all 18 rows of a segment, as the reference assembles them.  Otherwise 15: the first
+// position, velocity and acceleration row of a segment (rows 0, 6, 11) state, about the joint at its start, what the
+// previous segment's last rows (5, 10, 14) state about the same joint from the other side -- t c_{k,5} = t' c_{k+1,0},
+// equal end / start velocities and accelerations are the continuity equalities (solve_3d.cc:918-949).  Two bounds on
+// one quantity are one bound: the previous lane keeps the row with the intersection, this lane drops it -- same
+// feasible set, same optimum, a sixth less row work and state.  (Segment 0's start rows constrain the given initial
+// state, a constant: checked once.)  The rescue pass counts violations row by row and keeps all 18.
+template <bool FULL> __host__ __device__ constexpr int rows_kept() { return FULL ? 18 : 15; }
+template <bool FULL> __host__ __device__ constexpr int row_id(int i) {   // i-th kept row -> row of the segment
+  return FULL ? i : (i < 5 ? i + 1 : i < 9 ? i + 2 : i < 12 ? i + 3 : i + 3);
+}
+template <bool FULL> __host__ __device__ constexpr int state_index(int r) {   // row of the segment -> slot in the state arrays
+  return FULL ? r : (r < 6 ? r - 1 : r < 11 ? r - 2 : r < 15 ? r - 3 : r - 3);
+}
+template <bool FULL> __host__ __device__ constexpr int next_row(int r) {      // the kept row after r, -1 after the last
+  return r >= 17 ? -1 : (FULL ? r + 1 : (r + 1 == 6 || r + 1 == 11) ? r + 2 : r + 1);
+}
+#define FOR_ROWS(r) static_for<NR>([&](auto r##_c) { constexpr int r = row_id<FULL>(decltype(r##_c)::value);
 #define END_ROWS });
+#define SI(r) state_index<FULL>(r)
 
 // Null-space maps.  X = (p, v, a) physical state at a joint; segment duration t.
 //   start of segment:  c0 = p/t, c1 = c0 + v/5, c2 = c0 + 2v/5 + a t/20
@@ -139,7 +157,8 @@ __device__ __forceinline__ void ldl3_solve(const double (&F)[6], double b0, doub
 }
 
 // ---- LDS: one 64-wide row per per-lane scalar; a lane only ever touches its own column ----
-enum { L_LL = 0, L_LU = 18, L_ISL = 36, L_ISU = 54, L_RED = 72, L_ROWS = 76 };
+// (row offsets: L_LL = 0, L_LU = NR, L_ISL = 2 NR, L_ISU = 3 NR, four reduction rows behind them)
+template <bool FULL> __host__ __device__ constexpr int lds_rows() { return 4 * rows_kept<FULL>() + 4; }
 
 // Reductions over the S lanes of a group: every lane publishes 4 values, then reads its
 // group's S entries in batches of RB (reads issued back to back, one wait per batch; fixed order
@@ -172,12 +191,12 @@ template <int OP> __device__ __forceinline__ double pair_op(double v, bool has_n
 // Every lane first combines its value with its right neighbour's (DPP, if that lane belongs to the same group), so
 // only the even lanes' entries have to be read back: half the LDS reads and half the combining operations.
 template <int O0, int O1, int O2, int O3>
-__device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gbase, int k, int S, double v0, double v1,
+__device__ __forceinline__ Red4 group_reduce(double (*red)[64], int lane, int gbase, int k, int S, double v0, double v1,
                                              double v2, double v3) {
   const bool has_next = k + 1 < S;
   v0 = pair_op<O0>(v0, has_next); v1 = pair_op<O1>(v1, has_next); v2 = pair_op<O2>(v2, has_next); v3 = pair_op<O3>(v3, has_next);
   wave_lds_sync();
-  lds[L_RED + 0][lane] = v0; lds[L_RED + 1][lane] = v1; lds[L_RED + 2][lane] = v2; lds[L_RED + 3][lane] = v3;
+  red[0][lane] = v0; red[1][lane] = v1; red[2][lane] = v2; red[3][lane] = v3;
   wave_lds_sync();
   Red4 r = {red_init<O0>(), red_init<O1>(), red_init<O2>(), red_init<O3>()};
   const int n2 = (S + 1) >> 1;   // pairs (the last one may be a single lane)
@@ -185,7 +204,7 @@ __device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gb
     double a[RB], b[RB], c[RB], d[RB];
     UNROLL for (int u = 0; u < RB; u++) {
       const int j = gbase + 2 * (j0 + u < n2 ? j0 + u : n2 - 1);
-      a[u] = lds[L_RED + 0][j]; b[u] = lds[L_RED + 1][j]; c[u] = lds[L_RED + 2][j]; d[u] = lds[L_RED + 3][j];
+      a[u] = red[0][j]; b[u] = red[1][j]; c[u] = red[2][j]; d[u] = red[3][j];
     }
     UNROLL for (int u = 0; u < RB; u++) {
       const bool in = j0 + u < n2;
@@ -209,7 +228,10 @@ __device__ __forceinline__ Red4 group_reduce(double (*lds)[64], int lane, int gb
 template <bool WARM, bool ORDERED, bool ELASTIC = false>
 __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double *__restrict__ mqm, double (*lds)[64],
                                                const int wave_id, const int lane) {
-  constexpr bool CACHE_RP = !WARM && !ELASTIC;   // see the main loop
+  constexpr bool CACHE_RP = !ELASTIC;   // see the main loop
+  constexpr bool FULL = ELASTIC;                 // rows kept: see rows_kept()
+  constexpr int NR = rows_kept<FULL>();
+  constexpr int L_LL = 0, L_LU = NR, L_ISL = 2 * NR, L_ISU = 3 * NR, L_RED = 4 * NR;
   // the axis is wave-uniform
   const int axis = __builtin_amdgcn_readfirstlane(wave_id & 1);
   int S, pair = wave_id >> 1, ncand = a.B, cand0 = 0;
@@ -292,8 +314,24 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   const double alo = (axis == 0 ? sh.acc_s[0] : sh.acc_l[0]) * t, ahi = (axis == 0 ? sh.acc_s[1] : sh.acc_l[1]) * t;
   const double jlo = (axis == 0 ? sh.jerk_s[0] : sh.jerk_l[0]) * t * t, jhi = (axis == 0 ? sh.jerk_s[1] : sh.jerk_l[1]) * t * t;
 
-#define LO(r) ((r) < 6 ? plo0 + (double)(r) * dplo : (r) < 11 ? vlo[((r) >= 6 && (r) < 11) ? (r) - 6 : 0] : (r) < 15 ? alo : jlo)
-#define UP(r) ((r) < 6 ? phi0 + (double)(r) * dphi : (r) < 11 ? vhi[((r) >= 6 && (r) < 11) ? (r) - 6 : 0] : (r) < 15 ? ahi : jhi)
+  // bounds of the rows as the reference assembles them ...
+#define LO0(r) ((r) < 6 ? plo0 + (double)(r) * dplo : (r) < 11 ? vlo[((r) >= 6 && (r) < 11) ? (r) - 6 : 0] : (r) < 15 ? alo : jlo)
+#define UP0(r) ((r) < 6 ? phi0 + (double)(r) * dphi : (r) < 11 ? vhi[((r) >= 6 && (r) < 11) ? (r) - 6 : 0] : (r) < 15 ? ahi : jhi)
+  // ... and of the rows this solve keeps (rows_kept): the last position and velocity row of a segment (5, 10) carry the
+  // intersection with the next segment's first ones (0, 6), which state the same joint quantity; the acceleration rows
+  // 14 / 11 are one and the same interval for a, scaled by the two durations.
+  double mplo = plo0 + 5.0 * dplo, mphi = phi0 + 5.0 * dphi, mvlo = vlo[4], mvhi = vhi[4];
+  bool joint_empty = false;
+  if constexpr (!FULL) {
+    const double nplo = from_next(plo0), nphi = from_next(phi0), nvlo = from_next(vlo[0]), nvhi = from_next(vhi[0]);
+    if (!last) {
+      const bool own_ok = mplo <= mphi && mvlo <= mvhi && nplo <= nphi && nvlo <= nvhi;
+      mplo = fmax(mplo, nplo); mphi = fmin(mphi, nphi); mvlo = fmax(mvlo, nvlo); mvhi = fmin(mvhi, nvhi);
+      joint_empty = own_ok && (mplo > mphi || mvlo > mvhi);   // two consistent rows that contradict each other
+    }
+  }
+#define LO(r) ((!FULL && (r) == 5) ? mplo : (!FULL && (r) == 10) ? mvlo : LO0(r))
+#define UP(r) ((!FULL && (r) == 5) ? mphi : (!FULL && (r) == 10) ? mvhi : UP0(r))
 
   // P block (solve_3d.cc:159-171) from the batch-invariant MQM_d = M' pQp_d M: the table is
   // wave-uniform (one axis per wave) -> scalar loads.
@@ -331,10 +369,27 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 
   // ---------------- consistency of the bounds -------------------------------------------
   double gapmin = 1e300, bnorm = 0.0, qn = 0.0;
-  FOR_ROWS(r)
-    gapmin = fmin(gapmin, UP(r) - LO(r));
-    bnorm = fmax(bnorm, fmax(fabs(LO(r)), fabs(UP(r))));
-  END_ROWS
+  static_for<18>([&](auto r_c) {          // (all rows of the reference: a row with l > u is reported as such)
+    constexpr int r = decltype(r_c)::value;
+    gapmin = fmin(gapmin, UP0(r) - LO0(r));
+    bnorm = fmax(bnorm, fmax(fabs(LO0(r)), fabs(UP0(r))));
+  });
+  // Rows that no iterate can change: segment 0's first position / velocity / acceleration row state the given initial
+  // state (c0, c1, c2 of segment 0 follow from it alone), and a joint whose two sides leave no common value.  If they
+  // cannot be met the problem has no solution: the solve stops before its first iteration with the status of a stalled
+  // one (which the rescue pass, btrapz_options.elastic, then takes over).
+  bool no_solution_lane = false;
+  if constexpr (!FULL) {
+    double c0, c1, c2;
+    const double Xi[3] = {a.init[(size_t)b * 6 + axis * 3], a.init[(size_t)b * 6 + axis * 3 + 1], a.init[(size_t)b * 6 + axis * 3 + 2]};
+    U_apply(nm, Xi, c0, c1, c2);
+    auto outside = [&](double g, double lo, double hi) {
+      const double tol = 1e-7 * (1.0 + fmax(fabs(lo), fabs(hi)));
+      return !(g >= lo - tol && g <= hi + tol);
+    };
+    no_solution_lane = (first && (outside(t * c0, LO0(0), UP0(0)) || outside(5.0 * (c1 - c0), LO0(6), UP0(6)) ||
+                                  outside(20.0 * ((c0 - 2.0 * c1) + c2), LO0(11), UP0(11)))) || joint_empty;
+  }
   UNROLL for (int i = 0; i < 6; i++) qn = fmax(qn, fabs(q[i]));
   // ---------------- starting point: constant-velocity propagation of the initial state, or the caller's
   // joint states (warm start; a lane whose values are not finite keeps the cold start) -----
@@ -348,14 +403,16 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     Xcold0 = Xinit[0] + Xinit[1] * tsum;
   }
   {
-    const Red4 r0 = group_reduce<0, 1, 1, 2>(lds, lane, gbase, k, S, 0.0, bnorm, qn, gapmin);
+    const Red4 r0 = group_reduce<0, 1, 1, 2>(lds + L_RED, lane, gbase, k, S, no_solution_lane ? 1.0 : 0.0, bnorm, qn, gapmin);
     bnorm = r0.b; qn = r0.c; gapmin = r0.d;
+    no_solution_lane = r0.a > 0.0;      // (group-uniform from here on)
   }
   const bool infeasible_bounds = !(gapmin >= 0.0) || !(t > 0.0);
+  const bool no_solution = no_solution_lane;
 
-  double sl[18], su[18];
-#define LL(r) lds[L_LL + r][lane]
-#define LU(r) lds[L_LU + r][lane]
+  double sl[NR], su[NR];
+#define LL(r) lds[L_LL + SI(r)][lane]
+#define LU(r) lds[L_LU + SI(r)][lane]
   // cold start of this lane: slacks max(gap, 1), multipliers 1
   auto cold_start = [&]() {
     X[0] = Xcold0; X[1] = Xinit[1]; X[2] = 0.0;
@@ -365,7 +422,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     V_apply(nm, X, c[3], c[4], c[5]);
     FOR_ROWS(r)
       const double gc_r = row_dot<r>(c, t);
-      sl[r] = fmax(gc_r - LO(r), 1.0); su[r] = fmax(UP(r) - gc_r, 1.0);
+      sl[SI(r)] = fmax(gc_r - LO(r), 1.0); su[SI(r)] = fmax(UP(r) - gc_r, 1.0);
       LL(r) = 1.0; LU(r) = 1.0;
     END_ROWS
   };
@@ -391,10 +448,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       const double s_l = fmax(gc_r - LO(r), smin), s_u = fmax(UP(r) - gc_r, smin);
       double l_l = 0.0, l_u = 0.0;
       if (a.lam0) {
-        const double p_l = a.lam0[lam_e + (size_t)r * lam_row], p_u = a.lam0[lam_e + (size_t)(18 + r) * lam_row];
+        const double p_l = a.lam0[lam_e + (size_t)r * lam_row], p_u = a.lam0[lam_e + (size_t)(18 + r) * lam_row];   // (layout of the header: 18 + 18 rows)
         l_l = (p_l >= 0.0 && p_l < 1e300) ? p_l : 0.0; l_u = (p_u >= 0.0 && p_u < 1e300) ? p_u : 0.0;
       }
-      sl[r] = s_l; su[r] = s_u;
+      sl[SI(r)] = s_l; su[SI(r)] = s_u;
       LL(r) = l_l + mu0 * rcp(s_l); LU(r) = l_u + mu0 * rcp(s_u);
     END_ROWS
   } else {
@@ -410,10 +467,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   LOAD_P(Pk)
   const double eps = a.eps;
   [[maybe_unused]] const double edelta = ELASTIC ? a.elastic_delta : 0.0;
-  const double inv_m = 1.0 / (36.0 * (double)S);
+  const double inv_m = 1.0 / ((double)(2 * NR) * (double)S);
   double best_score = 1e300, Xb[3] = {X[0], X[1], X[2]};
   int best_it = 0, iters = 0;
-  bool done = !valid || infeasible_bounds;
+  bool done = !valid || infeasible_bounds || no_solution;
   // Warm-start instantiations: when one group of the wavefront restarts cold, the others lose that pass of the loop
   // (wave-uniform `continue` below).  Their iteration count must not see it, or a candidate's stall / step-rule /
   // iteration bookkeeping would depend on which candidates share its wavefront: every test below uses the group's own
@@ -426,7 +483,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     // Row residuals r_l = G c - s_l - l, r_u = G c + s_u - u: constant within an iteration and needed by six row
     // loops.  Cached (36 doubles; the allocator parks them in AGPRs) they save ~100 instructions per row loop:
     // 6.29 -> 6.04 ms.  The warm-start instantiations carry more state and would spill, so they recompute.
-    double c[6], gc[6], rpl_[CACHE_RP ? 18 : 1], rpu_[CACHE_RP ? 18 : 1];
+    double c[6], gc[6], rpl_[CACHE_RP ? NR : 1], rpu_[CACHE_RP ? NR : 1];
     double mu_part = 0.0, rp_part = 0.0, dscale = 0.0;
     {
       double Xp[3];
@@ -438,10 +495,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         const double ll = LL(r), lu = LU(r);
         double gcr = row_dot<r>(c, t);
         if constexpr (ELASTIC) gcr -= edelta * (lu - ll);
-        const double rpl = gcr - sl[r] - LO(r), rpu = gcr + su[r] - UP(r);
-        if constexpr (CACHE_RP) { rpl_[CACHE_RP ? r : 0] = rpl; rpu_[CACHE_RP ? r : 0] = rpu; }
+        const double rpl = gcr - sl[SI(r)] - LO(r), rpu = gcr + su[SI(r)] - UP(r);
+        if constexpr (CACHE_RP) { rpl_[CACHE_RP ? SI(r) : 0] = rpl; rpu_[CACHE_RP ? SI(r) : 0] = rpu; }
         rp_part = fmax(rp_part, fmax(fabs(rpl), fabs(rpu)));
-        mu_part += sl[r] * ll + su[r] * lu;
+        mu_part += sl[SI(r)] * ll + su[SI(r)] * lu;
         row_scatter<r>(lu - ll, t, gc);
       END_ROWS
       UNROLL for (int i = 0; i < 6; i++) dscale = fmax(dscale, fabs(gc[i]));
@@ -468,7 +525,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     if (!(mu_part == mu_part) || !(rd_part == rd_part) || !(rp_part == rp_part) || !(dscale == dscale) ||
         !(fabs(rd_part) < 1e300) || !(fabs(mu_part) < 1e300))
       rp_part = 1e300;
-    const Red4 rr = group_reduce<0, 1, 1, 1>(lds, lane, gbase, k, S, mu_part, rd_part, rp_part, dscale);
+    const Red4 rr = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, mu_part, rd_part, rp_part, dscale);
     const double mu = rr.a * inv_m;
     // KKT score: dual residual relative to (1+|q|) with a round-off floor, primal residual
     // relative to the bound scale, complementarity absolute.
@@ -523,24 +580,24 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // accumulated here instead of in a row loop of its own (one pass over the rows and 72 LDS reads less).
       UNROLL for (int i = 0; i < 6; i++) hp[i] = gc[i];
       FOR_ROWS(r)
-        const double isl = rcp(sl[r]), isu = rcp(su[r]);
+        const double isl = rcp(sl[SI(r)]), isu = rcp(su[SI(r)]);
         const double ll = LL(r), lu = LU(r);
-        lds[L_ISL + r][lane] = isl; lds[L_ISU + r][lane] = isu;
+        lds[L_ISL + SI(r)][lane] = isl; lds[L_ISU + SI(r)][lane] = isu;
         const double wl = ll * isl, wu = lu * isu;
         double rpl, rpu;
-        if constexpr (CACHE_RP) { rpl = rpl_[CACHE_RP ? r : 0]; rpu = rpu_[CACHE_RP ? r : 0]; }
+        if constexpr (CACHE_RP) { rpl = rpl_[CACHE_RP ? SI(r) : 0]; rpu = rpu_[CACHE_RP ? SI(r) : 0]; }
         else {
           double gcr = row_dot<r>(c, t);
           if constexpr (ELASTIC) gcr -= edelta * (lu - ll);
-          rpl = gcr - sl[r] - LO(r); rpu = gcr + su[r] - UP(r);
+          rpl = gcr - sl[SI(r)] - LO(r); rpu = gcr + su[SI(r)] - UP(r);
         }
         if constexpr (ELASTIC) {
           const double ef = rcp(1.0 + edelta * (wl + wu));
           row_outer<r>((wl + wu) * ef, t2, H);
-          row_scatter<r>((wl * (sl[r] + rpl) - wu * (su[r] - rpu)) * ef, t, hp);
+          row_scatter<r>((wl * (sl[SI(r)] + rpl) - wu * (su[SI(r)] - rpu)) * ef, t, hp);
         } else {
           row_outer<r>(wl + wu, t2, H);
-          row_scatter<r>(wl * (sl[r] + rpl) - wu * (su[r] - rpu), t, hp);
+          row_scatter<r>(wl * (sl[SI(r)] + rpl) - wu * (su[SI(r)] - rpu), t, hp);
         }
       END_ROWS
       reduce_rhs(hp, up);
@@ -685,20 +742,21 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     // sinking the loads back to their uses (measured: 7.12 -> 6.98 ms; two rows ahead costs registers: 7.11; the
     // same in the residual and Newton-matrix loops, which read only the multipliers: 7.17).
     double pf_isl, pf_isu, pf_ll, pf_lu;
-#define ROW_PREFETCH() do { pf_isl = lds[L_ISL][lane]; pf_isu = lds[L_ISU][lane]; pf_ll = LL(0); pf_lu = LU(0); } while (0)
+#define ROW_PREFETCH() do { pf_isl = lds[L_ISL][lane]; pf_isu = lds[L_ISU][lane]; pf_ll = lds[L_LL][lane]; pf_lu = lds[L_LU][lane]; } while (0)
 #define ROW_BASE(r)                                                                               \
       const double isl = pf_isl, isu = pf_isu, ll = pf_ll, lu = pf_lu;                              \
-      if constexpr (r + 1 < 18) {                                                                   \
-        pf_isl = lds[L_ISL + (r + 1 < 18 ? r + 1 : r)][lane]; pf_isu = lds[L_ISU + (r + 1 < 18 ? r + 1 : r)][lane]; \
-        pf_ll = LL((r + 1 < 18 ? r + 1 : r)); pf_lu = LU((r + 1 < 18 ? r + 1 : r));                  \
+      if constexpr (next_row<FULL>(r) >= 0) {                                                       \
+        constexpr int rn_ = next_row<FULL>(r) >= 0 ? next_row<FULL>(r) : r;                         \
+        pf_isl = lds[L_ISL + SI(rn_)][lane]; pf_isu = lds[L_ISU + SI(rn_)][lane];                   \
+        pf_ll = LL(rn_); pf_lu = LU(rn_);                                                           \
         __builtin_amdgcn_sched_barrier(0x067F); /* anything but LDS reads may cross */               \
       }                                                                                             \
       double rpl, rpu;                                                                              \
-      if constexpr (CACHE_RP) { rpl = rpl_[r < 18 && CACHE_RP ? r : 0]; rpu = rpu_[r < 18 && CACHE_RP ? r : 0]; }      \
+      if constexpr (CACHE_RP) { rpl = rpl_[CACHE_RP ? SI(r) : 0]; rpu = rpu_[CACHE_RP ? SI(r) : 0]; }                  \
       else {                                                                                        \
         double gcr = row_dot<r>(c, t);                                                              \
         if constexpr (ELASTIC) gcr -= edelta * (lu - ll);                                           \
-        rpl = gcr - sl[r] - LO(r); rpu = gcr + su[r] - UP(r);                                       \
+        rpl = gcr - sl[SI(r)] - LO(r); rpu = gcr + su[SI(r)] - UP(r);                                       \
       }
     // elastic rows: the step of the row value, g' dc -> (g' dc - delta b) / (1 + delta w)
 #define ROW_STEP(gd, b) (ELASTIC ? ((gd) - edelta * (b)) * rcp(1.0 + edelta * (ll * isl + lu * isu)) : (gd))
@@ -724,7 +782,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         S1 += al + au;
         S4 += al * ql + au * qu;
       END_ROWS
-      const Red4 ra = group_reduce<0, 0, 1, 2>(lds, lane, gbase, k, S, S1, S4, qmax, qmin);
+      const Red4 ra = group_reduce<0, 0, 1, 2>(lds + L_RED, lane, gbase, k, S, S1, S4, qmax, qmin);
       const double ap = 1.0 / fmax(-ra.d, 1.0), ad = 1.0 / fmax(1.0 + ra.c, 1.0);
       const double mua = ((1.0 - ad) * rr.a + (ap - ad - ap * ad) * ra.a - ap * ad * ra.b) * inv_m;
       const double sr = mua / mu;
@@ -735,18 +793,18 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 #define ROW_CORR(r)                                                                               \
       const double ga = ROW_STEP(row_dot<r>(dca, t), (ll - lu) + (ll * isl) * rpl + (lu * isu) * rpu); \
       const double dsa = ga + rpl, dua = -ga - rpu;                                                 \
-      const double rcl = __builtin_fma(sl[r], ll, -sigma_mu) - (ll * dsa) * (1.0 + dsa * isl);      \
-      const double rcu = __builtin_fma(su[r], lu, -sigma_mu) - (lu * dua) * (1.0 + dua * isu);      \
+      const double rcl = __builtin_fma(sl[SI(r)], ll, -sigma_mu) - (ll * dsa) * (1.0 + dsa * isl);      \
+      const double rcu = __builtin_fma(su[SI(r)], lu, -sigma_mu) - (lu * dua) * (1.0 + dua * isu);      \
       const double el = rcl * isl, eu = rcu * isu, wl = ll * isl, wu = lu * isu;
       double h[6], dc[6];
-      double el_[18], eu_[18];   // rc/s of the corrected complementarity targets, reused by the two loops below
+          double el_[NR], eu_[NR];   // rc/s of the corrected complementarity targets, reused by the two loops below
       UNROLL for (int i = 0; i < 6; i++) h[i] = gc[i];
       PHASE_FENCE(opaque6(c); opaque6(dca));
       ROW_PREFETCH();
       FOR_ROWS(r)
         ROW_BASE(r)
         ROW_CORR(r)
-        el_[r] = el; eu_[r] = eu;
+        el_[SI(r)] = el; eu_[SI(r)] = eu;
         if constexpr (ELASTIC) row_scatter<r>(((el - eu) + (wl * rpl + wu * rpu)) * rcp(1.0 + edelta * (wl + wu)), t, h);
         else row_scatter<r>((el - eu) + (wl * rpl + wu * rpu), t, h);
       END_ROWS
@@ -757,13 +815,13 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       ROW_PREFETCH();
       FOR_ROWS(r)
         ROW_BASE(r)
-        const double gd = ROW_STEP(row_dot<r>(dc, t), (el_[r] - eu_[r]) + (ll * isl) * rpl + (lu * isu) * rpu);
+        const double gd = ROW_STEP(row_dot<r>(dc, t), (el_[SI(r)] - eu_[SI(r)]) + (ll * isl) * rpl + (lu * isu) * rpu);
         const double dsl = gd + rpl, dsu = -gd - rpu;
-        const double dll = -el_[r] - (ll * isl) * dsl, dlu = -eu_[r] - (lu * isu) * dsu;
+        const double dll = -el_[SI(r)] - (ll * isl) * dsl, dlu = -eu_[SI(r)] - (lu * isu) * dsu;
         pr = fmax(pr, fmax(-dsl * isl, -dsu * isu));
         dr = fmax(dr, fmax(-dll * rcp_fast(ll), -dlu * rcp_fast(lu)));
       END_ROWS
-      const Red4 ra = group_reduce<0, 1, 1, 1>(lds, lane, gbase, k, S, 0.0, pr, dr, 0.0);
+      const Red4 ra = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, 0.0, pr, dr, 0.0);
       // m = largest ratio -ds/s, -dlambda/lambda: the boundary is 1/m away.  A long step may go almost all the way
       // (fewer iterations); a blocked one keeps 0.5 % distance, or the iterates lose centrality and crawl.
       const double m_ = fmax(ra.b, ra.c);
@@ -777,10 +835,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         ROW_PREFETCH();
         FOR_ROWS(r)
           ROW_BASE(r)
-          const double gd = ROW_STEP(row_dot<r>(dc, t), (el_[r] - eu_[r]) + (ll * isl) * rpl + (lu * isu) * rpu);
+          const double gd = ROW_STEP(row_dot<r>(dc, t), (el_[SI(r)] - eu_[SI(r)]) + (ll * isl) * rpl + (lu * isu) * rpu);
           const double dsl = gd + rpl, dsu = -gd - rpu;
-          sl[r] += alpha * dsl; su[r] += alpha * dsu;
-          LL(r) = ll + alpha * (-el_[r] - (ll * isl) * dsl); LU(r) = lu + alpha * (-eu_[r] - (lu * isu) * dsu);
+          sl[SI(r)] += alpha * dsl; su[SI(r)] += alpha * dsu;
+          LL(r) = ll + alpha * (-el_[SI(r)] - (ll * isl) * dsl); LU(r) = lu + alpha * (-eu_[SI(r)] - (lu * isu) * dsu);
         END_ROWS
       }
 #undef ROW_CORR
@@ -795,6 +853,12 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     FOR_ROWS(r)
       a.lam_out[lam_e + (size_t)r * lam_row] = LL(r); a.lam_out[lam_e + (size_t)(18 + r) * lam_row] = LU(r);
     END_ROWS
+    if constexpr (!FULL) {   // the rows this lane does not keep (their bounds live in the previous segment's last rows)
+      UNROLL for (int r0 = 0; r0 < 3; r0++) {
+        const int rr_ = r0 == 0 ? 0 : r0 == 1 ? 6 : 11;
+        a.lam_out[lam_e + (size_t)rr_ * lam_row] = 0.0; a.lam_out[lam_e + (size_t)(18 + rr_) * lam_row] = 0.0;
+      }
+    }
   }
   {
     double Xp[3], c[6];
@@ -817,7 +881,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         viol = fmax(viol, fmax(LO(r) - gcr, gcr - UP(r)));
       END_ROWS
     }
-    const Red4 ro = group_reduce<0, 1, 1, 1>(lds, lane, gbase, k, S, obj, viol, 0.0, 0.0);
+    const Red4 ro = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, obj, viol, 0.0, 0.0);
     if (valid) {
       // control points in the reference's order: s axis (6 S), then l axis (6 S); rows are 12*seg_stride apart
       double *dst = a.ctrl + (size_t)b * 12 * a.seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
@@ -844,24 +908,24 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 // Four instantiations: {cold, warm start} x {candidates in memory order, candidates through a.order (ragged batches
 // and scheduling hints)}.  The bench path is the first; keeping the others out of it keeps its register allocation.
 __global__ __launch_bounds__(64) void ipm_solve_kernel(const KernelArgs a, const double *__restrict__ mqm) {
-  __shared__ double lds[L_ROWS][64];
+  __shared__ double lds[lds_rows<false>()][64];
   ipm_solve_body<false, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 __global__ __launch_bounds__(64) void ipm_solve_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
-  __shared__ double lds[L_ROWS][64];
+  __shared__ double lds[lds_rows<false>()][64];
   ipm_solve_body<false, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 __global__ __launch_bounds__(64) void ipm_solve_warm_kernel(const KernelArgs a, const double *__restrict__ mqm) {
-  __shared__ double lds[L_ROWS][64];
+  __shared__ double lds[lds_rows<false>()][64];
   ipm_solve_body<true, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 __global__ __launch_bounds__(64) void ipm_solve_warm_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
-  __shared__ double lds[L_ROWS][64];
+  __shared__ double lds[lds_rows<false>()][64];
   ipm_solve_body<true, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 // Rescue pass (btrapz_options.elastic): the stalled axis problems, listed per axis, with elastic rows.
 __global__ __launch_bounds__(64) void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm) {
-  __shared__ double lds[L_ROWS][64];
+  __shared__ double lds[lds_rows<true>()][64];
   ipm_solve_body<false, true, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 // keys of the rescue lists: key[axis][b] = segment count of candidate b when that axis problem stalled, else 0
@@ -1083,7 +1147,7 @@ __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, doubl
 __global__ __launch_bounds__(128) void single_candidate_kernel(const KernelArgs a, const double *__restrict__ mqm,
                                                                double delta, int max_points, double *out) {
   double *res = out, *traj = out + 3 + 12 * a.S;
-  __shared__ double lds[2][L_ROWS][64];
+  __shared__ double lds[2][lds_rows<false>()][64];
   const int w = (int)threadIdx.x >> 6;
   ipm_solve_body<false, false>(a, mqm, lds[w], w, (int)threadIdx.x & 63);
   __threadfence_block();

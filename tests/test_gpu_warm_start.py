@@ -201,9 +201,13 @@ def test_scheduling_hint_changes_nothing_but_the_schedule(solver):
     B, S = 4099, 20                                   # not a multiple of anything
     batch, sh = synth.make_batch(B, S, config=3)
     db = solver.upload(batch)
-    ref = solver.solve(db, sh, keep_multipliers=True)
+    ref0 = solver.solve(db, sh)                        # the same solve without a hint (cold-start kernels)
     torch.cuda.synchronize()
-    r_ctrl, r_cost, r_st, r_it = (ref[k].clone() for k in ("ctrl", "cost", "status", "iters"))
+    r_ctrl, r_cost, r_st, r_it = (ref0[k].clone() for k in ("ctrl", "cost", "status", "iters"))
+    ref = solver.solve(db, sh, keep_multipliers=True)  # (warm-start kernels: another instantiation, equal to rounding)
+    torch.cuda.synchronize()
+    assert (ref["ctrl"] - r_ctrl).abs().max().item() <= 1e-11 * r_ctrl.abs().max().item() and torch.equal(ref["iters"], r_it)
+    k_ctrl, k_lam = ref["ctrl"].clone(), ref["lam"].clone()      # (the output buffers are reused by the next solve)
     g = torch.Generator().manual_seed(2)
     hints = {"constant": torch.full((B,), 3, dtype=torch.int32),
              "own iterations": (r_it + 1).to(torch.int32).cpu(),
@@ -213,11 +217,14 @@ def test_scheduling_hint_changes_nothing_but_the_schedule(solver):
         torch.cuda.synchronize()
         assert torch.equal(o["ctrl"], r_ctrl) and torch.equal(o["cost"], r_cost), name
         assert torch.equal(o["status"], r_st) and torch.equal(o["iters"], r_it), name
+    kh = solver.solve(db, sh, keep_multipliers=True, warm=dict(hint=hints["own iterations"].to(solver.device).contiguous()))
+    torch.cuda.synchronize()
+    assert torch.equal(kh["ctrl"], k_ctrl) and torch.equal(kh["lam"], k_lam)
     # warm start + hint against warm start alone
     x0 = solver.eval_states(db, r_ctrl, joint_times(batch))
-    w0 = solver.solve(db, sh, warm=dict(x0=x0, lam=ref["lam"].clone()))
+    w0 = solver.solve(db, sh, warm=dict(x0=x0, lam=k_lam.clone()))
     torch.cuda.synchronize()
     w_ctrl, w_it = w0["ctrl"].clone(), w0["iters"].clone()
-    w1 = solver.solve(db, sh, warm=dict(x0=x0, lam=ref["lam"].clone(), hint=hints["random, out of range"].to(solver.device)))
+    w1 = solver.solve(db, sh, warm=dict(x0=x0, lam=k_lam.clone(), hint=hints["random, out of range"].to(solver.device)))
     torch.cuda.synchronize()
     assert torch.equal(w1["ctrl"], w_ctrl) and torch.equal(w1["iters"], w_it)
