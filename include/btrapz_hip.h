@@ -167,6 +167,11 @@ typedef struct btrapz_options {
   int elastic;
   double elastic_tol;
   double elastic_delta;
+  /* Uniform cold batches of many more candidates than the device holds at once: 1 -> persistent wavefronts draw
+   * candidates from a queue, so that the groups of a wavefront do not wait for its slowest one.  Pays where iteration
+   * counts spread widely (batches with stalling candidates: -10 %), costs where they do not (+6 %); 0 -> off.
+   * Results do not depend on it. */
+  int queue;
 } btrapz_options;
 
 /* A context owns the per-launch workspace of one device: it is NOT thread-safe (one context per calling

@@ -53,6 +53,7 @@ struct KernelArgs {
   // rescue pass (btrapz_options.elastic): order = [2][B] per-axis lists, cand_prefix / wave_prefix = [2][198] tables
   double elastic_delta;     // penalty d^2 / (2 delta) on the relaxation d of every inequality row
   double elastic_tol;       // largest row violation still reported as BTRAPZ_SOLVED_INACCURATE
+  int *queue;               // ipm_solve_queue_kernel: [2] next candidate per axis (zeroed before the launch)
 };
 
 struct CorridorArgs {
@@ -81,6 +82,7 @@ __global__ void ipm_solve_kernel(const KernelArgs a, const double *__restrict__ 
 __global__ void ipm_solve_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);       // through a.order
 __global__ void ipm_solve_warm_kernel(const KernelArgs a, const double *__restrict__ mqm);          // + btrapz_warm
 __global__ void ipm_solve_warm_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);
+__global__ void ipm_solve_queue_kernel(const KernelArgs a, const double *__restrict__ mqm);         // persistent, candidate queue
 __global__ void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm);       // rescue pass
 __global__ void rescue_keys_kernel(int B, int S, const int *seg_count, const int *axis_status, int *keys, int all);
 __global__ void rescue_init_kernel(int B, int S, const int *seg_count, double *axis_obj, int *axis_status, int *axis_iters);

@@ -225,9 +225,16 @@ __device__ __forceinline__ Red4 group_reduce(double (*red)[64], int lane, int gb
 // (g'dc - delta b) / (1 + delta w), b the row's entry of the right-hand side.  delta = 0 is the plain method.
 // wave_id: the wavefront's number in the launch (wavefront w solves axis w & 1 of the candidates of pair w >> 1);
 // lds: this wavefront's private [L_ROWS][64] block of LDS; lane: 0..63.
-template <bool WARM, bool ORDERED, bool ELASTIC = false>
+// QUEUE = true (uniform cold batches): the wavefront is persistent.  Its group slots draw candidates from a counter in
+// device memory; a slot whose candidate has finished writes it back and takes the next one at the top of the loop,
+// while the other slots keep iterating -- a wavefront no longer runs as long as its slowest group for every group it
+// holds (on the scenario_1 batch the slowest of three needs 11 iterations against a mean of 9.7).  The counter is read
+// one candidate ahead, so its latency is hidden behind ten iterations; which slot solves a candidate has no influence
+// on its result.
+template <bool WARM, bool ORDERED, bool ELASTIC = false, bool QUEUE = false>
 __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double *__restrict__ mqm, double (*lds)[64],
                                                const int wave_id, const int lane) {
+  static_assert(!QUEUE || (!WARM && !ORDERED && !ELASTIC), "the queue serves uniform cold batches");
   constexpr bool CACHE_RP = !ELASTIC;   // see the main loop
   constexpr bool FULL = ELASTIC;                 // rows kept: see rows_kept()
   constexpr int NR = rows_kept<FULL>();
@@ -259,60 +266,42 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   const bool lane_in_group = g < gpw;
   const int gl = lane_in_group ? g : gpw - 1;
   const int gbase = gl * S;
-  long long cand = (long long)pair * gpw + gl;
-  const bool valid = lane_in_group && cand < ncand;
-  if (cand >= ncand) cand = ncand - 1;
-  const int b = ORDERED ? a.order[cand0 + (int)cand] : (int)cand;
-  const long long prob = 2LL * b + axis;
   const bool first = (k == 0), last = (k == S - 1);
   const int m = S >> 1;                               // root block of the two-sided elimination
   const bool top = k < m, bot = k > m, mid = k == m;
   const int my_step = top ? k : (bot ? S - 1 - k : m);  // the step at which this lane owns a pivot
-
-  // ---------------- load the segment record (coalesced: lanes -> consecutive (b,k)) ----------
   const size_t BS = (size_t)a.B * a.seg_stride;
-  const size_t e = (size_t)b * a.seg_stride + k;
   const double *sg = a.seg;
-  const double t = sg[BTRAPZ_F_T * BS + e];
-  const double it = 1.0 / t;
-  const NullMap nm = {it, t * 0.05};
   const Shared &sh = a.sh;
   const int variant = sh.variant;
+  // P block (solve_3d.cc:159-171) from the batch-invariant MQM_d = M' pQp_d M: the table is
+  // wave-uniform (one axis per wave) -> scalar loads.
+  const double *__restrict__ mq = mqm + axis * 84;
+  const size_t lam_row = (size_t)a.B * a.seg_stride;
+  const double eps = a.eps;
+  [[maybe_unused]] const double edelta = ELASTIC ? a.elastic_delta : 0.0;
+  const double inv_m = 1.0 / ((double)(2 * NR) * (double)S);
 
-  // position rows: lo_i = plo0 + i*dplo , up_i = phi0 + i*dphi  (solve_3d.cc:827-828,965-966)
-  double plo0, dplo, phi0, dphi;
-  {
-    double lb, ls, ub, us;
-    if (axis == 0) {
-      lb = sg[BTRAPZ_F_DOWN_BIAS * BS + e]; ls = sg[BTRAPZ_F_DOWN_SKEW * BS + e];
-      ub = sg[BTRAPZ_F_UPP_BIAS * BS + e];  us = sg[BTRAPZ_F_UPP_SKEW * BS + e];
-    } else {
-      lb = sg[BTRAPZ_F_L_DOWN_BIAS * BS + e]; ls = sg[BTRAPZ_F_L_DOWN_SKEW * BS + e];
-      ub = sg[BTRAPZ_F_L_UPP_BIAS * BS + e];  us = sg[BTRAPZ_F_L_UPP_SKEW * BS + e];
-    }
-    plo0 = lb; dplo = ls * 0.2 * t; phi0 = ub; dphi = us * 0.2 * t;
-    if (variant == BTRAPZ_CUBOID) {
-      if (axis == 0) {  // cuboid_3d.cc:677-689: inscribed interval, clamped to [0,100]
-        const double lo = fmax(0.0, fmax(lb, lb + ls * t));
-        const double hi = fmin(100.0, fmin(ub, ub + us * t));
-        plo0 = lo; phi0 = hi;
-      } else {  // cuboid_3d.cc:826-827
-        plo0 = sg[BTRAPZ_F_BEG_L * BS + e]; phi0 = sg[BTRAPZ_F_END_L * BS + e];
-      }
-      dplo = 0.0; dphi = 0.0;
-    }
-  }
-  // velocity rows (solve_3d.cc:835-859 s axis; :1003-1004 l axis: dy_bounds_[i], i = row index)
-  double vlo[5], vhi[5];
-  if (axis == 0) {
-    const double lo = sg[BTRAPZ_F_DS_LO * BS + e], hi = sg[BTRAPZ_F_DS_HI * BS + e];
-    UNROLL for (int i = 0; i < 5; i++) { vlo[i] = lo; vhi[i] = hi; }
-  } else {
-    UNROLL for (int i = 0; i < 5; i++) { vlo[i] = a.dl_bounds[(size_t)b * 10 + 2 * i]; vhi[i] = a.dl_bounds[(size_t)b * 10 + 2 * i + 1]; }
-  }
-  // acceleration / jerk rows (solve_3d.cc:862-888, 1010-1037)
-  const double alo = (axis == 0 ? sh.acc_s[0] : sh.acc_l[0]) * t, ahi = (axis == 0 ? sh.acc_s[1] : sh.acc_l[1]) * t;
-  const double jlo = (axis == 0 ? sh.jerk_s[0] : sh.jerk_l[0]) * t * t, jhi = (axis == 0 ? sh.jerk_s[1] : sh.jerk_l[1]) * t * t;
+  // ---- everything that belongs to the candidate a group is solving (set by begin_candidate) ----
+  int b = 0;                       // candidate
+  bool valid = false;              // this lane holds a segment of a real candidate
+  size_t lam_e = 0;                // its slot in the warm-start arrays
+  double t = 1.0, it = 1.0, t2 = 1.0, t3 = 1.0, it3 = 1.0, pend = 0.0;
+  NullMap nm = {1.0, 0.05};
+  double plo0 = 0.0, dplo = 0.0, phi0 = 0.0, dphi = 0.0, vlo[5], vhi[5], alo = 0.0, ahi = 0.0, jlo = 0.0, jhi = 0.0;
+  double mplo = 0.0, mphi = 0.0, mvlo = 0.0, mvhi = 0.0;
+  double q[6], Xinit[3], Pk[21], qn = 0.0, bnorm = 0.0;
+  bool infeasible_bounds = false, no_solution = false;
+  double X[3] = {0.0, 0.0, 0.0}, Xcold0 = 0.0, sl[NR], su[NR];
+  bool warm_started = false, restarted = true;   // a warm-started group that stalls gets ONE cold restart
+  int it0 = 0;                                   // iteration at which the current start was made
+  double best_score = 1e300, Xb[3] = {0.0, 0.0, 0.0};
+  int best_it = 0, iters = 0;
+  bool done = true;
+  // The group's own iteration count.  (Warm-start instantiations: when one group of the wavefront restarts cold the
+  // others lose that pass of the loop; queue: the groups of a wavefront are at different iterations.  A candidate's
+  // stall / step-rule / iteration bookkeeping must not depend on which candidates share its wavefront.)
+  int eit = 0;
 
   // bounds of the rows as the reference assembles them ...
 #define LO0(r) ((r) < 6 ? plo0 + (double)(r) * dplo : (r) < 11 ? vlo[((r) >= 6 && (r) < 11) ? (r) - 6 : 0] : (r) < 15 ? alo : jlo)
@@ -320,97 +309,13 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   // ... and of the rows this solve keeps (rows_kept): the last position and velocity row of a segment (5, 10) carry the
   // intersection with the next segment's first ones (0, 6), which state the same joint quantity; the acceleration rows
   // 14 / 11 are one and the same interval for a, scaled by the two durations.
-  double mplo = plo0 + 5.0 * dplo, mphi = phi0 + 5.0 * dphi, mvlo = vlo[4], mvhi = vhi[4];
-  bool joint_empty = false;
-  if constexpr (!FULL) {
-    const double nplo = from_next(plo0), nphi = from_next(phi0), nvlo = from_next(vlo[0]), nvhi = from_next(vhi[0]);
-    if (!last) {
-      const bool own_ok = mplo <= mphi && mvlo <= mvhi && nplo <= nphi && nvlo <= nvhi;
-      mplo = fmax(mplo, nplo); mphi = fmin(mphi, nphi); mvlo = fmax(mvlo, nvlo); mvhi = fmin(mvhi, nvhi);
-      joint_empty = own_ok && (mplo > mphi || mvlo > mvhi);   // two consistent rows that contradict each other
-    }
-  }
 #define LO(r) ((!FULL && (r) == 5) ? mplo : (!FULL && (r) == 10) ? mvlo : LO0(r))
 #define UP(r) ((!FULL && (r) == 5) ? mphi : (!FULL && (r) == 10) ? mvhi : UP0(r))
-
-  // P block (solve_3d.cc:159-171) from the batch-invariant MQM_d = M' pQp_d M: the table is
-  // wave-uniform (one axis per wave) -> scalar loads.
-  const double *__restrict__ mq = mqm + axis * 84;
-  const double t3 = t * t * t, it3 = it * it * it, t2 = t * t;
-  const double pend = last ? 2.0 * (axis == 0 ? sh.weight_end_s : sh.weight_end_l) * t2 : 0.0;  // :164-168
 #define LOAD_P(H)                                                                                     \
   UNROLL for (int i_ = 0; i_ < 21; i_++)                                                              \
     H[i_] = 2.0 * (t3 * mq[i_] + t * mq[21 + i_] + it * mq[42 + i_] + it3 * mq[63 + i_]);             \
   H[SYM(5, 5)] += pend;
 #define HSYM(H, i, j) ((i) <= (j) ? H[SYM(i, j)] : H[SYM(j, i)])
-  // q block (solve_3d.cc:248-268): q_p in the monomial basis, then q_p * M
-  double q[6];
-  {
-    const double skew = sg[(axis == 0 ? BTRAPZ_F_X_SKEW : BTRAPZ_F_Y_SKEW) * BS + e];
-    const double bias = sg[(axis == 0 ? BTRAPZ_F_X_BIAS : BTRAPZ_F_Y_BIAS) * BS + e];
-    const double wr = axis == 0 ? sh.w_s[0] : sh.w_l[0], wd = axis == 0 ? sh.w_s[1] : sh.w_l[1];
-    const double dref = axis == 0 ? sh.ds_ref : sh.dl_ref;
-    double qp[6];
-    UNROLL for (int i = 0; i < 6; i++) {
-      qp[i] = -2.0 * (t * t * t) * wr * skew / (double)(i + 2) - 2.0 * (t * t) * wr * bias / (double)(i + 1);
-      if (i > 0) qp[i] += -2.0 * wd * dref * t;
-    }
-    // M (Bernstein -> monomial, solve_3d.cc:122-127), row = power, col = control point
-    q[0] = qp[0] - 5.0 * qp[1] + 10.0 * qp[2] - 10.0 * qp[3] + 5.0 * qp[4] - qp[5];
-    q[1] = 5.0 * qp[1] - 20.0 * qp[2] + 30.0 * qp[3] - 20.0 * qp[4] + 5.0 * qp[5];
-    q[2] = 10.0 * qp[2] - 30.0 * qp[3] + 30.0 * qp[4] - 10.0 * qp[5];
-    q[3] = 10.0 * qp[3] - 20.0 * qp[4] + 10.0 * qp[5];
-    q[4] = 5.0 * qp[4] - 5.0 * qp[5];
-    q[5] = qp[5];
-    if (last) q[5] -= dref * 2.0 * a.ref_end[(size_t)b * 2 + axis] * t;  // :268/:315 (multiplies by d_ref: bug-compatible)
-  }
-  double Xinit[3];
-  UNROLL for (int i = 0; i < 3; i++) Xinit[i] = a.init[(size_t)b * 6 + axis * 3 + i];
-
-  // ---------------- consistency of the bounds -------------------------------------------
-  double gapmin = 1e300, bnorm = 0.0, qn = 0.0;
-  static_for<18>([&](auto r_c) {          // (all rows of the reference: a row with l > u is reported as such)
-    constexpr int r = decltype(r_c)::value;
-    gapmin = fmin(gapmin, UP0(r) - LO0(r));
-    bnorm = fmax(bnorm, fmax(fabs(LO0(r)), fabs(UP0(r))));
-  });
-  // Rows that no iterate can change: segment 0's first position / velocity / acceleration row state the given initial
-  // state (c0, c1, c2 of segment 0 follow from it alone), and a joint whose two sides leave no common value.  If they
-  // cannot be met the problem has no solution: the solve stops before its first iteration with the status of a stalled
-  // one (which the rescue pass, btrapz_options.elastic, then takes over).
-  bool no_solution_lane = false;
-  if constexpr (!FULL) {
-    double c0, c1, c2;
-    const double Xi[3] = {a.init[(size_t)b * 6 + axis * 3], a.init[(size_t)b * 6 + axis * 3 + 1], a.init[(size_t)b * 6 + axis * 3 + 2]};
-    U_apply(nm, Xi, c0, c1, c2);
-    auto outside = [&](double g, double lo, double hi) {
-      const double tol = 1e-7 * (1.0 + fmax(fabs(lo), fabs(hi)));
-      return !(g >= lo - tol && g <= hi + tol);
-    };
-    no_solution_lane = (first && (outside(t * c0, LO0(0), UP0(0)) || outside(5.0 * (c1 - c0), LO0(6), UP0(6)) ||
-                                  outside(20.0 * ((c0 - 2.0 * c1) + c2), LO0(11), UP0(11)))) || joint_empty;
-  }
-  UNROLL for (int i = 0; i < 6; i++) qn = fmax(qn, fabs(q[i]));
-  // ---------------- starting point: constant-velocity propagation of the initial state, or the caller's
-  // joint states (warm start; a lane whose values are not finite keeps the cold start) -----
-  double X[3], Xcold0;
-  {
-    wave_lds_sync();
-    lds[L_RED][lane] = t;
-    wave_lds_sync();
-    double tsum = 0.0;
-    for (int j = 0; j < S; j++) tsum += (j <= k) ? lds[L_RED][gbase + j] : 0.0;
-    Xcold0 = Xinit[0] + Xinit[1] * tsum;
-  }
-  {
-    const Red4 r0 = group_reduce<0, 1, 1, 2>(lds + L_RED, lane, gbase, k, S, no_solution_lane ? 1.0 : 0.0, bnorm, qn, gapmin);
-    bnorm = r0.b; qn = r0.c; gapmin = r0.d;
-    no_solution_lane = r0.a > 0.0;      // (group-uniform from here on)
-  }
-  const bool infeasible_bounds = !(gapmin >= 0.0) || !(t > 0.0);
-  const bool no_solution = no_solution_lane;
-
-  double sl[NR], su[NR];
 #define LL(r) lds[L_LL + SI(r)][lane]
 #define LU(r) lds[L_LU + SI(r)][lane]
   // cold start of this lane: slacks max(gap, 1), multipliers 1
@@ -426,59 +331,278 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       LL(r) = 1.0; LU(r) = 1.0;
     END_ROWS
   };
-  // multipliers of this lane in the warm-start arrays: [axis][row 0..35][b][k]
-  const size_t lam_row = (size_t)a.B * a.seg_stride, lam_e = (size_t)axis * 36 * lam_row + (size_t)b * a.seg_stride + k;
-  const bool warm_started = WARM && (a.x0 || a.lam0);
-  if (WARM && warm_started) {
-    // warm: slacks floored at smin, multipliers = earlier multipliers (sanitised) + mu0 / s so that every
-    // complementarity product is at least mu0
-    X[0] = Xcold0; X[1] = Xinit[1]; X[2] = 0.0;
-    if (a.x0) {
-      const double *xw = a.x0 + (((size_t)b * 2 + axis) * a.seg_stride + k) * 3;
-      const double w0 = xw[0], w1 = xw[1], w2 = xw[2];
-      if (fabs(w0) < 1e300 && fabs(w1) < 1e300 && fabs(w2) < 1e300) { X[0] = w0; X[1] = w1; X[2] = w2; }
+
+  // What a lane reads of its candidate: its segment's fields for the wavefront's axis and the candidate's per-axis
+  // records (coalesced: lanes -> consecutive (b, k)).  A plain value so that the queue can hold the NEXT candidate's
+  // record in registers while the current one iterates (its loads are issued a whole solve ahead of their use).
+  struct Record { double t, lb, ls, ub, us, begl, endl, v[10], skew, bias, ref_end, init[3]; };
+  auto load_record = [&](const int b_) {
+    Record r;
+    const size_t e_ = (size_t)b_ * a.seg_stride + k;
+    r.t = sg[BTRAPZ_F_T * BS + e_];
+    r.begl = 0.0; r.endl = 0.0;
+    if (axis == 0) {
+      r.lb = sg[BTRAPZ_F_DOWN_BIAS * BS + e_]; r.ls = sg[BTRAPZ_F_DOWN_SKEW * BS + e_];
+      r.ub = sg[BTRAPZ_F_UPP_BIAS * BS + e_];  r.us = sg[BTRAPZ_F_UPP_SKEW * BS + e_];
+      r.v[0] = sg[BTRAPZ_F_DS_LO * BS + e_]; r.v[1] = sg[BTRAPZ_F_DS_HI * BS + e_];
+      UNROLL for (int i = 2; i < 10; i++) r.v[i] = 0.0;
+    } else {
+      r.lb = sg[BTRAPZ_F_L_DOWN_BIAS * BS + e_]; r.ls = sg[BTRAPZ_F_L_DOWN_SKEW * BS + e_];
+      r.ub = sg[BTRAPZ_F_L_UPP_BIAS * BS + e_];  r.us = sg[BTRAPZ_F_L_UPP_SKEW * BS + e_];
+      if (variant == BTRAPZ_CUBOID) { r.begl = sg[BTRAPZ_F_BEG_L * BS + e_]; r.endl = sg[BTRAPZ_F_END_L * BS + e_]; }
+      UNROLL for (int i = 0; i < 10; i++) r.v[i] = a.dl_bounds[(size_t)b_ * 10 + i];
     }
-    double Xp[3], c[6];
-    UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(X[i]); Xp[i] = first ? Xinit[i] : v; }
-    U_apply(nm, Xp, c[0], c[1], c[2]);
-    V_apply(nm, X, c[3], c[4], c[5]);
-    const double smin = a.smin, mu0 = a.mu0;
-    FOR_ROWS(r)
-      const double gc_r = row_dot<r>(c, t);
-      const double s_l = fmax(gc_r - LO(r), smin), s_u = fmax(UP(r) - gc_r, smin);
-      double l_l = 0.0, l_u = 0.0;
-      if (a.lam0) {
-        const double p_l = a.lam0[lam_e + (size_t)r * lam_row], p_u = a.lam0[lam_e + (size_t)(18 + r) * lam_row];   // (layout of the header: 18 + 18 rows)
-        l_l = (p_l >= 0.0 && p_l < 1e300) ? p_l : 0.0; l_u = (p_u >= 0.0 && p_u < 1e300) ? p_u : 0.0;
+    r.skew = sg[(axis == 0 ? BTRAPZ_F_X_SKEW : BTRAPZ_F_Y_SKEW) * BS + e_];
+    r.bias = sg[(axis == 0 ? BTRAPZ_F_X_BIAS : BTRAPZ_F_Y_BIAS) * BS + e_];
+    r.ref_end = a.ref_end[(size_t)b_ * 2 + axis];
+    UNROLL for (int i = 0; i < 3; i++) r.init[i] = a.init[(size_t)b_ * 6 + axis * 3 + i];
+    return r;
+  };
+
+  // Sets up the solve of candidate b_new from its record in the lanes of the calling group(s).  (Called once for the
+  // whole wavefront, or -- queue -- under the mask of the groups that take a new candidate: everything in here is per
+  // lane or per group; the DPP reads across a group's last lane are masked by `last`.)
+  auto begin_candidate = [&](const int b_new, const bool valid_new, const Record &rec) {
+    b = b_new; valid = valid_new;
+    t = rec.t;
+    it = 1.0 / t;
+    nm = NullMap{it, t * 0.05};
+    // position rows: lo_i = plo0 + i*dplo , up_i = phi0 + i*dphi  (solve_3d.cc:827-828,965-966)
+    {
+      const double lb = rec.lb, ls = rec.ls, ub = rec.ub, us = rec.us;
+      plo0 = lb; dplo = ls * 0.2 * t; phi0 = ub; dphi = us * 0.2 * t;
+      if (variant == BTRAPZ_CUBOID) {
+        if (axis == 0) {  // cuboid_3d.cc:677-689: inscribed interval, clamped to [0,100]
+          const double lo = fmax(0.0, fmax(lb, lb + ls * t));
+          const double hi = fmin(100.0, fmin(ub, ub + us * t));
+          plo0 = lo; phi0 = hi;
+        } else {  // cuboid_3d.cc:826-827
+          plo0 = rec.begl; phi0 = rec.endl;
+        }
+        dplo = 0.0; dphi = 0.0;
       }
-      sl[SI(r)] = s_l; su[SI(r)] = s_u;
-      LL(r) = l_l + mu0 * rcp(s_l); LU(r) = l_u + mu0 * rcp(s_u);
-    END_ROWS
+    }
+    // velocity rows (solve_3d.cc:835-859 s axis; :1003-1004 l axis: dy_bounds_[i], i = row index)
+    if (axis == 0) {
+      UNROLL for (int i = 0; i < 5; i++) { vlo[i] = rec.v[0]; vhi[i] = rec.v[1]; }
+    } else {
+      UNROLL for (int i = 0; i < 5; i++) { vlo[i] = rec.v[2 * i]; vhi[i] = rec.v[2 * i + 1]; }
+    }
+    // acceleration / jerk rows (solve_3d.cc:862-888, 1010-1037)
+    alo = (axis == 0 ? sh.acc_s[0] : sh.acc_l[0]) * t; ahi = (axis == 0 ? sh.acc_s[1] : sh.acc_l[1]) * t;
+    jlo = (axis == 0 ? sh.jerk_s[0] : sh.jerk_l[0]) * t * t; jhi = (axis == 0 ? sh.jerk_s[1] : sh.jerk_l[1]) * t * t;
+    mplo = plo0 + 5.0 * dplo; mphi = phi0 + 5.0 * dphi; mvlo = vlo[4]; mvhi = vhi[4];
+    bool joint_empty = false;
+    if constexpr (!FULL) {
+      const double nplo = from_next(plo0), nphi = from_next(phi0), nvlo = from_next(vlo[0]), nvhi = from_next(vhi[0]);
+      if (!last) {
+        const bool own_ok = mplo <= mphi && mvlo <= mvhi && nplo <= nphi && nvlo <= nvhi;
+        mplo = fmax(mplo, nplo); mphi = fmin(mphi, nphi); mvlo = fmax(mvlo, nvlo); mvhi = fmin(mvhi, nvhi);
+        joint_empty = own_ok && (mplo > mphi || mvlo > mvhi);   // two consistent rows that contradict each other
+      }
+    }
+    t3 = t * t * t; it3 = it * it * it; t2 = t * t;
+    pend = last ? 2.0 * (axis == 0 ? sh.weight_end_s : sh.weight_end_l) * t2 : 0.0;  // :164-168
+    // q block (solve_3d.cc:248-268): q_p in the monomial basis, then q_p * M
+    {
+      const double skew = rec.skew, bias = rec.bias;
+      const double wr = axis == 0 ? sh.w_s[0] : sh.w_l[0], wd = axis == 0 ? sh.w_s[1] : sh.w_l[1];
+      const double dref = axis == 0 ? sh.ds_ref : sh.dl_ref;
+      double qp[6];
+      UNROLL for (int i = 0; i < 6; i++) {
+        qp[i] = -2.0 * (t * t * t) * wr * skew / (double)(i + 2) - 2.0 * (t * t) * wr * bias / (double)(i + 1);
+        if (i > 0) qp[i] += -2.0 * wd * dref * t;
+      }
+      // M (Bernstein -> monomial, solve_3d.cc:122-127), row = power, col = control point
+      q[0] = qp[0] - 5.0 * qp[1] + 10.0 * qp[2] - 10.0 * qp[3] + 5.0 * qp[4] - qp[5];
+      q[1] = 5.0 * qp[1] - 20.0 * qp[2] + 30.0 * qp[3] - 20.0 * qp[4] + 5.0 * qp[5];
+      q[2] = 10.0 * qp[2] - 30.0 * qp[3] + 30.0 * qp[4] - 10.0 * qp[5];
+      q[3] = 10.0 * qp[3] - 20.0 * qp[4] + 10.0 * qp[5];
+      q[4] = 5.0 * qp[4] - 5.0 * qp[5];
+      q[5] = qp[5];
+      if (last) q[5] -= dref * 2.0 * rec.ref_end * t;  // :268/:315 (multiplies by d_ref: bug-compatible)
+    }
+    UNROLL for (int i = 0; i < 3; i++) Xinit[i] = rec.init[i];
+
+    // ---------------- consistency of the bounds -------------------------------------------
+    double gapmin = 1e300;
+    bnorm = 0.0; qn = 0.0;
+    static_for<18>([&](auto r_c) {          // (all rows of the reference: a row with l > u is reported as such)
+      constexpr int r = decltype(r_c)::value;
+      gapmin = fmin(gapmin, UP0(r) - LO0(r));
+      bnorm = fmax(bnorm, fmax(fabs(LO0(r)), fabs(UP0(r))));
+    });
+    // Rows that no iterate can change: segment 0's first position / velocity / acceleration row state the given
+    // initial state (c0, c1, c2 of segment 0 follow from it alone), and a joint whose two sides leave no common value.
+    // If they cannot be met the problem has no solution: the solve stops before its first iteration with the status of
+    // a stalled one (which the rescue pass, btrapz_options.elastic, then takes over).
+    bool no_solution_lane = false;
+    if constexpr (!FULL) {
+      double c0, c1, c2;
+      U_apply(nm, Xinit, c0, c1, c2);
+      auto outside = [&](double g_, double lo, double hi) {
+        const double tol = 1e-7 * (1.0 + fmax(fabs(lo), fabs(hi)));
+        return !(g_ >= lo - tol && g_ <= hi + tol);
+      };
+      no_solution_lane = (first && (outside(t * c0, LO0(0), UP0(0)) || outside(5.0 * (c1 - c0), LO0(6), UP0(6)) ||
+                                    outside(20.0 * ((c0 - 2.0 * c1) + c2), LO0(11), UP0(11)))) || joint_empty;
+    }
+    UNROLL for (int i = 0; i < 6; i++) qn = fmax(qn, fabs(q[i]));
+    // ---------------- starting point: constant-velocity propagation of the initial state, or the caller's
+    // joint states (warm start; a lane whose values are not finite keeps the cold start) -----
+    {
+      wave_lds_sync();
+      lds[L_RED][lane] = t;
+      wave_lds_sync();
+      double tsum = 0.0;
+      for (int j = 0; j < S; j++) tsum += (j <= k) ? lds[L_RED][gbase + j] : 0.0;
+      Xcold0 = Xinit[0] + Xinit[1] * tsum;
+    }
+    {
+      const Red4 r0 = group_reduce<0, 1, 1, 2>(lds + L_RED, lane, gbase, k, S, no_solution_lane ? 1.0 : 0.0, bnorm, qn, gapmin);
+      bnorm = r0.b; qn = r0.c; gapmin = r0.d;
+      no_solution = r0.a > 0.0;
+    }
+    infeasible_bounds = !(gapmin >= 0.0) || !(t > 0.0);
+
+    // multipliers of this lane in the warm-start arrays: [axis][row 0..35][b][k]
+    lam_e = (size_t)axis * 36 * lam_row + (size_t)b * a.seg_stride + k;
+    warm_started = WARM && (a.x0 || a.lam0);
+    if (WARM && warm_started) {
+      // warm: slacks floored at smin, multipliers = earlier multipliers (sanitised) + mu0 / s so that every
+      // complementarity product is at least mu0
+      X[0] = Xcold0; X[1] = Xinit[1]; X[2] = 0.0;
+      if (a.x0) {
+        const double *xw = a.x0 + (((size_t)b * 2 + axis) * a.seg_stride + k) * 3;
+        const double w0 = xw[0], w1 = xw[1], w2 = xw[2];
+        if (fabs(w0) < 1e300 && fabs(w1) < 1e300 && fabs(w2) < 1e300) { X[0] = w0; X[1] = w1; X[2] = w2; }
+      }
+      double Xp[3], c[6];
+      UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(X[i]); Xp[i] = first ? Xinit[i] : v; }
+      U_apply(nm, Xp, c[0], c[1], c[2]);
+      V_apply(nm, X, c[3], c[4], c[5]);
+      const double smin = a.smin, mu0 = a.mu0;
+      FOR_ROWS(r)
+        const double gc_r = row_dot<r>(c, t);
+        const double s_l = fmax(gc_r - LO(r), smin), s_u = fmax(UP(r) - gc_r, smin);
+        double l_l = 0.0, l_u = 0.0;
+        if (a.lam0) {
+          const double p_l = a.lam0[lam_e + (size_t)r * lam_row], p_u = a.lam0[lam_e + (size_t)(18 + r) * lam_row];   // (layout of the header: 18 + 18 rows)
+          l_l = (p_l >= 0.0 && p_l < 1e300) ? p_l : 0.0; l_u = (p_u >= 0.0 && p_u < 1e300) ? p_u : 0.0;
+        }
+        sl[SI(r)] = s_l; su[SI(r)] = s_u;
+        LL(r) = l_l + mu0 * rcp(s_l); LU(r) = l_u + mu0 * rcp(s_u);
+      END_ROWS
+    } else {
+      cold_start();
+    }
+    restarted = !warm_started;
+    it0 = 0; eit = 0;
+    // P block of this lane's segment, once per solve: rebuilding it from the scalar table where it is needed (twice
+    // per iteration: 168 FMAs and the spill traffic of 84 scalar doubles) was the price of an earlier, tighter
+    // register budget; kept live it costs the allocator nothing measurable (6.67 -> 6.32 ms).
+    LOAD_P(Pk)
+    best_score = 1e300; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2];
+    best_it = 0; iters = 0;
+    done = !valid || infeasible_bounds || no_solution;
+  };
+  auto write_back = [&]() {
+    // ---------------- write back: multipliers (warm start of a later solve), control points, objective/status ----
+    if (WARM && a.lam_out && valid) {
+      FOR_ROWS(r)
+        a.lam_out[lam_e + (size_t)r * lam_row] = LL(r); a.lam_out[lam_e + (size_t)(18 + r) * lam_row] = LU(r);
+      END_ROWS
+      if constexpr (!FULL) {   // the rows this lane does not keep (their bounds live in the previous segment's last rows)
+        UNROLL for (int r0 = 0; r0 < 3; r0++) {
+          const int rr_ = r0 == 0 ? 0 : r0 == 1 ? 6 : 11;
+          a.lam_out[lam_e + (size_t)rr_ * lam_row] = 0.0; a.lam_out[lam_e + (size_t)(18 + rr_) * lam_row] = 0.0;
+        }
+      }
+    }
+    {
+      double Xp[3], c[6];
+      UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(Xb[i]); Xp[i] = first ? Xinit[i] : v; }
+      U_apply(nm, Xp, c[0], c[1], c[2]);
+      V_apply(nm, Xb, c[3], c[4], c[5]);
+      double obj = 0.0;
+      double Pm[21];
+      UNROLL for (int i_ = 0; i_ < 21; i_++) Pm[i_] = Pk[i_];
+      UNROLL for (int i = 0; i < 6; i++) {
+        double s = 0.0;
+        UNROLL for (int j = 0; j < 6; j++) s += HSYM(Pm, i, j) * c[j];
+        obj += c[i] * (0.5 * s + q[i]);
+      }
+      // rescue pass: largest violation of an original row by the returned control points
+      double viol = 0.0;
+      if constexpr (ELASTIC) {
+        FOR_ROWS(r)
+          const double gcr = row_dot<r>(c, t);
+          viol = fmax(viol, fmax(LO(r) - gcr, gcr - UP(r)));
+        END_ROWS
+      }
+      const Red4 ro = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, obj, viol, 0.0, 0.0);
+      if (valid) {
+        // control points in the reference's order: s axis (6 S), then l axis (6 S); rows are 12*seg_stride apart
+        double *dst = a.ctrl + (size_t)b * 12 * a.seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
+        UNROLL for (int i = 0; i < 6; i++) dst[i] = c[i];
+        if (first) {
+          int st;
+          if (infeasible_bounds) st = BTRAPZ_PRIMAL_INFEASIBLE;
+          else if (best_score < 1e-7) st = BTRAPZ_SOLVED;
+          else if (best_score < 1e-5) st = BTRAPZ_SOLVED_INACCURATE;
+          else st = BTRAPZ_MAX_ITER_REACHED;
+          if constexpr (ELASTIC) {
+            // converged on the relaxed problem: feasible after all (rows kept to 1e-7) -> as solved; least violation
+            // within the caller's tolerance -> the reference's "solved inaccurate"; beyond it -> infeasible
+            if (st > 0 && ro.b > 1e-7 * (1.0 + bnorm)) st = ro.b <= a.elastic_tol ? BTRAPZ_SOLVED_INACCURATE : BTRAPZ_PRIMAL_INFEASIBLE;
+          }
+          const long long prob = 2LL * b + axis;
+          a.axis_obj[prob] = ro.a;
+          a.axis_status[prob] = st;
+          a.axis_iters[prob] = ELASTIC ? iters + a.axis_iters[prob] + 1 : iters;   // rescue: on top of the first attempt's
+        }
+      }
+    }
+  };
+
+  // ---- which candidate(s) this wavefront solves ----
+  // queue: this slot has drawn an index beyond the batch (the idle tail lanes of a wavefront never draw one)
+  [[maybe_unused]] bool retired = QUEUE && !lane_in_group;
+  [[maybe_unused]] bool has_cand = false;    // queue: the slot holds a candidate whose result is still to be written
+  // queue: the index the slot takes at its next refill, drawn one solve ahead (held by the group's first lane, so the
+  // counter's latency is hidden).  (Holding the next candidate's whole record in registers as well was tried: the
+  // loads have to be parked in AGPRs, which waits for them on the spot -- slower.)
+  [[maybe_unused]] int next_cand = 0;
+  if constexpr (QUEUE) {
+    if (first && lane_in_group) next_cand = atomicAdd(a.queue + axis, 1);
   } else {
-    cold_start();
+    long long cand = (long long)pair * gpw + gl;
+    const bool valid0 = lane_in_group && cand < ncand;
+    if (cand >= ncand) cand = ncand - 1;
+    const int b0 = ORDERED ? a.order[cand0 + (int)cand] : (int)cand;
+    begin_candidate(b0, valid0, load_record(b0));
   }
-  bool restarted = !warm_started;   // a warm-started group that stalls gets ONE cold restart
-  int it0 = 0;                      // iteration at which the current start was made
 
-  // P block of this lane's segment, once per solve: rebuilding it from the scalar table where it is needed (twice
-  // per iteration: 168 FMAs and the spill traffic of 84 scalar doubles) was the price of an earlier, tighter
-  // register budget; kept live it costs the allocator nothing measurable (6.67 -> 6.32 ms).
-  double Pk[21];
-  LOAD_P(Pk)
-  const double eps = a.eps;
-  [[maybe_unused]] const double edelta = ELASTIC ? a.elastic_delta : 0.0;
-  const double inv_m = 1.0 / ((double)(2 * NR) * (double)S);
-  double best_score = 1e300, Xb[3] = {X[0], X[1], X[2]};
-  int best_it = 0, iters = 0;
-  bool done = !valid || infeasible_bounds || no_solution;
-  // Warm-start instantiations: when one group of the wavefront restarts cold, the others lose that pass of the loop
-  // (wave-uniform `continue` below).  Their iteration count must not see it, or a candidate's stall / step-rule /
-  // iteration bookkeeping would depend on which candidates share its wavefront: every test below uses the group's own
-  // count `eit` (= iter in the cold instantiations).
-  [[maybe_unused]] int skipped = 0;
-
-  for (int iter = 0; iter < a.max_iter; ++iter) {
-    const int eit = WARM ? iter - skipped : iter;
+  for (;;) {
+    if constexpr (QUEUE) {
+      // A slot whose candidate is finished (or that has none yet) writes it back and takes the next one; the other
+      // slots of the wavefront wait for the ~0.2 iterations this takes and go on where they were.
+      const bool refill = done && !retired;
+      if (__any(refill)) {
+        if (refill) {
+          if (has_cand) write_back();
+          wave_lds_sync();
+          if (first && lane_in_group) lds[L_RED][lane] = (double)next_cand;
+          wave_lds_sync();
+          const int cnew = (int)lds[L_RED][gbase];
+          if (cnew < a.B) {
+            if (first && lane_in_group) next_cand = atomicAdd(a.queue + axis, 1);   // (needed a whole solve from now)
+            begin_candidate(cnew, lane_in_group, load_record(cnew)); has_cand = true;
+          } else { retired = true; has_cand = false; valid = false; done = true; }
+        }
+        if (__all(retired)) break;
+      }
+    }
     // ---- 1. control points of this segment, rows, residuals, gradient ----
     // Row residuals r_l = G c - s_l - l, r_u = G c + s_u - u: constant within an iteration and needed by six row
     // loops.  Cached (36 doubles; the allocator parks them in AGPRs) they save ~100 instructions per row loop:
@@ -547,8 +671,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       else if (WARM && !restarted && (stalled || (eit - it0 >= 12 && best_score > 1e-4) || eit - it0 >= 24)) restart_now = true;
       else if (stalled) done = true;
 #endif
+      // the iteration budget: the iterate just evaluated was the last one (a step nobody evaluates is not taken)
+      if (!done && !restart_now && eit + 1 >= a.max_iter) done = true;
     }
-    if (__all(done)) break;
+    if constexpr (!QUEUE) { if (__all(done)) break; }
     if (WARM && __any(restart_now)) {
       // wave-uniform branch; the other groups of the wavefront only lose this iteration's Newton step.  A group
       // restarts as a whole (the score is group-uniform), so the DPP reads inside cold_start stay in the group.
@@ -556,8 +682,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         cold_start();
         best_score = 1e300; best_it = eit + 1; it0 = eit + 1; restarted = true;
         Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2];
-      } else {
-        ++skipped;   // this group did not take a step in this pass
+        ++eit;       // (the other groups did not take a step in this pass: their count stands)
       }
       continue;
     }
@@ -846,63 +971,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 #undef ROW_BASE
 #undef ROW_STEP
 #undef ROW_PREFETCH
+    if (!done) ++eit;
   }
+  if constexpr (!QUEUE) write_back();
 
-  // ---------------- write back: multipliers (warm start of a later solve), control points, objective/status ----
-  if (WARM && a.lam_out && valid) {
-    FOR_ROWS(r)
-      a.lam_out[lam_e + (size_t)r * lam_row] = LL(r); a.lam_out[lam_e + (size_t)(18 + r) * lam_row] = LU(r);
-    END_ROWS
-    if constexpr (!FULL) {   // the rows this lane does not keep (their bounds live in the previous segment's last rows)
-      UNROLL for (int r0 = 0; r0 < 3; r0++) {
-        const int rr_ = r0 == 0 ? 0 : r0 == 1 ? 6 : 11;
-        a.lam_out[lam_e + (size_t)rr_ * lam_row] = 0.0; a.lam_out[lam_e + (size_t)(18 + rr_) * lam_row] = 0.0;
-      }
-    }
-  }
-  {
-    double Xp[3], c[6];
-    UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(Xb[i]); Xp[i] = first ? Xinit[i] : v; }
-    U_apply(nm, Xp, c[0], c[1], c[2]);
-    V_apply(nm, Xb, c[3], c[4], c[5]);
-    double obj = 0.0;
-    double Pm[21];
-    UNROLL for (int i_ = 0; i_ < 21; i_++) Pm[i_] = Pk[i_];
-    UNROLL for (int i = 0; i < 6; i++) {
-      double s = 0.0;
-      UNROLL for (int j = 0; j < 6; j++) s += HSYM(Pm, i, j) * c[j];
-      obj += c[i] * (0.5 * s + q[i]);
-    }
-    // rescue pass: largest violation of an original row by the returned control points
-    double viol = 0.0;
-    if constexpr (ELASTIC) {
-      FOR_ROWS(r)
-        const double gcr = row_dot<r>(c, t);
-        viol = fmax(viol, fmax(LO(r) - gcr, gcr - UP(r)));
-      END_ROWS
-    }
-    const Red4 ro = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, obj, viol, 0.0, 0.0);
-    if (valid) {
-      // control points in the reference's order: s axis (6 S), then l axis (6 S); rows are 12*seg_stride apart
-      double *dst = a.ctrl + (size_t)b * 12 * a.seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
-      UNROLL for (int i = 0; i < 6; i++) dst[i] = c[i];
-      if (first) {
-        int st;
-        if (infeasible_bounds) st = BTRAPZ_PRIMAL_INFEASIBLE;
-        else if (best_score < 1e-7) st = BTRAPZ_SOLVED;
-        else if (best_score < 1e-5) st = BTRAPZ_SOLVED_INACCURATE;
-        else st = BTRAPZ_MAX_ITER_REACHED;
-        if constexpr (ELASTIC) {
-          // converged on the relaxed problem: feasible after all (rows kept to 1e-7) -> as solved; least violation
-          // within the caller's tolerance -> the reference's "solved inaccurate"; beyond it -> infeasible
-          if (st > 0 && ro.b > 1e-7 * (1.0 + bnorm)) st = ro.b <= a.elastic_tol ? BTRAPZ_SOLVED_INACCURATE : BTRAPZ_PRIMAL_INFEASIBLE;
-        }
-        a.axis_obj[prob] = ro.a;
-        a.axis_status[prob] = st;
-        a.axis_iters[prob] = ELASTIC ? iters + a.axis_iters[prob] + 1 : iters;   // rescue: on top of the first attempt's
-      }
-    }
-  }
 }
 
 // Four instantiations: {cold, warm start} x {candidates in memory order, candidates through a.order (ragged batches
@@ -922,6 +994,11 @@ __global__ __launch_bounds__(64) void ipm_solve_warm_kernel(const KernelArgs a, 
 __global__ __launch_bounds__(64) void ipm_solve_warm_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[lds_rows<false>()][64];
   ipm_solve_body<true, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
+}
+// Uniform cold batches much larger than the machine: persistent wavefronts over a candidate queue (see QUEUE above).
+__global__ __launch_bounds__(64) void ipm_solve_queue_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  __shared__ double lds[lds_rows<false>()][64];
+  ipm_solve_body<false, false, false, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 // Rescue pass (btrapz_options.elastic): the stalled axis problems, listed per axis, with elastic rows.
 __global__ __launch_bounds__(64) void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm) {

@@ -54,7 +54,7 @@ def test_params_layout_is_the_reference_abi():
         assert P.iteration.offset == 80
     assert C.sizeof(native.CShared) == 21 * 8 + 8
     assert C.sizeof(native.CSegment) == 104
-    assert C.sizeof(native.COptions) == 56               # btrapz_options: int (+pad), three doubles, int (+pad), two doubles
+    assert C.sizeof(native.COptions) == 64               # btrapz_options: int (+pad), three doubles, int (+pad), two doubles, int (+pad)
     assert native.COptions.elastic.offset == 32 and native.COptions.elastic_delta.offset == 48
     assert C.sizeof(native.CWarm) == 3 * 8 + 2 * 8 + 8   # btrapz_warm: three pointers, two doubles, one pointer
     assert [f[0] for f in native.CWarm._fields_] == ["x0", "lam0", "lam_out", "mu0", "smin", "hint"]

@@ -116,3 +116,33 @@ def test_default_step_rule_loses_no_candidate_the_conservative_rule_solves(monke
         scale = np.abs(cc[both]).max(axis=1)
         assert (np.abs(cc[both] - cd[both]).max(axis=1) <= 1e-5 * scale).all()
         assert idf[both].mean() < ic[both].mean()
+
+
+def test_candidate_queue_changes_the_schedule_not_the_results():
+    """btrapz_options.queue: persistent wavefronts draw candidates from a counter; which slot of which wavefront solves
+    a candidate, and next to whom, must not matter.  Same statuses and iteration counts, control points equal to
+    rounding (the queue kernel is another instantiation of the same body), deterministic from run to run; against the
+    oracle's x* like any other path."""
+    import torch
+    from helpers import O
+    from spectral_amd import synth
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    batch, sh = synth.make_scenario1_batch(20000, 20, 0)        # ~6 candidates per wavefront slot, some without a solution
+    db = solver.upload(batch)
+    plain = {k: v.clone() for k, v in solver.solve(db, sh).items()}
+    q1 = {k: v.clone() for k, v in solver.solve(db, sh, queue=1).items()}
+    q2 = solver.solve(db, sh, queue=1)
+    torch.cuda.synchronize()
+    assert torch.equal(q1["ctrl"], q2["ctrl"]) and torch.equal(q1["cost"], q2["cost"])          # no race, no order dependence
+    assert torch.equal(plain["status"], q1["status"])
+    ok = (plain["status"] > 0)
+    it_p, it_q = plain["iters"][ok], q1["iters"][ok]
+    assert (it_p != it_q).sum().item() <= 0.001 * ok.sum().item()                                # (a rounding-level tie may fall either way)
+    x, y = plain["ctrl"][ok].cpu().numpy(), q1["ctrl"][ok].cpu().numpy()
+    assert np.abs(x - y).max() <= 1e-5 * np.abs(x).max()
+    xs, obj, st, _ = O.batch_solve(batch, sh, 19990, 20000, exact=True, threads=4)             # the last candidates drawn
+    got = q1["ctrl"].cpu().numpy()[19990:]
+    for i in range(10):
+        if st[i] == 1:
+            assert np.abs(got[i] - xs[i]).max() <= 1e-5 * np.abs(xs[i]).max()
