@@ -330,6 +330,17 @@ def main():
             for i in range(max(20, a.latency_reps // 4)):
                 t1 = time.perf_counter(); solver.ctx.solve_host(b1, shared); lat_h.append(time.perf_counter() - t1)
             out["p50_solve_latency_with_pcie_ms"] = float(np.percentile(np.array(lat_h[5:]) * 1e3, 50))
+            # the reference's own call pattern: ONE find_traj per replanning step (cart_frenet.py:1567) -- knot-level
+            # input of the same scene (N = 201, two lane corridors) through the host corridor stage and the one-launch
+            # single-candidate kernel, trajectory and control points back in host memory (btrapz_find_traj_mem)
+            from spectral_amd import synth as _synth
+            kb1 = _synth.scenario1_knots(1, S)
+            prm = native.CParams(*[float(v) for v in _synth.REFERENCE_WEIGHTS], 0)
+            lat_f = []
+            for i in range(max(30, a.latency_reps // 2)):
+                t1 = time.perf_counter(); cst, _, ctl = native.find_traj_mem(a.variant, prm, kb1); lat_f.append(time.perf_counter() - t1)
+            out["p50_find_traj_mem_ms"] = float(np.percentile(np.array(lat_f[5:]) * 1e3, 50))
+            out["find_traj_mem_segments"] = None if ctl is None else int(len(ctl) // 12)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, shared, a.cpu_seconds)
         else:

@@ -107,10 +107,10 @@ __global__ void single_candidate_kernel(const KernelArgs a, const double *__rest
 
 // library-internal: the HIP device a context lives on
 int btrapz_ctx_device(const btrapz_ctx *ctx);
-// library-internal: find_traj's single-candidate path.  One launch on the null stream; in and out may be host memory
+// library-internal: find_traj's single-candidate path.  One launch; in and out may be host memory
 // mapped into the device.  in: seg[17 S] init[6] ref_end[2] dl[10] mqm[168]; out: cost, status|iters, np, ctrl[12 S],
 // traj[6 max_points].  The M'QM table comes from the caller (btrapz_mqm_table_host).
 int btrapz_launch_single(btrapz_ctx *ctx, const btrapz_shared *shared, const btrapz_options *opt, int S, const double *in,
-                         double *out, int max_points);
+                         double *out, int max_points, void *stream);
 void btrapz_mqm_table_host(const btrapz_shared *shared, double *table /* [2][4][21] */);
 #endif

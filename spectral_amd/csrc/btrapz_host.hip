@@ -179,7 +179,8 @@ void btrapz_mqm_table_host(const btrapz_shared *sh, double *table) {
 }
 
 int btrapz_launch_single(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int S, const double *in,
-                         double *out, int max_points) {
+                         double *out, int max_points, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
   if (!c || !sh || S < 1 || S > BTRAPZ_MAX_SEGMENTS || !in || !out || max_points < 1) return BTRAPZ_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   KernelArgs a;
@@ -191,12 +192,12 @@ int btrapz_launch_single(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_op
   int rc = ensure_axis_ws(c, 2);
   if (rc != BTRAPZ_OK) return rc;
   if (!c->d_single) HIPCHK(c, hipMalloc(&c->d_single, sizeof(double) * 12 * BTRAPZ_MAX_SEGMENTS));
-  if (c->ws_used && c->ws_stream != nullptr) HIPCHK(c, hipStreamWaitEvent(nullptr, c->ws_free, 0));
+  if (c->ws_used && c->ws_stream != stream) HIPCHK(c, hipStreamWaitEvent(stream, c->ws_free, 0));
   a.axis_obj = c->d_axis_obj; a.axis_status = c->d_axis_status; a.axis_iters = c->d_axis_iters;
   a.ctrl = c->d_single; a.queue = nullptr;
-  hipLaunchKernelGGL(single_candidate_kernel, dim3(1), dim3(128), 0, (hipStream_t) nullptr, a, mqm, sh->delta, max_points, out);
-  c->ws_stream = nullptr; c->ws_used = true;
-  HIPCHK(c, hipEventRecord(c->ws_free, nullptr));
+  hipLaunchKernelGGL(single_candidate_kernel, dim3(1), dim3(128), 0, stream, a, mqm, sh->delta, max_points, out);
+  c->ws_stream = stream; c->ws_used = true;
+  HIPCHK(c, hipEventRecord(c->ws_free, stream));
   HIPCHK(c, hipGetLastError());
   return BTRAPZ_OK;
 }

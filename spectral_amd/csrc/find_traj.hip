@@ -31,22 +31,34 @@ const char *kDefaultInput[2] = {"/home/srujan_d/RISS/code/btrapz/src/c_road_s1_2
 const char *kDefaultOutputPrefix[2] = {"/home/srujan_d/RISS/code/btrapz/src/s1_slt_3d_",
                                        "/home/srujan_d/RISS/code/btrapz/src/s1_cub_3d_"};
 
-std::mutex g_ctx_mutex;
-std::mutex g_run_mutex;  // the shared context's workspace serves one find_traj at a time
-btrapz_ctx *g_ctx = nullptr;
-// (all under g_run_mutex)
-void *g_pinned = nullptr, *g_pinned_dev = nullptr;   // pinned host block of the single-candidate launch and its device mapping
-size_t g_pinned_bytes = 0;
-void *g_scratch = nullptr;        // device block of the rescue attempt
-size_t g_scratch_bytes = 0;
+// find_traj is re-entrant and concurrent: every calling thread gets, on its first call, a context, a stream and the
+// buffers of its own (a btrapz_ctx serves one launch sequence at a time), so concurrent callers -- e.g. parallel Optuna
+// trials of the harness -- neither queue behind a lock nor behind each other on the device's null stream.  The objects
+// live as long as the process (a thread pool's threads come and go rarely; nothing is torn down at thread exit, when the
+// HIP runtime may already be gone).
+struct Caller {
+  btrapz_ctx *ctx = nullptr;
+  hipStream_t stream = nullptr;
+  void *pinned = nullptr, *pinned_dev = nullptr;   // pinned host block of the single-candidate launch and its device mapping
+  size_t pinned_bytes = 0;
+  void *scratch = nullptr;                         // device block of the rescue attempt
+  size_t scratch_bytes = 0;
+};
+std::mutex g_callers_mutex;
+std::vector<Caller *> g_callers;     // (kept reachable for leak checkers)
 
-btrapz_ctx *shared_ctx() {
-  std::lock_guard<std::mutex> lk(g_ctx_mutex);
-  if (!g_ctx) {
+Caller *this_caller() {
+  thread_local Caller *me = nullptr;
+  if (!me) {
+    Caller *c = new Caller();
     const char *dev = getenv("BTRAPZ_DEVICE");
-    if (btrapz_create(&g_ctx, dev ? atoi(dev) : 0) != BTRAPZ_OK) g_ctx = nullptr;
+    if (btrapz_create(&c->ctx, dev ? atoi(dev) : 0) != BTRAPZ_OK) { delete c; return nullptr; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { btrapz_destroy(c->ctx); delete c; return nullptr; }
+    std::lock_guard<std::mutex> lk(g_callers_mutex);
+    g_callers.push_back(c);
+    me = c;
   }
-  return g_ctx;
+  return me;
 }
 
 bool verbose() { const char *v = getenv("BTRAPZ_VERBOSE"); return v && *v && *v != '0'; }
@@ -188,8 +200,9 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   for (int i = 0; i < 2; i++) { sh.dds[i] = in.dds[i]; sh.ddds[i] = in.ddds[i]; sh.ddl[i] = in.ddl[i]; sh.dddl[i] = in.dddl[i]; }
   sh.delta = in.delta; sh.variant = variant;
 
-  btrapz_ctx *ctx = shared_ctx();
-  if (!ctx) { fprintf(stderr, "btrapz: no HIP device available (this library has no CPU path)\n"); return FAIL; }
+  Caller *me = this_caller();
+  if (!me) { fprintf(stderr, "btrapz: no HIP device available (this library has no CPU path)\n"); return FAIL; }
+  btrapz_ctx *ctx = me->ctx;
 
   // expected sample count and the reference's CHECK_EQ(var_index, num_of_points_) (solve_3d.cc:1407)
   int np_expected = 1, var_index = 1;
@@ -197,9 +210,6 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   if (np_expected != var_index || np_expected < 1) return FAIL;
   const int max_points = np_expected;
 
-  // A btrapz_ctx is not thread-safe (its per-axis workspace is shared by every launch): concurrent callers of
-  // find_traj queue here.  The reference's own calls only ever race on the output file.
-  std::lock_guard<std::mutex> run_lock(g_run_mutex);
   // the buffers below must belong to the context's device whatever the calling thread's current device is
   if (hipSetDevice(btrapz_ctx_device(ctx)) != hipSuccess) return FAIL;
   // One pinned host block, mapped into the device, laid out as doubles:
@@ -209,16 +219,16 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   // second and third launch (btrapz_launch_single).  Only a stalled solve takes the batched entry points below.
   const size_t n_in = (size_t)BTRAPZ_NUM_SEG_FIELDS * S + 6 + 2 + 10 + 168;
   const size_t n_out = 3 + (size_t)12 * S + (size_t)6 * max_points;
-  if ((n_in + n_out) * 8 > g_pinned_bytes) {
-    if (g_pinned) (void)hipHostFree(g_pinned);
-    g_pinned = nullptr; g_pinned_dev = nullptr; g_pinned_bytes = 0;
+  if ((n_in + n_out) * 8 > me->pinned_bytes) {
+    if (me->pinned) (void)hipHostFree(me->pinned);
+    me->pinned = nullptr; me->pinned_dev = nullptr; me->pinned_bytes = 0;
     const size_t want = (n_in + n_out) * 8 * 2;
-    if (hipHostMalloc(&g_pinned, want, hipHostMallocMapped) != hipSuccess) return FAIL;
-    if (hipHostGetDevicePointer(&g_pinned_dev, g_pinned, 0) != hipSuccess) { (void)hipHostFree(g_pinned); g_pinned = nullptr; return FAIL; }
-    g_pinned_bytes = want;
+    if (hipHostMalloc(&me->pinned, want, hipHostMallocMapped) != hipSuccess) return FAIL;
+    if (hipHostGetDevicePointer(&me->pinned_dev, me->pinned, 0) != hipSuccess) { (void)hipHostFree(me->pinned); me->pinned = nullptr; return FAIL; }
+    me->pinned_bytes = want;
   }
-  double *h_in = static_cast<double *>(g_pinned), *h_out = h_in + n_in;
-  double *d_in = static_cast<double *>(g_pinned_dev), *d_out = d_in + n_in;
+  double *h_in = static_cast<double *>(me->pinned), *h_out = h_in + n_in;
+  double *d_in = static_cast<double *>(me->pinned_dev), *d_out = d_in + n_in;
   std::copy(h_seg.begin(), h_seg.end(), h_in);
   double *p_init = h_in + (size_t)BTRAPZ_NUM_SEG_FIELDS * S;
   std::copy(h_init.begin(), h_init.end(), p_init);
@@ -228,7 +238,8 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   int h_status[2] = {0, 0}, h_np = 0;
   double h_cost = 0.0;
   const ElasticEnv el = elastic_env();
-  if (btrapz_launch_single(ctx, &sh, nullptr, S, d_in, d_out, max_points) != BTRAPZ_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
+  if (btrapz_launch_single(ctx, &sh, nullptr, S, d_in, d_out, max_points, me->stream) != BTRAPZ_OK ||
+      hipStreamSynchronize(me->stream) != hipSuccess) {
     fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
     return FAIL;
   }
@@ -241,30 +252,30 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
     // through the batched entry points on a device copy of the inputs.
     if (verbose()) fprintf(stderr, "btrapz: S=%d stalled after %d iterations, rescue pass\n", S, h_status[1]);
     const size_t n_dev = n_in + n_out + 1;
-    if (n_dev * 8 > g_scratch_bytes) {
-      if (g_scratch) (void)hipFree(g_scratch);
-      g_scratch = nullptr; g_scratch_bytes = 0;
-      if (hipMalloc(&g_scratch, n_dev * 8 * 2) != hipSuccess) return FAIL;
-      g_scratch_bytes = n_dev * 8 * 2;
+    if (n_dev * 8 > me->scratch_bytes) {
+      if (me->scratch) (void)hipFree(me->scratch);
+      me->scratch = nullptr; me->scratch_bytes = 0;
+      if (hipMalloc(&me->scratch, n_dev * 8 * 2) != hipSuccess) return FAIL;
+      me->scratch_bytes = n_dev * 8 * 2;
     }
-    double *s_in = static_cast<double *>(g_scratch), *s_out = s_in + n_in + 1;
+    double *s_in = static_cast<double *>(me->scratch), *s_out = s_in + n_in + 1;
     double *s_init = s_in + (size_t)BTRAPZ_NUM_SEG_FIELDS * S;
     long long *s_sel = reinterpret_cast<long long *>(s_in + n_in);
     int *s_status = reinterpret_cast<int *>(s_out + 1), *s_np = reinterpret_cast<int *>(s_out + 2);
     const long long sel0 = 0;
-    if (hipMemcpy(s_in, h_in, n_in * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(s_sel, &sel0, 8, hipMemcpyHostToDevice) != hipSuccess) return FAIL;
+    memcpy(&h_in[n_in], &sel0, 8);   // (h_in[n_in] is h_out[0]: it stages the selection index until the results overwrite it)
+    if (hipMemcpyAsync(s_in, h_in, (n_in + 1) * 8, hipMemcpyHostToDevice, me->stream) != hipSuccess) return FAIL;
     btrapz_options opt = {};
     opt.elastic = 1; opt.elastic_tol = el.tol;
     if (btrapz_solve_batch_device(ctx, &sh, &opt, 1, S, s_in, s_init, s_init + 6, s_init + 8, s_out + 3, s_out, s_status,
-                                  s_status + 1, nullptr) != BTRAPZ_OK ||
+                                  s_status + 1, me->stream) != BTRAPZ_OK ||
         btrapz_sample_device(ctx, 1, S, in.delta, s_in, s_init, s_out + 3, 1, s_sel, max_points, s_out + 3 + 12 * S, s_np,
-                             nullptr) != BTRAPZ_OK) {
+                             me->stream) != BTRAPZ_OK) {
       fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
       return FAIL;
     }
-    // (a blocking copy on the null stream waits for the launches before it)
-    if (hipMemcpy(h_out, s_out, n_out * 8, hipMemcpyDeviceToHost) != hipSuccess) return FAIL;
+    if (hipMemcpyAsync(h_out, s_out, n_out * 8, hipMemcpyDeviceToHost, me->stream) != hipSuccess ||
+        hipStreamSynchronize(me->stream) != hipSuccess) return FAIL;
     h_cost = h_out[0];
     memcpy(h_status, &h_out[1], 8);
     memcpy(&h_np, &h_out[2], 4);

@@ -100,6 +100,33 @@ def test_find_traj_is_reentrant(tmp_path, monkeypatch):
     assert len(set(res.values())) == 1 and list(res.values())[0] < 1e10
 
 
+def test_find_traj_concurrent_callers_do_not_share_state(tmp_path):
+    """Every calling thread has a context, a stream and buffers of its own: eight threads hammering different inputs
+    (solvable, rescued, failing) get, call for call, what a single thread gets."""
+    import threading
+    cases = [("c1", 0), ("c2", 1), ("c7", 0), ("c_road_s1_2", 0), ("c4", 0), ("c_road_s1_3", 0), ("c3", 1), ("c7_7", 1)]
+    want = {}
+    for i, (name, variant) in enumerate(cases):
+        p = native.CParams(*[float(v) for v in W], 100 + i)
+        want[(name, variant)] = native.find_traj_native(variant, p, os.path.join(GOLD, "inputs", name + ".txt"), str(tmp_path / ("w%d.txt" % i)))
+    got, errors = {}, []
+
+    def work(tid):
+        try:
+            for rep in range(12):
+                name, variant = cases[(tid + rep) % len(cases)]
+                p = native.CParams(*[float(v) for v in W], tid)
+                c = native.find_traj_native(variant, p, os.path.join(GOLD, "inputs", name + ".txt"), str(tmp_path / ("t%d_%d.txt" % (tid, rep))))
+                got[(tid, rep)] = (name, variant, c)
+        except Exception as e:      # pragma: no cover
+            errors.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errors and len(got) == 96
+    for (tid, rep), (name, variant, c) in got.items():
+        assert c == want[(name, variant)], (tid, rep, name, variant, c, want[(name, variant)])
+
+
 @pytest.mark.parametrize("name,variant", FEASIBLE)
 def test_find_traj_mem_equals_file_path_at_full_precision(name, variant, tmp_path):
     """btrapz_find_traj_mem (arrays in, arrays out: SURVEY 8f rank 2) is the same computation as the file-based
