@@ -81,6 +81,12 @@ typedef struct btrapz_traj_input {
 double btrapz_find_traj_mem(int variant, const btrapz_traj_input *in, const Params *p, int cap,
                             double *traj, int *n_points, double *ctrl, int *n_segments);
 
+/* Interior-point iterations of the calling thread's last find_traj / btrapz_find_traj_mem call (-1: none yet).
+ * Diagnostics: with BTRAPZ_WARM=1 a call starts from the joint states and multipliers the thread's previous call
+ * left on the device (the replanning loop cart_frenet.py:1516-1571 solves a problem close to the previous one at every
+ * step), which shows here as fewer iterations; the result is x* to solver accuracy either way. */
+int btrapz_find_traj_last_iterations(void);
+
 /* Host-side corridor stage of find_traj alone (CorridorGeneration + CorridorSplit per obstacle,
  * then CollisionCheck: src/solve_3d.cc:323-486,729-772,488-714 ; src/cuboid_3d.cc:301-573).
  * Parses input_path, writes up to cap segments.  Returns the segment count S >= 1, 0 when no

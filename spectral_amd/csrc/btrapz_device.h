@@ -54,6 +54,7 @@ struct KernelArgs {
   double elastic_delta;     // penalty d^2 / (2 delta) on the relaxation d of every inequality row
   double elastic_tol;       // largest row violation still reported as BTRAPZ_SOLVED_INACCURATE
   int *queue;               // ipm_solve_queue_kernel: [2] next candidate per axis (zeroed before the launch)
+  double *x_out;            // warm-start instantiations: joint states of the returned iterate, layout of x0 (may be null)
 };
 
 struct CorridorArgs {
@@ -102,6 +103,8 @@ __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, doubl
 
 __global__ void single_candidate_kernel(const KernelArgs a, const double *__restrict__ mqm, double delta, int max_points,
                                         double *out);
+__global__ void single_candidate_warm_kernel(const KernelArgs a, const double *__restrict__ mqm, double delta, int max_points,
+                                             double *out);
 
 }  // namespace btrapz
 
@@ -110,7 +113,10 @@ int btrapz_ctx_device(const btrapz_ctx *ctx);
 // library-internal: find_traj's single-candidate path.  One launch; in and out may be host memory
 // mapped into the device.  in: seg[17 S] init[6] ref_end[2] dl[10] mqm[168]; out: cost, status|iters, np, ctrl[12 S],
 // traj[6 max_points].  The M'QM table comes from the caller (btrapz_mqm_table_host).
+// warm: 0 cold; 1 start from what the previous warm call of this context left (same variant and segment count, else
+// cold) and leave this call's joint states and multipliers for the next one.
 int btrapz_launch_single(btrapz_ctx *ctx, const btrapz_shared *shared, const btrapz_options *opt, int S, const double *in,
-                         double *out, int max_points, void *stream);
+                         double *out, int max_points, int warm, void *stream);
+void btrapz_single_forget(btrapz_ctx *ctx);   // the next warm call starts cold
 void btrapz_mqm_table_host(const btrapz_shared *shared, double *table /* [2][4][21] */);
 #endif

@@ -63,6 +63,9 @@ struct btrapz_ctx {
   // staging for the host-pointer wrapper
   double *d_stage = nullptr; size_t stage_cap = 0;
   double *d_single = nullptr;       // control points of the single-candidate launch (find_traj)
+  // what a warm single-candidate launch leaves for the next one: joint states [2][64][3], multipliers [2][36][64] (two
+  // sets, read / written alternately), and the problem shape they belong to
+  double *d_single_warm = nullptr; int single_S = 0, single_variant = -1, single_flip = 0;
   int *d_queue = nullptr;           // [2] candidate counters of the persistent launch (ipm_solve_queue_kernel)
   int resident_waves = 1024;        // wavefronts the device holds at one per SIMD
   int *d_istage = nullptr; size_t istage_cap = 0;
@@ -109,7 +112,7 @@ BTRAPZ_EXPORT int btrapz_destroy(btrapz_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters);
   (void)hipFree(c->d_mqm); (void)hipFree(c->d_stage); (void)hipFree(c->d_istage); (void)hipFree(c->d_single);
-  (void)hipFree(c->d_queue);
+  (void)hipFree(c->d_queue); (void)hipFree(c->d_single_warm);
   (void)hipFree(c->d_order); (void)hipFree(c->d_meta); (void)hipFree(c->d_retry);
   (void)hipFree(c->d_rescue); (void)hipFree(c->d_rescue_meta); (void)hipFree(c->d_argmin_cost); (void)hipFree(c->d_argmin_idx);
   if (c->ws_free) (void)hipEventDestroy(c->ws_free);
@@ -178,8 +181,10 @@ void btrapz_mqm_table_host(const btrapz_shared *sh, double *table) {
   }
 }
 
+void btrapz_single_forget(btrapz_ctx *c) { if (c) c->single_S = 0; }
+
 int btrapz_launch_single(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int S, const double *in,
-                         double *out, int max_points, void *stream_) {
+                         double *out, int max_points, int warm, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!c || !sh || S < 1 || S > BTRAPZ_MAX_SEGMENTS || !in || !out || max_points < 1) return BTRAPZ_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
@@ -194,8 +199,20 @@ int btrapz_launch_single(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_op
   if (!c->d_single) HIPCHK(c, hipMalloc(&c->d_single, sizeof(double) * 12 * BTRAPZ_MAX_SEGMENTS));
   if (c->ws_used && c->ws_stream != stream) HIPCHK(c, hipStreamWaitEvent(stream, c->ws_free, 0));
   a.axis_obj = c->d_axis_obj; a.axis_status = c->d_axis_status; a.axis_iters = c->d_axis_iters;
-  a.ctrl = c->d_single; a.queue = nullptr;
-  hipLaunchKernelGGL(single_candidate_kernel, dim3(1), dim3(128), 0, stream, a, mqm, sh->delta, max_points, out);
+  a.ctrl = c->d_single; a.queue = nullptr; a.x_out = nullptr;
+  if (warm) {
+    const size_t nx = 2 * 64 * 3, nl = 2 * 36 * 64, set = nx + nl;
+    if (!c->d_single_warm) HIPCHK(c, hipMalloc(&c->d_single_warm, sizeof(double) * 2 * set));
+    double *rd = c->d_single_warm + (size_t)c->single_flip * set, *wr = c->d_single_warm + (size_t)(1 - c->single_flip) * set;
+    const bool have = c->single_S == S && c->single_variant == sh->variant;
+    // layouts for B = 1, seg_stride = S: x [2][S][3], lam [2][36][1][S]
+    a.x0 = have ? rd : nullptr; a.lam0 = have ? rd + nx : nullptr;
+    a.x_out = wr; a.lam_out = wr + nx;
+    c->single_flip = 1 - c->single_flip; c->single_S = S; c->single_variant = sh->variant;
+    hipLaunchKernelGGL(single_candidate_warm_kernel, dim3(1), dim3(128), 0, stream, a, mqm, sh->delta, max_points, out);
+  } else {
+    hipLaunchKernelGGL(single_candidate_kernel, dim3(1), dim3(128), 0, stream, a, mqm, sh->delta, max_points, out);
+  }
   c->ws_stream = stream; c->ws_used = true;
   HIPCHK(c, hipEventRecord(c->ws_free, stream));
   HIPCHK(c, hipGetLastError());
@@ -234,6 +251,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   a.B = B; a.S = S; a.seg_stride = S; a.order = nullptr; a.seg_count = nullptr; a.cand_prefix = nullptr; a.wave_prefix = nullptr;
   a.seg = seg; a.init = init; a.ref_end = ref_end; a.dl_bounds = dl_bounds; a.mqm = c->d_mqm;
   a.ctrl = ctrl; a.axis_obj = c->d_axis_obj; a.axis_status = c->d_axis_status; a.axis_iters = c->d_axis_iters;
+  a.x_out = nullptr;
   const int elastic = opt ? opt->elastic : 0;
   if (elastic < 0 || elastic > 2) { c->err = "invalid argument: btrapz_options.elastic"; return BTRAPZ_EINVAL; }
   unsigned blocks;

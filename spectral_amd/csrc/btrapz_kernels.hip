@@ -519,6 +519,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         }
       }
     }
+    if (WARM && a.x_out && valid) {   // joint states of the returned iterate: x0 of a later solve of a nearby problem
+      double *xo = a.x_out + (((size_t)b * 2 + axis) * a.seg_stride + k) * 3;
+      xo[0] = Xb[0]; xo[1] = Xb[1]; xo[2] = Xb[2];
+    }
     {
       double Xp[3], c[6];
       UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(Xb[i]); Xp[i] = first ? Xinit[i] : v; }
@@ -1221,12 +1225,13 @@ __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, doubl
 // once, results written once -- so the call needs no copy either; what the kernel reads back (control points, per-axis
 // records) lives in device memory (a.ctrl, a.axis_*).  out: [0] cost, [1] status and iterations (two ints), [2]
 // sample count (int), [3 .. 3 + 12 S) control points, then traj [6][max_points].
-__global__ __launch_bounds__(128) void single_candidate_kernel(const KernelArgs a, const double *__restrict__ mqm,
-                                                               double delta, int max_points, double *out) {
+template <bool WARM>
+__device__ __forceinline__ void single_candidate_body(const KernelArgs &a, const double *__restrict__ mqm, double delta,
+                                                      int max_points, double *out) {
   double *res = out, *traj = out + 3 + 12 * a.S;
   __shared__ double lds[2][lds_rows<false>()][64];
   const int w = (int)threadIdx.x >> 6;
-  ipm_solve_body<false, false>(a, mqm, lds[w], w, (int)threadIdx.x & 63);
+  ipm_solve_body<WARM, false>(a, mqm, lds[w], w, (int)threadIdx.x & 63);
   __threadfence_block();
   __syncthreads();
   const int s0 = a.axis_status[0], s1 = a.axis_status[1];
@@ -1244,6 +1249,16 @@ __global__ __launch_bounds__(128) void single_candidate_kernel(const KernelArgs 
     ri[0] = st; ri[1] = a.axis_iters[0] > a.axis_iters[1] ? a.axis_iters[0] : a.axis_iters[1];
     reinterpret_cast<int *>(res + 2)[0] = np;
   }
+}
+__global__ __launch_bounds__(128) void single_candidate_kernel(const KernelArgs a, const double *__restrict__ mqm,
+                                                               double delta, int max_points, double *out) {
+  single_candidate_body<false>(a, mqm, delta, max_points, out);
+}
+// ... starting from the joint states and multipliers the previous call left on the device (find_traj in a replanning
+// loop, BTRAPZ_WARM=1), and leaving its own for the next one
+__global__ __launch_bounds__(128) void single_candidate_warm_kernel(const KernelArgs a, const double *__restrict__ mqm,
+                                                                    double delta, int max_points, double *out) {
+  single_candidate_body<true>(a, mqm, delta, max_points, out);
 }
 
 }  // namespace btrapz

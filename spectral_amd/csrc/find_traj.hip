@@ -43,6 +43,7 @@ struct Caller {
   size_t pinned_bytes = 0;
   void *scratch = nullptr;                         // device block of the rescue attempt
   size_t scratch_bytes = 0;
+  int last_iters = -1;                             // interior-point iterations of this thread's last call
 };
 std::mutex g_callers_mutex;
 std::vector<Caller *> g_callers;     // (kept reachable for leak checkers)
@@ -238,7 +239,13 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   int h_status[2] = {0, 0}, h_np = 0;
   double h_cost = 0.0;
   const ElasticEnv el = elastic_env();
-  if (btrapz_launch_single(ctx, &sh, nullptr, S, d_in, d_out, max_points, me->stream) != BTRAPZ_OK ||
+  // BTRAPZ_WARM=1 (a replanning loop: every call solves a problem close to the previous one's): start from the joint
+  // states and multipliers the previous call of this thread left on the device.  The optimum does not depend on the
+  // start -- the result is x* to solver accuracy either way -- but its last digits and the iteration count do, so it is
+  // off by default: a call's output then depends on its inputs alone.
+  const char *warm_env = getenv("BTRAPZ_WARM");
+  const bool warm_on = warm_env && *warm_env && *warm_env != '0';
+  if (btrapz_launch_single(ctx, &sh, nullptr, S, d_in, d_out, max_points, warm_on ? 1 : 0, me->stream) != BTRAPZ_OK ||
       hipStreamSynchronize(me->stream) != hipSuccess) {
     fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
     return FAIL;
@@ -246,6 +253,8 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   h_cost = h_out[0];
   memcpy(h_status, &h_out[1], 8);
   memcpy(&h_np, &h_out[2], 4);
+  me->last_iters = h_status[1];
+  if (h_status[0] != BTRAPZ_SOLVED && h_status[0] != BTRAPZ_SOLVED_INACCURATE) btrapz_single_forget(ctx);
   if (h_status[0] == BTRAPZ_MAX_ITER_REACHED && el.on) {
     // Second attempt (no solution to converge to: a marginally infeasible corridor): the rescue pass of
     // btrapz_options.elastic, the counterpart of the reference accepting OSQP's status 2.  Rare, so it simply goes
@@ -336,6 +345,11 @@ BTRAPZ_EXPORT double btrapz_find_traj(int variant, const char *input_path, const
     fprintf(stderr, "btrapz: cannot write '%s'\n", out_path.c_str());
   }
   return cost;
+}
+
+BTRAPZ_EXPORT int btrapz_find_traj_last_iterations(void) {
+  Caller *me = this_caller();
+  return me ? me->last_iters : -1;
 }
 
 // find_traj without the file side channel: the parsed content of the corridor file comes in as

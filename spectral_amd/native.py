@@ -102,7 +102,8 @@ EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "bt
            "btrapz_device_count", "btrapz_solve_batch_device", "btrapz_argmin_device",
            "btrapz_sample_device", "btrapz_solve_batch_host", "btrapz_solve_ragged_device",
            "btrapz_corridor_batch_device", "btrapz_sample_ragged_device", "btrapz_solve_warm_device",
-           "btrapz_eval_states_device", "btrapz_find_traj_mem", "btrapz_prism_bounds_device")
+           "btrapz_eval_states_device", "btrapz_find_traj_mem", "btrapz_prism_bounds_device",
+           "btrapz_find_traj_last_iterations")
 
 
 def build(verbose=False):
@@ -163,6 +164,7 @@ def lib():
         l.btrapz_destroy.argtypes = [C.c_void_p]
         l.btrapz_last_error.argtypes = [C.c_void_p]; l.btrapz_last_error.restype = C.c_char_p
         l.btrapz_device_count.restype = C.c_int
+        l.btrapz_find_traj_last_iterations.restype = C.c_int
         l.btrapz_solve_batch_device.argtypes = [vp, C.POINTER(CShared), C.POINTER(COptions), C.c_int, C.c_int,
                                                 dp, dp, dp, dp, dp, dp, ip, ip, vp]
         l.btrapz_argmin_device.argtypes = [vp, C.c_int, C.c_int, C.c_longlong, dp, llp, dp, vp]

@@ -163,3 +163,45 @@ def test_find_traj_mem_failures():
         cost, traj, ctrl = native.find_traj_mem(variant, params, kb)
         assert cost == 100000000000.0 and traj is None
     assert native.lib().btrapz_find_traj_mem(0, None, C.byref(params), 0, None, None, None, None) == 100000000000.0
+
+
+def test_find_traj_warm_start_across_calls(monkeypatch):
+    """BTRAPZ_WARM=1: in a replanning loop every call solves a problem close to the previous one's; starting from the
+    joint states and multipliers the previous call left on the device costs fewer iterations and returns the same
+    optimum (to solver accuracy, against the oracle's x* of every problem).  Off by default."""
+    from spectral_amd import knots
+    params = native.CParams(*[float(v) for v in W], 1)
+    base = knots.parse_corridor_file(os.path.join(GOLD, "inputs", "c2.txt"))
+    seq = knots.jittered(base, 12, seed=21, s_shift=0.15, l_shift=0.02)      # a sequence of nearby problems
+    p = O.params_from_weights(W)
+
+    def run():
+        out = []
+        for b in range(seq.B):
+            cost, traj, ctrl = native.find_traj_mem(0, params, seq, b=b)
+            out.append((cost, ctrl, native.lib().btrapz_find_traj_last_iterations()))
+        return out
+    monkeypatch.delenv("BTRAPZ_WARM", raising=False)
+    cold = run()
+    again = run()
+    assert all(a[0] == b[0] and np.array_equal(a[1], b[1]) for a, b in zip(cold, again))        # stateless by default
+    monkeypatch.setenv("BTRAPZ_WARM", "1")
+    warm = run()
+    it_cold = np.array([c[2] for c in cold]); it_warm = np.array([w[2] for w in warm])
+    assert it_warm[0] >= it_cold[0] - 1                        # the first warm call has nothing to start from (or what `again` left: no -- that was cold)
+    assert it_warm[1:].mean() <= it_cold[1:].mean() - 2.0, (it_cold, it_warm)
+    for b in range(seq.B):
+        assert cold[b][0] < 1e10 and warm[b][0] < 1e10
+        lists = [O.corridor_generation(0, seq.N, seq.delta, seq.s_bounds[b, o], seq.l_bounds[b, o]) for o in range(seq.num_obs)]
+        n, cubes = O.collision_check(0, seq.N, seq.delta, lists, seq.s_ref[b], seq.l_ref[b])
+        src = type("S", (), {})()
+        src.N, src.delta = seq.N, seq.delta
+        src.dx_bounds, src.dy_bounds, src.x_ref, src.y_ref = seq.ds_bounds[b], seq.dl_bounds[b], seq.s_ref[b], seq.l_ref[b]
+        src.init_s, src.init_l = seq.init[b, :3], seq.init[b, 3:]
+        for key, v in seq.header.items():
+            setattr(src, key, v)
+        xs, _, info = O.AssembledQp(0, cubes, p, src).solve_exact()
+        assert info.status == 1
+        for res in (cold[b], warm[b]):
+            assert np.abs(res[1] - xs).max() <= 1e-5 * np.abs(xs).max()
+        assert abs(warm[b][0] - cold[b][0]) <= 1e-7 * abs(cold[b][0])
