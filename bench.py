@@ -206,7 +206,7 @@ def main():
     def step():
         o = solver.solve(db, shared)                                   # assembly + solve: one launch
         bi, bc = solver.argmin(o["cost"], index_base=index_base)       # winner of this rank's shard
-        wc, wi = global_argmin(bc, bi)                                  # N > 1: 16 B per rank over RCCL
+        wc, wi = global_argmin(bc, bi, ctx=solver.ctx)                  # N > 1: 16 B per rank over RCCL
         return o, wi[0], wc[0]
 
     def sync():
@@ -225,7 +225,7 @@ def main():
         o = solver.solve(db, shared)
         ev[i][1].record()
         bi, bc = solver.argmin(o["cost"], index_base=index_base)
-        wc, wi = global_argmin(bc, bi)
+        wc, wi = global_argmin(bc, bi, ctx=solver.ctx)
         win_idx, win_cost = wi[0], wc[0]
     sync()
     elapsed_local = time.perf_counter() - t0

@@ -212,6 +212,13 @@ int btrapz_argmin_device(btrapz_ctx *ctx, int B, int group, long long index_base
                          const double *cost, long long *best_idx, double *best_cost,
                          void *stream);
 
+/* Multi-GPU arg-min, last step: the winners of all ranks after the all-gather (one process per GPU; RCCL has no
+ * MINLOC).  pairs [world][n][2] int64 = (bit pattern of the float64 cost, global index or -1) of every rank's local
+ * winner of arg-min group g; best_cost / best_idx [n]: lowest cost, ties -> lowest index, -1 when nobody solved one.
+ * Device pointers.  (spectral_amd/dist.py packs, gathers and calls this.) */
+int btrapz_argmin_pairs_device(btrapz_ctx *ctx, int world, int n, const long long *pairs, double *best_cost,
+                               long long *best_idx, void *stream);
+
 /* Bernstein sampling (solve_3d.cc:1279-1392) of nsel selected candidates on device.
  *   sel [nsel] candidate indices; t taken from seg; out [nsel][6][max_points]
  *   (s, ds, dds, l, dl, ddl); npoints [nsel].  Device pointers. */

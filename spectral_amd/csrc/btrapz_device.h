@@ -95,6 +95,7 @@ __global__ void argmin_kernel(int group, long long index_base, const double *cos
                               double *best_cost, double *part_cost, long long *part_idx);
 __global__ void argmin_final_kernel(int chunks, long long index_base, const double *part_cost, const long long *part_idx,
                                     long long *best_idx, double *best_cost);
+__global__ void argmin_pairs_kernel(int world, int n, const long long *pairs, double *best_cost, long long *best_idx);
 __global__ void eval_states_kernel(int B, int seg_stride, const int *seg_count, const double *seg, const double *ctrl,
                                    int n_times, const double *times, double *x);
 __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, double delta, const double *seg,

@@ -472,6 +472,17 @@ BTRAPZ_EXPORT int btrapz_argmin_device(btrapz_ctx *c, int B, int group, long lon
   return BTRAPZ_OK;
 }
 
+BTRAPZ_EXPORT int btrapz_argmin_pairs_device(btrapz_ctx *c, int world, int n, const long long *pairs, double *best_cost,
+                                          long long *best_idx, void *stream_) {
+  if (!c) return BTRAPZ_EINVAL;
+  if (world < 1 || n < 1 || !pairs || !best_cost || !best_idx) { c->err = "invalid argument"; return BTRAPZ_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(argmin_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream_, world, n, pairs, best_cost,
+                     best_idx);
+  HIPCHK(c, hipGetLastError());
+  return BTRAPZ_OK;
+}
+
 BTRAPZ_EXPORT int btrapz_sample_device(btrapz_ctx *c, int B, int S, double delta, const double *seg, const double *init,
                                     const double *ctrl, int nsel, const long long *sel, int max_points, double *out,
                                     int *npoints, void *stream_) {

@@ -1126,6 +1126,23 @@ __global__ __launch_bounds__(256) void argmin_final_kernel(int chunks, long long
   if (threadIdx.x == 0) { best_idx[g] = bi >= 0 ? bi + index_base : -1; best_cost[g] = bc; }
 }
 
+// ---- the global winner from the ranks' winners (multi-GPU arg-min, after the all-gather) --------------------------
+// pairs [world][n][2] int64: (bit pattern of the float64 cost, global candidate index or -1) of every rank's local
+// winner of group g.  Lexicographic min over the ranks: cost first (a NaN never wins), then the lowest index.
+__global__ void argmin_pairs_kernel(int world, int n, const long long *pairs, double *best_cost, long long *best_idx) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  double bc = __builtin_huge_val();
+  long long bi = -1;
+  for (int r = 0; r < world; r++) {
+    double c = __longlong_as_double(pairs[((size_t)r * n + g) * 2]);
+    const long long i = pairs[((size_t)r * n + g) * 2 + 1];
+    if (!(c == c)) c = __builtin_huge_val();
+    if (argmin_better(c, i, bc, bi)) { bc = c; bi = i; }
+  }
+  best_cost[g] = bc; best_idx[g] = bi;
+}
+
 // ---- state of solved trajectories at arbitrary times (warm start of the next replanning step) ----------
 // thread = (candidate, time index).  x[b][axis][j] = (p, v, a) at times[b][j] seconds from the start of the
 // candidate's horizon; the Bezier evaluation is the one of solve_3d.cc:1366-1388.  Past the last segment the end

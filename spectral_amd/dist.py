@@ -18,7 +18,7 @@ def shard_bounds(B, world, rank):
     return lo, min(B, lo + per)
 
 
-def global_argmin(best_cost, best_idx, group=None):
+def global_argmin(best_cost, best_idx, group=None, ctx=None):
     """best_cost [n] float64, best_idx [n] int64 (global candidate indices, -1 = none) of this rank.
     Returns (cost [n], idx [n]) of the winners over all ranks; identical on every rank.
 
@@ -29,7 +29,9 @@ def global_argmin(best_cost, best_idx, group=None):
     0's group g would merge unrelated agents).  The entry count must be the same on every rank (checked).
 
     One all_gather of n x 16 bytes per rank: the cost travels as its float64 bit pattern next to the int64 index in one
-    int64 tensor, so indices are exact (no float round trip) and there is a single collective per step."""
+    int64 tensor, so indices are exact (no float round trip) and there is a single collective per step.  With ctx (a
+    spectral_amd.native.Context) and device tensors the reduction over the ranks is one launch of the library
+    (btrapz_argmin_pairs_device) on torch's current stream; otherwise a handful of torch ops with the same result."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return best_cost, best_idx
@@ -41,6 +43,11 @@ def global_argmin(best_cost, best_idx, group=None):
     gathered = [torch.empty_like(pair) for _ in range(world)]
     dist.all_gather(gathered, pair, group=group)             # raises on a size mismatch: same n on every rank
     allp = torch.stack(gathered).to(dev)                     # [world, n, 2] int64
+    if ctx is not None and allp.is_cuda:
+        n = allp.shape[1]
+        out_c = torch.empty(n, dtype=torch.float64, device=dev); out_i = torch.empty(n, dtype=torch.int64, device=dev)
+        ctx.argmin_pairs_device(world, n, allp.contiguous(), out_c, out_i, stream=torch.cuda.current_stream(dev).cuda_stream)
+        return out_c, out_i
     cost = allp[..., 0].contiguous().view(torch.float64)
     idx = allp[..., 1]
     big = torch.iinfo(torch.int64).max

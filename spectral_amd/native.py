@@ -103,7 +103,7 @@ EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "bt
            "btrapz_sample_device", "btrapz_solve_batch_host", "btrapz_solve_ragged_device",
            "btrapz_corridor_batch_device", "btrapz_sample_ragged_device", "btrapz_solve_warm_device",
            "btrapz_eval_states_device", "btrapz_find_traj_mem", "btrapz_prism_bounds_device",
-           "btrapz_find_traj_last_iterations")
+           "btrapz_find_traj_last_iterations", "btrapz_argmin_pairs_device")
 
 
 def build(verbose=False):
@@ -168,6 +168,7 @@ def lib():
         l.btrapz_solve_batch_device.argtypes = [vp, C.POINTER(CShared), C.POINTER(COptions), C.c_int, C.c_int,
                                                 dp, dp, dp, dp, dp, dp, ip, ip, vp]
         l.btrapz_argmin_device.argtypes = [vp, C.c_int, C.c_int, C.c_longlong, dp, llp, dp, vp]
+        l.btrapz_argmin_pairs_device.argtypes = [vp, C.c_int, C.c_int, llp, dp, llp, vp]
         l.btrapz_sample_device.argtypes = [vp, C.c_int, C.c_int, C.c_double, dp, dp, dp, C.c_int, llp, C.c_int,
                                            dp, ip, vp]
         l.btrapz_solve_batch_host.argtypes = [vp, C.POINTER(CShared), C.POINTER(COptions), C.c_int, C.c_int,
@@ -294,6 +295,11 @@ class Context:
         ptr = lambda t: C.c_void_p(t.data_ptr())
         self._check(lib().btrapz_argmin_device(self._h, B, group, int(index_base), ptr(cost), ptr(best_idx),
                                                ptr(best_cost), C.c_void_p(stream or 0)), "btrapz_argmin_device")
+
+    def argmin_pairs_device(self, world, n, pairs, best_cost, best_idx, stream=None):
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        self._check(lib().btrapz_argmin_pairs_device(self._h, int(world), int(n), ptr(pairs), ptr(best_cost), ptr(best_idx),
+                                                     C.c_void_p(stream or 0)), "btrapz_argmin_pairs_device")
 
     def sample_device(self, B, S, delta, seg, init, ctrl, sel, max_points, out, npoints, stream=None):
         ptr = lambda t: C.c_void_p(t.data_ptr())

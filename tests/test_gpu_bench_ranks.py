@@ -35,3 +35,32 @@ def test_two_ranks_on_one_gpu_pick_the_single_rank_winner():
     assert weak["config"]["batch_total"] == 12000 and weak["scaling"] == "weak"
     for line in (one, two, weak):
         assert line["roofline"]["frac"] > 0 and "cpu_baseline" in line and line["value"] > 0
+
+
+def test_argmin_pairs_kernel_equals_the_torch_reduction():
+    """btrapz_argmin_pairs_device (the last step of the multi-GPU arg-min) against dist.global_argmin's torch path on
+    the same gathered pairs: ties -> lowest index, -1 and +inf for groups nobody solved, NaN never wins, indices beyond
+    2^53 exact."""
+    import numpy as np
+    import torch
+    from spectral_amd.native import Context
+    ctx = Context(0)
+    rng = np.random.default_rng(0)
+    world, n = 8, 700
+    cost = rng.normal(size=(world, n)) * 1e3
+    idx = rng.integers(0, 1 << 40, size=(world, n)) + (1 << 55)
+    cost[rng.uniform(size=(world, n)) < 0.2] = np.inf
+    idx[np.isinf(cost)] = -1
+    cost[:, 5] = np.inf; idx[:, 5] = -1                       # nobody solved group 5
+    cost[2, 9] = cost[6, 9] = cost[:, 9].min() - 1.0           # a tie -> lowest index
+    cost[3, 11] = np.nan
+    pairs = torch.from_numpy(np.stack([cost.view(np.int64), idx], axis=-1)).cuda().contiguous()
+    out_c = torch.empty(n, dtype=torch.float64, device="cuda"); out_i = torch.empty(n, dtype=torch.int64, device="cuda")
+    ctx.argmin_pairs_device(world, n, pairs, out_c, out_i)
+    torch.cuda.synchronize()
+    c = np.where(np.isnan(cost), np.inf, cost)
+    want_c = c.min(axis=0)
+    key = np.where((c == want_c[None]) & (idx >= 0), idx, np.iinfo(np.int64).max)
+    want_i = key.min(axis=0); want_i[want_i == np.iinfo(np.int64).max] = -1
+    assert np.array_equal(out_c.cpu().numpy(), want_c) and np.array_equal(out_i.cpu().numpy(), want_i)
+    assert out_i[5].item() == -1 and out_i[9].item() == min(idx[2, 9], idx[6, 9])
