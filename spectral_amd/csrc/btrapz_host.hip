@@ -422,7 +422,7 @@ BTRAPZ_EXPORT int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B
   const int staged = slope_bytes <= 24 * 1024 ? 1 : 0;
   auto lds_bytes = [&](int cap_o, int cap_sel) {
     const size_t cap_all = (size_t)cap_o * num_obs;
-    return 104 * (cap_all + cap_sel) + sizeof(double) * 2 * (size_t)N + (staged ? slope_bytes : 0) +
+    return 104 * (cap_all > (size_t)cap_sel ? cap_all : (size_t)cap_sel) + sizeof(double) * 4 * (size_t)N + (staged ? slope_bytes : 0) +
            sizeof(int) * (cap_all + 64 + cap_sel) + sizeof(short) * (cap_all + cap_sel) + 16;
   };
   const bool two_pass = cap_o_small < cap_o_big || cap_sel_small < cap_sel_big;

@@ -175,8 +175,8 @@ BTRAPZ_HD int selection_pushes(int hits_inside, int &carry) {
 }
 
 // De-dup (keep first), then ordering and time-overlap resolution: solve_3d.cc:617-703 (trapezoid),
-// cuboid_3d.cc:538-567 (cuboid: no sort, no reorder, every later twin, a third of the span).  Three steps so that
-// the device can run the first two across the lanes (corridor_kernels.hip) and only the last one serially.
+// cuboid_3d.cc:538-567 (cuboid: no sort, no reorder, every later twin, a third of the span).  Separate steps so that
+// the device can run all but the overlap walk across the lanes (corridor_kernels.hip).
 BTRAPZ_HD int dedup_segments_core(Seg *v, int n) {
   for (int i = 0; i + 1 < n; i++)
     for (int j = i + 1; j < n;) {
@@ -192,15 +192,21 @@ BTRAPZ_HD void sort_segments_core(Seg *v, int n) {  // stable insertion sort by 
     v[j + 1] = x;
   }
 }
-BTRAPZ_HD void resolve_segments_core(int variant, double delta, Seg *v, int n) {
+// Trapezoid variant, first half: pull a segment that continues segment i's lane next to it (solve_3d.cc:640-666).
+// Only beg_l, beg_t and end_t are compared; the device runs the k search across the lanes (corridor_kernels.hip).
+BTRAPZ_HD void reorder_segments_core(Seg *v, int n) {
+  for (int i = 0; i + 1 < n; i++)
+    for (int j = i + 1; j < n; j++) {
+      if (v[i].beg_l == v[j].beg_l && j - i == 1) break;
+      for (int k = j + 1; k < n; k++)
+        if (v[i].beg_l == v[k].beg_l && v[i].end_t == v[k].beg_t) { const Seg x = v[j]; v[j] = v[k]; v[k] = x; break; }
+    }
+}
+// Time overlaps: between neighbours (trapezoid, solve_3d.cc:678-703: its inner loop breaks after j = i + 1) or between every pair of twins (cuboid).
+// Each step sees the spans the previous one left, so this stays a serial walk on the device too.
+BTRAPZ_HD void overlap_segments_core(int variant, double delta, Seg *v, int n) {
   if (variant == 0) {
-    for (int i = 0; i + 1 < n; i++)  // pull a segment that continues segment i's lane next to it
-      for (int j = i + 1; j < n; j++) {
-        if (v[i].beg_l == v[j].beg_l && j - i == 1) break;
-        for (int k = j + 1; k < n; k++)
-          if (v[i].beg_l == v[k].beg_l && v[i].end_t == v[k].beg_t) { const Seg x = v[j]; v[j] = v[k]; v[k] = x; break; }
-      }
-    for (int i = 0; i + 1 < n; i++) {  // overlaps between neighbours
+    for (int i = 0; i + 1 < n; i++) {
       Seg &a = v[i], &b = v[i + 1];
       if (a.beg_t == b.beg_t && a.end_t == b.end_t) {
         const int half = (a.end_t - a.beg_t) / 2;
@@ -221,6 +227,10 @@ BTRAPZ_HD void resolve_segments_core(int variant, double delta, Seg *v, int n) {
           v[j].beg_t += third; v[j].t = (v[j].end_t - v[j].beg_t) * delta;
         }
   }
+}
+BTRAPZ_HD void resolve_segments_core(int variant, double delta, Seg *v, int n) {
+  if (variant == 0) reorder_segments_core(v, n);
+  overlap_segments_core(variant, delta, v, n);
 }
 BTRAPZ_HD int order_segments_core(int variant, double delta, Seg *v, int n) {
   n = dedup_segments_core(v, n);

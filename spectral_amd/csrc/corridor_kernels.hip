@@ -22,7 +22,7 @@ enum { MAX_ALL = 160, MAX_SEL = 64 };   // capacities of the retry pass (see btr
 // segment lists are sized per launch: a first pass with room for the usual case (cap_o segments per obstacle,
 // cap_sel selected ones: 14 KB, 11 wavefronts per CU at N = 71 with 3 obstacles) and, for the candidates that
 // overflow it, a retry pass with the full MAX_ALL / MAX_SEL (29 KB, 5 per CU).  Same code, same results.
-// Dynamic LDS: Seg all[O * cap_o] | Seg sel[cap_sel] | s_ref[N] | l_ref[N] | slopes[O][N][2] (when `staged`) |
+// Dynamic LDS: Seg all[O * cap_o] (later: Seg sel[cap_sel], same storage) | s_ref[N] | l_ref[N] | ds_bounds[N][2] | slopes[O][N][2] (when `staged`) |
 //              int hits[O * cap_o] | int ocount[64] | int key[cap_sel] | short slot_of[O * cap_o] | short pick[cap_sel]
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw);
 
@@ -39,55 +39,207 @@ __global__ __launch_bounds__(64) void corridor_batch_kernel(const CorridorArgs a
   }
 }
 
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// CorridorGeneration + CorridorSplit of every obstacle with the whole wavefront (extract_segments_core, the serial
+// statement, gives the same segments bit for bit and is what the host driver and the fallback below run):
+//  1. breaks: a segment ends at the first knot whose slopes differ from the OPEN segment's by more than 0.2 -- a
+//     recurrence over the knots, but the open segment's slopes only change at a break.  64 knots are compared at a
+//     time against the current pair; ballot + find-first gives the next break, the pair is re-read there and the
+//     window restarts behind it: N/64 + (number of breaks) rounds per obstacle instead of N steps on one lane.
+//  2. one lane per (obstacle, base segment): bounds at its first knot (independent loads: one memory round trip for
+//     all of them instead of one per segment), duration, number of 1-second pieces; a scan places the pieces.
+//  3. every lane writes the pieces of its base segment (the bias recurrence `bias + 1.0 * skew` step by step).
+// brk (int[O * cap_o]) and first (short[O]) are scratch.  Returns false when there are more than 64 base segments in
+// total (the caller then runs the serial statement).
+__device__ __forceinline__ bool extract_segments_wave(const CorridorArgs &a, int lane, const double *gs, const double *gl,
+                                                      const double *slopes, Seg *all, int cap_o, int *ocount, int *brk,
+                                                      short *first) {
+  const int N = a.N, O = a.num_obs;
+  const double2 *sk2 = reinterpret_cast<const double2 *>(slopes);
+  const double threshold = 0.2;  // solve_3d.cc:372
+  int my_nb = 0;                 // lane o: base segments of obstacle o, -1 when they exceed cap_o
+  for (int o = 0; o < O; o++) {
+    const double2 *sk = sk2 + (size_t)o * N;
+    double2 cur = sk[1];
+    int nb = 1, start = 2;
+    if (lane == 0) brk[o * cap_o] = 0;
+    while (start < N - 1) {
+      const int i = start + lane;
+      bool differs = false;
+      if (i < N - 1) {
+        const double2 v = sk[i];
+        differs = fabs(v.x - cur.x) > threshold || fabs(v.y - cur.y) > threshold;
+      }
+      const unsigned long long m = __ballot(differs);
+      if (m == 0) { start += 64; continue; }
+      const int j = start + __ffsll((long long)m) - 1;
+      if (nb + 1 > cap_o) { nb = -1; break; }
+      if (lane == 0) brk[o * cap_o + nb] = j;
+      nb++;
+      cur = sk[j + 1];   // j <= N - 2
+      start = j + 1;
+    }
+    if (lane == o) my_nb = nb;
+  }
+  __syncthreads();
+  const int nbp = my_nb > 0 ? my_nb : 0;
+  const int incl = wave_inclusive_scan(nbp, lane);
+  if (__shfl(incl, 63) > 64) return false;
+  if (lane < O) ocount[lane] = my_nb < 0 ? -1 : 0;
+  int mo = -1, mk = 0, mn = 0;
+  for (int o = 0; o < O; o++) {
+    const int n = __shfl(nbp, o), q0 = __shfl(incl, o) - n;
+    if (lane >= q0 && lane < q0 + n) { mo = o; mk = lane - q0; mn = n; }
+  }
+  Seg s = seg_default();
+  int h = 0;
+  bool bad = false;
+  if (mo >= 0) {
+    const int beg = brk[mo * cap_o + mk];
+    const BoundsView sb{gs + (size_t)mo * N * 2}, lb{gl + (size_t)mo * N * 2};
+    const double2 slope = sk2[(size_t)mo * N + beg + 1];
+    s.beg_t = beg;
+    s.end_t = mk + 1 < mn ? brk[mo * cap_o + mk + 1] : N - 1;
+    s.down_skew = slope.x; s.down_bias = sb.lo(beg);
+    s.upp_skew = slope.y; s.upp_bias = sb.hi(beg);
+    s.beg_l = lb.lo(beg); s.end_l = lb.hi(beg);
+    if (a.variant == 0) {  // forward difference for the first segment, backward for the later ones (solve_3d.cc:338-341,358-367)
+      const int i1 = beg == 0 ? 1 : beg, i0 = i1 - 1;
+      s.l_down_bias = s.beg_l; s.l_upp_bias = s.end_l;
+      s.l_down_skew = (lb.lo(i1) - lb.lo(i0)) / a.delta; s.l_upp_skew = (lb.hi(i1) - lb.hi(i0)) / a.delta;
+    }
+    s.t = (s.end_t - s.beg_t) * a.delta;
+    double t = s.t;
+    while (t > 1) { t = t - 1; if (++h > cap_o) { bad = true; break; } }
+  }
+  const int cnt = mo >= 0 ? h + 1 : 0;
+  const int upto = wave_inclusive_scan(cnt, lane);
+  if (mo >= 0 && mk == 0) first[mo] = (short)(upto - cnt);
+  __syncthreads();
+  const int pos = mo >= 0 ? upto - cnt - first[mo] : 0;
+  if (bad) ocount[mo] = -1;
+  __syncthreads();
+  if (mo >= 0 && mk == mn - 1 && ocount[mo] == 0) ocount[mo] = pos + cnt > cap_o ? -1 : pos + cnt;
+  __syncthreads();
+  if (mo >= 0 && ocount[mo] > 0) {
+    Seg *w = all + mo * cap_o + pos;
+    while (s.t > 1) {   // CorridorSplit, solve_3d.cc:735-746
+      s.t = s.t - 1;
+      Seg head = seg_default();
+      head.beg_t = s.beg_t; head.end_t = head.beg_t + 10; head.t = 1.0;
+      head.down_skew = s.down_skew; head.down_bias = s.down_bias;
+      head.upp_skew = s.upp_skew; head.upp_bias = s.upp_bias;
+      if (a.variant == 0) {
+        head.l_down_skew = s.l_down_skew; head.l_down_bias = s.l_down_bias;
+        head.l_upp_skew = s.l_upp_skew; head.l_upp_bias = s.l_upp_bias;
+      }
+      head.beg_l = s.beg_l; head.end_l = s.end_l;
+      s.beg_t = s.beg_t + 10;
+      s.down_bias = head.down_bias + 1.0 * head.down_skew;
+      s.upp_bias = head.upp_bias + 1.0 * head.upp_skew;
+      *w++ = head;
+    }
+    *w = s;
+  }
+  return true;
+}
+
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw) {
   const int lane = threadIdx.x;
   const int N = a.N, O = a.num_obs;
   const int cap_o = a.cap_o, cap_all = cap_o * O, cap_sel = a.cap_sel;
   Seg *all = reinterpret_cast<Seg *>(lds_raw);           // segments of every obstacle, obstacle o at [o * cap_o, ...)
-  Seg *sel = all + cap_all;                              // the selected, ordered corridor
+  Seg *sel = all;                                        // the selected, ordered corridor: written (from registers)
+                                                         // when all[] has been read for the last time, over it
   // (16-byte aligned: the slopes are written as double2)
-  double *dyn = reinterpret_cast<double *>((reinterpret_cast<size_t>(sel + cap_sel) + 15) & ~(size_t)15);
+  double *dyn = reinterpret_cast<double *>((reinterpret_cast<size_t>(all + (cap_all > cap_sel ? cap_all : cap_sel)) + 15) & ~(size_t)15);
   double *sref = dyn, *lref = dyn + N;
-  double *slopes = dyn + 2 * N;
+  double *dsb = dyn + 2 * N;                             // ds bounds of the knots, (lower, upper) pairs
+  double *slopes = dyn + 4 * N;
   int *hits = reinterpret_cast<int *>(slopes + (staged ? (size_t)O * N * 2 : 0));   // reference knots inside every segment
   int *ocount = hits + cap_all;
   int *key = ocount + 64;                                // beg_t of the survivors of the de-dup, for the rank sort
   short *slot_of = reinterpret_cast<short *>(key + cap_sel);  // flattened segment index -> slot in all[]
   short *pick = slot_of + cap_all;                       // slots of the selected segments, in selection order
 
-  bool refs_finite = true;
-  for (int i = lane; i < N; i += 64) {
-    const double s_ = a.s_ref[(size_t)b * N + i], l_ = a.l_ref[(size_t)b * N + i];
-    sref[i] = s_; lref[i] = l_;
-    refs_finite = refs_finite && fabs(s_) < 1e300 && fabs(l_) < 1e300;
-  }
-  refs_finite = __all(refs_finite);
-  // The per-obstacle scan below is a serial walk over the knots that compares slopes: all lanes compute the
-  // slopes (two divisions per knot) with coalesced 16-byte loads and leave them in LDS; the bounds themselves
-  // are read again only where a segment starts (a handful of knots, L2 hits).
+  // The streaming phase.  A wavefront that waits for each load before it issues the next one pays a memory round
+  // trip per 64 knots: the loads are issued in blocks of four per array (indices clamped instead of predicated, so
+  // that they stay in one basic block) and the first block of the obstacle bounds is in flight before the
+  // reference is consumed.
+  // The extraction compares slopes: all lanes compute them (two divisions per knot) from coalesced 16-byte loads and
+  // leave them in LDS; the bounds themselves are read again only where a segment starts.
   const double *gs = a.s_bounds + (size_t)b * O * N * 2, *gl = a.l_bounds + (size_t)b * O * N * 2;
-  if (staged) {
-    const int n2 = O * N;  // pairs
-    const double2 *gs2 = reinterpret_cast<const double2 *>(gs);
-    double2 *sk2 = reinterpret_cast<double2 *>(slopes);
-    for (int i = lane; i < n2; i += 64) {
-      if (i % N > 0) {  // (b(i) - b(i-1)) / delta: the expression of SlopesOnTheFly
-        const double2 cur = gs2[i], prv = gs2[i - 1];
-        sk2[i] = make_double2((cur.x - prv.x) / a.delta, (cur.y - prv.y) / a.delta);
+  const int n2 = O * N;  // (lower, upper) pairs
+  const double2 *gs2 = reinterpret_cast<const double2 *>(gs);
+  double2 *sk2 = reinterpret_cast<double2 *>(slopes);
+  double2 cur[4], prv[4];
+  auto load_pairs = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = base + u * 64 + lane, ic = i < n2 ? i : n2 - 1;
+      cur[u] = gs2[ic]; prv[u] = gs2[ic > 0 ? ic - 1 : 0];
+    }
+  };
+  auto store_slopes = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = base + u * 64 + lane;
+      if (i < n2 && i % N > 0)  // (b(i) - b(i-1)) / delta: the expression of SlopesOnTheFly
+        sk2[i] = make_double2((cur[u].x - prv[u].x) / a.delta, (cur[u].y - prv[u].y) / a.delta);
+    }
+  };
+  if (staged) load_pairs(0);
+  bool refs_finite = true;
+  {
+    const double *gsr = a.s_ref + (size_t)b * N, *glr = a.l_ref + (size_t)b * N;
+    const double2 *gds = reinterpret_cast<const double2 *>(a.ds_bounds + (size_t)b * N * 2);
+    double2 *d2 = reinterpret_cast<double2 *>(dsb);  // reduced over every segment's knots at the end
+    for (int base = 0; base < N; base += 256) {
+      double s_[4], l_[4];
+      double2 ds_[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = base + u * 64 + lane, ic = i < N ? i : N - 1;
+        s_[u] = gsr[ic]; l_[u] = glr[ic]; ds_[u] = gds[ic];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = base + u * 64 + lane;
+        if (i < N) {
+          sref[i] = s_[u]; lref[i] = l_[u]; d2[i] = ds_[u];
+          refs_finite = refs_finite && fabs(s_[u]) < 1e300 && fabs(l_[u]) < 1e300;
+        }
       }
     }
+  }
+  refs_finite = __all(refs_finite);
+  if (staged) {
+    store_slopes(0);
+    for (int base = 256; base < n2; base += 256) { load_pairs(base); store_slopes(base); }
   }
   __syncthreads();
   // ---- per-obstacle extraction: lane o owns obstacle o ----
 #ifdef CABL_NOEXTRACT
   if (lane < O) { ocount[lane] = 1; all[lane * cap_o] = seg_default(); all[lane * cap_o].end_t = N - 1; all[lane * cap_o].t = 1.0; }
 #else
-  if (lane < O) {
-    const BoundsView sb{gs + (size_t)lane * N * 2}, lb{gl + (size_t)lane * N * 2};
-    if (staged)
-      ocount[lane] = extract_segments_core(a.variant, N, a.delta, sb, lb, SlopeTable{slopes + (size_t)lane * N * 2}, all + lane * cap_o, cap_o);
-    else
-      ocount[lane] = extract_segments_core(a.variant, N, a.delta, sb, lb, SlopesOnTheFly{sb, a.delta}, all + lane * cap_o, cap_o);
+  // hits / slot_of are free until the selection: scratch of the wave-wide extraction
+  const bool done = staged && extract_segments_wave(a, lane, gs, gl, slopes, all, cap_o, ocount, hits, slot_of);
+  if (!done) {
+    __syncthreads();
+    if (lane < O) {  // the serial statement: lane o owns obstacle o
+      const BoundsView sb{gs + (size_t)lane * N * 2}, lb{gl + (size_t)lane * N * 2};
+      if (staged)
+        ocount[lane] = extract_segments_core(a.variant, N, a.delta, sb, lb, SlopeTable{slopes + (size_t)lane * N * 2}, all + lane * cap_o, cap_o);
+      else
+        ocount[lane] = extract_segments_core(a.variant, N, a.delta, sb, lb, SlopesOnTheFly{sb, a.delta}, all + lane * cap_o, cap_o);
+    }
   }
 #endif
   __syncthreads();
@@ -140,7 +292,10 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   int S = overflow ? -1 : 0;
   if (!overflow && nsel > 0) {
 #ifdef CABL_NOORDER
-    if (lane < nsel) { sel[lane] = all[pick[lane]]; sel[lane].count = 3; }
+    Seg mine = seg_default();
+    if (lane < nsel) { mine = all[pick[lane]]; mine.count = 3; }
+    __syncthreads();
+    if (lane < nsel) sel[lane] = mine;
     S = nsel;
 #else
     Seg mine = seg_default();
@@ -162,10 +317,38 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
         for (int i = 0; i < n; i++) rank += (key[i] < mine.beg_t || (key[i] == mine.beg_t && i < pos)) ? 1 : 0;
       }
     }
+    __syncthreads();                                       // every lane has its copy: all[] may be overwritten
     if (keep) sel[rank] = mine;
     __syncthreads();
-    // the data-dependent reordering and the overlap resolution stay serial (a few neighbour comparisons)
-    if (lane == 0) resolve_segments_core(a.variant, a.delta, sel, n);
+    if (a.variant == 0 && n > 2) {
+      // reorder_segments_core with lane r holding position r's keys: the search for "the first k > j that continues
+      // segment i" is a ballot; a hit swaps the keys (and the source slots) of lanes j and k
+      double bl = 0.0;
+      int bt = 0, et = 0, src = lane;
+      if (lane < n) { bl = sel[lane].beg_l; bt = sel[lane].beg_t; et = sel[lane].end_t; }
+      for (int i = 0; i + 1 < n; i++) {
+        const double bl_i = __shfl(bl, i);
+        const int et_i = __shfl(et, i);
+        for (int j = i + 1; j < n; j++) {
+          if (j == i + 1 && bl_i == __shfl(bl, j)) break;
+          const unsigned long long m = __ballot(lane > j && lane < n && bl == bl_i && bt == et_i);
+          if (m == 0) continue;
+          const int k = __ffsll((long long)m) - 1;
+          const int other = lane == j ? k : j;       // only lanes j and k take the exchanged values
+          const double bl_x = __shfl(bl, other);
+          const int bt_x = __shfl(bt, other), et_x = __shfl(et, other), src_x = __shfl(src, other);
+          if (lane == j || lane == k) { bl = bl_x; bt = bt_x; et = et_x; src = src_x; }
+        }
+      }
+      Seg moved = seg_default();
+      const bool moves = lane < n && src != lane;
+      if (moves) moved = sel[src];
+      __syncthreads();
+      if (moves) sel[lane] = moved;
+      __syncthreads();
+    }
+    // every step of the overlap resolution sees the spans the previous one left: a serial walk over the neighbours
+    if (lane == 0) overlap_segments_core(a.variant, a.delta, sel, n);
     S = n;
 #endif
   }
@@ -186,8 +369,8 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     double lo = 0.0, hi = 1000.0;  // solve_3d.cc:835-841
     for (int i = c.beg_t; i <= c.end_t; i++) {
       const int ii = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
-      lo = fmax(a.ds_bounds[((size_t)b * N + ii) * 2], lo);
-      hi = fmin(a.ds_bounds[((size_t)b * N + ii) * 2 + 1], hi);
+      lo = fmax(dsb[2 * ii], lo);
+      hi = fmin(dsb[2 * ii + 1], hi);
     }
     sg[BTRAPZ_F_DS_LO * BS + e] = lo; sg[BTRAPZ_F_DS_HI * BS + e] = hi;
     const int i0 = 10 * lane > N - 1 ? N - 1 : 10 * lane, i1 = 10 * lane + 1 > N - 1 ? N - 1 : 10 * lane + 1;  // :1161-1165, clamped
