@@ -422,8 +422,12 @@ BTRAPZ_EXPORT int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B
   const int staged = slope_bytes <= 24 * 1024 ? 1 : 0;
   auto lds_bytes = [&](int cap_o, int cap_sel) {
     const size_t cap_all = (size_t)cap_o * num_obs;
-    return 104 * (cap_all > (size_t)cap_sel ? cap_all : (size_t)cap_sel) + sizeof(double) * 4 * (size_t)N + (staged ? slope_bytes : 0) +
-           sizeof(int) * (cap_all + 64 + cap_sel) + sizeof(short) * (cap_all + cap_sel) + 16;
+    return 104 * (cap_all > (size_t)cap_sel ? cap_all : (size_t)cap_sel) + (staged && slope_bytes > sizeof(double) * 4 * (size_t)N ? slope_bytes : sizeof(double) * 4 * (size_t)N) +
+           sizeof(int) * (cap_all + 64 + cap_sel) + sizeof(short) * (cap_all + cap_sel) + 16
+#ifdef CABL_PAD   // occupancy experiments: scratch/build_variant.sh X -DCABL_PAD=bytes
+           + CABL_PAD
+#endif
+        ;
   };
   const bool two_pass = cap_o_small < cap_o_big || cap_sel_small < cap_sel_big;
   a.pass = 0; a.cap_o = cap_o_small; a.cap_sel = cap_sel_small;

@@ -22,11 +22,15 @@ enum { MAX_ALL = 160, MAX_SEL = 64 };   // capacities of the retry pass (see btr
 // segment lists are sized per launch: a first pass with room for the usual case (cap_o segments per obstacle,
 // cap_sel selected ones: 14 KB, 11 wavefronts per CU at N = 71 with 3 obstacles) and, for the candidates that
 // overflow it, a retry pass with the full MAX_ALL / MAX_SEL (29 KB, 5 per CU).  Same code, same results.
-// Dynamic LDS: Seg all[O * cap_o] (later: Seg sel[cap_sel], same storage) | s_ref[N] | l_ref[N] | ds_bounds[N][2] | slopes[O][N][2] (when `staged`) |
+// Dynamic LDS: Seg all[O * cap_o] (later: Seg sel[cap_sel], same storage) | slopes[O][N][2] (when `staged`; later, same
+//              storage: s_ref[N] | l_ref[N] | ds_bounds[N][2]) |
 //              int hits[O * cap_o] | int ocount[64] | int key[cap_sel] | short slot_of[O * cap_o] | short pick[cap_sel]
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw);
 
-__global__ __launch_bounds__(64) void corridor_batch_kernel(const CorridorArgs a, int staged) {
+#ifndef CABL_WAVES
+#define CABL_WAVES 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 8))) void corridor_batch_kernel(const CorridorArgs a, int staged) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   if (a.pass == 0) {
     corridor_candidate(a, staged, (int)blockIdx.x, lds_raw);
@@ -56,15 +60,14 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
 //  2. one lane per (obstacle, base segment): bounds at its first knot (independent loads: one memory round trip for
 //     all of them instead of one per segment), duration, number of 1-second pieces; a scan places the pieces.
 //  3. every lane writes the pieces of its base segment (the bias recurrence `bias + 1.0 * skew` step by step).
-// brk (int[O * cap_o]) and first (short[O]) are scratch.  Returns false when there are more than 64 base segments in
-// total (the caller then runs the serial statement).
-__device__ __forceinline__ bool extract_segments_wave(const CorridorArgs &a, int lane, const double *gs, const double *gl,
-                                                      const double *slopes, Seg *all, int cap_o, int *ocount, int *brk,
-                                                      short *first) {
+// brk (int[O * cap_o]) and first (short[O]) are scratch.  find_breaks_wave is step 1 and returns false when there are
+// more than 64 base segments in total (the caller then runs the serial statement); build_segments_wave is steps 2-3.
+__device__ __forceinline__ bool find_breaks_wave(const CorridorArgs &a, int lane, const double *slopes, int cap_o, int *brk,
+                                                 int &my_nb) {
   const int N = a.N, O = a.num_obs;
   const double2 *sk2 = reinterpret_cast<const double2 *>(slopes);
   const double threshold = 0.2;  // solve_3d.cc:372
-  int my_nb = 0;                 // lane o: base segments of obstacle o, -1 when they exceed cap_o
+  my_nb = 0;                     // lane o: base segments of obstacle o, -1 when they exceed cap_o
   for (int o = 0; o < O; o++) {
     const double2 *sk = sk2 + (size_t)o * N;
     double2 cur = sk[1];
@@ -89,9 +92,15 @@ __device__ __forceinline__ bool extract_segments_wave(const CorridorArgs &a, int
     if (lane == o) my_nb = nb;
   }
   __syncthreads();
+  return __shfl(wave_inclusive_scan(my_nb > 0 ? my_nb : 0, lane), 63) <= 64;
+}
+__device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int lane, const double *gs, const double *gl,
+                                                    const double *slopes, Seg *all, int cap_o, int *ocount, const int *brk,
+                                                    short *first, int my_nb) {
+  const int N = a.N, O = a.num_obs;
+  const double2 *sk2 = reinterpret_cast<const double2 *>(slopes);
   const int nbp = my_nb > 0 ? my_nb : 0;
   const int incl = wave_inclusive_scan(nbp, lane);
-  if (__shfl(incl, 63) > 64) return false;
   if (lane < O) ocount[lane] = my_nb < 0 ? -1 : 0;
   int mo = -1, mk = 0, mn = 0;
   for (int o = 0; o < O; o++) {
@@ -148,7 +157,6 @@ __device__ __forceinline__ bool extract_segments_wave(const CorridorArgs &a, int
     }
     *w = s;
   }
-  return true;
 }
 
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw) {
@@ -160,10 +168,13 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
                                                          // when all[] has been read for the last time, over it
   // (16-byte aligned: the slopes are written as double2)
   double *dyn = reinterpret_cast<double *>((reinterpret_cast<size_t>(all + (cap_all > cap_sel ? cap_all : cap_sel)) + 15) & ~(size_t)15);
+  // the slope table lives until the segments are built; the reference and the ds bounds (needed from the selection
+  // on) are loaded meanwhile and stored over it
+  double *slopes = dyn;
   double *sref = dyn, *lref = dyn + N;
   double *dsb = dyn + 2 * N;                             // ds bounds of the knots, (lower, upper) pairs
-  double *slopes = dyn + 4 * N;
-  int *hits = reinterpret_cast<int *>(slopes + (staged ? (size_t)O * N * 2 : 0));   // reference knots inside every segment
+  const size_t shared_doubles = staged && O > 2 ? (size_t)O * N * 2 : (size_t)N * 4;
+  int *hits = reinterpret_cast<int *>(dyn + shared_doubles);   // reference knots inside every segment
   int *ocount = hits + cap_all;
   int *key = ocount + 64;                                // beg_t of the survivors of the de-dup, for the rank sort
   short *slot_of = reinterpret_cast<short *>(key + cap_sel);  // flattened segment index -> slot in all[]
@@ -171,8 +182,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
 
   // The streaming phase.  A wavefront that waits for each load before it issues the next one pays a memory round
   // trip per 64 knots: the loads are issued in blocks of four per array (indices clamped instead of predicated, so
-  // that they stay in one basic block) and the first block of the obstacle bounds is in flight before the
-  // reference is consumed.
+  // that they stay in one basic block).
   // The extraction compares slopes: all lanes compute them (two divisions per knot) from coalesced 16-byte loads and
   // leave them in LDS; the bounds themselves are read again only where a segment starts.
   const double *gs = a.s_bounds + (size_t)b * O * N * 2, *gl = a.l_bounds + (size_t)b * O * N * 2;
@@ -195,43 +205,49 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
         sk2[i] = make_double2((cur[u].x - prv[u].x) / a.delta, (cur[u].y - prv[u].y) / a.delta);
     }
   };
-  if (staged) load_pairs(0);
-  bool refs_finite = true;
-  {
-    const double *gsr = a.s_ref + (size_t)b * N, *glr = a.l_ref + (size_t)b * N;
-    const double2 *gds = reinterpret_cast<const double2 *>(a.ds_bounds + (size_t)b * N * 2);
-    double2 *d2 = reinterpret_cast<double2 *>(dsb);  // reduced over every segment's knots at the end
-    for (int base = 0; base < N; base += 256) {
-      double s_[4], l_[4];
-      double2 ds_[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = base + u * 64 + lane, ic = i < N ? i : N - 1;
-        s_[u] = gsr[ic]; l_[u] = glr[ic]; ds_[u] = gds[ic];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = base + u * 64 + lane;
-        if (i < N) {
-          sref[i] = s_[u]; lref[i] = l_[u]; d2[i] = ds_[u];
-          refs_finite = refs_finite && fabs(s_[u]) < 1e300 && fabs(l_[u]) < 1e300;
-        }
-      }
-    }
-  }
-  refs_finite = __all(refs_finite);
   if (staged) {
+    load_pairs(0);
     store_slopes(0);
     for (int base = 256; base < n2; base += 256) { load_pairs(base); store_slopes(base); }
   }
+  // reference and ds bounds of the first 256 knots: issued behind the break search, in the same memory round trip
+  // as the bounds at the segment starts
+  const double *gsr = a.s_ref + (size_t)b * N, *glr = a.l_ref + (size_t)b * N;
+  const double2 *gds = reinterpret_cast<const double2 *>(a.ds_bounds + (size_t)b * N * 2);
+  double ref_s[4], ref_l[4];
+  double2 ref_ds[4];
+  auto load_refs = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = base + u * 64 + lane, ic = i < N ? i : N - 1;
+      ref_s[u] = gsr[ic]; ref_l[u] = glr[ic]; ref_ds[u] = gds[ic];
+    }
+  };
+  bool refs_finite = true;
+  auto store_refs = [&](int base) {
+    double2 *d2 = reinterpret_cast<double2 *>(dsb);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = base + u * 64 + lane;
+      if (i < N) {
+        sref[i] = ref_s[u]; lref[i] = ref_l[u]; d2[i] = ref_ds[u];
+        refs_finite = refs_finite && fabs(ref_s[u]) < 1e300 && fabs(ref_l[u]) < 1e300;
+      }
+    }
+  };
   __syncthreads();
   // ---- per-obstacle extraction: lane o owns obstacle o ----
 #ifdef CABL_NOEXTRACT
   if (lane < O) { ocount[lane] = 1; all[lane * cap_o] = seg_default(); all[lane * cap_o].end_t = N - 1; all[lane * cap_o].t = 1.0; }
+  load_refs(0);
 #else
   // hits / slot_of are free until the selection: scratch of the wave-wide extraction
-  const bool done = staged && extract_segments_wave(a, lane, gs, gl, slopes, all, cap_o, ocount, hits, slot_of);
-  if (!done) {
+  int my_nb = 0;
+  const bool wide = staged && find_breaks_wave(a, lane, slopes, cap_o, hits, my_nb);
+  load_refs(0);
+  if (wide) {
+    build_segments_wave(a, lane, gs, gl, slopes, all, cap_o, ocount, hits, slot_of, my_nb);
+  } else {
     __syncthreads();
     if (lane < O) {  // the serial statement: lane o owns obstacle o
       const BoundsView sb{gs + (size_t)lane * N * 2}, lb{gl + (size_t)lane * N * 2};
@@ -242,6 +258,10 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     }
   }
 #endif
+  __syncthreads();                                         // the slope table has been read for the last time
+  store_refs(0);
+  for (int base = 256; base < N; base += 256) { load_refs(base); store_refs(base); }
+  refs_finite = __all(refs_finite);
   __syncthreads();
   // ---- selection along the reference (solve_3d.cc:534-596): knots inside every segment, the lanes spread over
   // (segment, knot) pairs; the reference's running hit counter then reduces to a carry over the segments in order
@@ -348,7 +368,9 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
       __syncthreads();
     }
     // every step of the overlap resolution sees the spans the previous one left: a serial walk over the neighbours
+#ifndef CABL_NOOVERLAP
     if (lane == 0) overlap_segments_core(a.variant, a.delta, sel, n);
+#endif
     S = n;
 #endif
   }
