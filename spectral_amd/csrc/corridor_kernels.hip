@@ -1,13 +1,18 @@
 // corridor_kernels.hip -- the corridor stage batched on the device and the
 // bucketing that lets the QP kernel take candidates with different segment counts.
 //
-// corridor_batch_kernel: one wavefront per candidate.  Per-knot bounds of every obstacle -> slopes (all lanes)
-// -> CorridorGeneration + CorridorSplit (one lane per obstacle) -> CollisionCheck: reference knots are tested
-// against every segment with the lanes spread over (segment, knot) pairs (ballot + popcount gives the hit
-// counts; the reference's running counter becomes a carry, corridor_core.h) -> de-dup and stable sort across
-// the lanes (one selected segment per lane) -> reorder / overlap resolution (lane 0) -> the batch record of the
-// QP kernel (one lane per selected segment, coalesced field-major stores).  This is the one stage of the path that streams
-// HBM: num_obs * N * 4 doubles per candidate (11 KB at N = 71, 5 obstacles).
+// corridor_batch_kernel: one wavefront per candidate, every phase across the lanes.  Per-knot bounds of every
+// obstacle -> slopes (all lanes, loads issued in blocks) -> CorridorGeneration + CorridorSplit (ballot search for the
+// next slope break, then one lane per base segment; extract_segments_wave) -> CollisionCheck: one lane per segment
+// counts the reference knots inside it, a scan turns the reference's running counter into a per-segment decision
+// -> de-dup (keys compared through readlane), stable rank sort, the "continues this lane" reorder (ballot search) and
+// the neighbour-overlap walk, all on keys held in the lanes (only the cuboid variant's all-pairs overlap pass runs
+// serially) -> the batch record of the QP kernel (one lane per selected segment, coalesced field-major stores).
+// The serial statements of corridor_core.h (what the host driver runs) remain the fallback for the shapes the
+// wave-wide code does not take (slope table larger than 24 KB, more than 64 base segments) and give the same
+// segments bit for bit.  This is the one stage of the path that streams HBM: num_obs * N * 4 doubles per candidate
+// (11 KB at N = 71, 5 obstacles); it runs on latency (wavefronts per CU x round trips per candidate), hence the LDS
+// overlays and the 4-wavefronts-per-SIMD register budget below.
 // References: src/solve_3d.cc:323-486,488-714,729-772,835-845,1159-1166 ; src/cuboid_3d.cc:301-573.
 #include <hip/hip_runtime.h>
 
@@ -43,6 +48,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 
   }
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int l) {  // l: the same in every lane
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
   for (int d = 1; d < 64; d <<= 1) {
     const int t = __shfl_up(v, d);
@@ -283,8 +291,12 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     // upp_bias > down_bias and the upper end above the lower end, the edge functions d0 and d2 of knot_inside
     // (whose first products are exact zeros for a finite reference) have opposite signs there -- so the lane only
     // visits its own knots.  A segment that fails those conditions, or a reference that is not finite, takes all.
+    // The reference's running hit counter (selection_pushes): its value when it reaches a segment is the number of
+    // hits before it, mod 3 -- a scan over the lanes instead of a walk over the segments.
+    int carry = 0;
     for (int q0 = 0; q0 < total; q0 += 64) {
       const int q = q0 + lane;
+      int h = 0;
       if (q < total) {
         const Seg c = all[slot_of[q]];
         const bool own_range = refs_finite && (c.upp_bias - c.down_bias) > 0.0 &&
@@ -292,19 +304,18 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
                                c.beg_t <= c.end_t;
         const int i_lo = own_range ? (c.beg_t > 0 ? c.beg_t : 0) : 0;
         const int i_hi = own_range ? (c.end_t < N - 1 ? c.end_t : N - 1) : N - 1;
-        int h = 0;
         for (int i = i_lo; i <= i_hi; i++) h += knot_inside(c, sref[i], lref[i], (double)i, a.delta) ? 1 : 0;
-        hits[q] = h;
       }
+      const int upto = wave_inclusive_scan(h, lane);
+      int counter = (carry + upto - h) % 3;
+      const bool take = q < total && selection_pushes(h, counter) >= 1;
+      const unsigned long long m = __ballot(take);
+      const int r = nsel + __popcll(m & ((1ull << lane) - 1ull));
+      if (take && r < cap_sel) pick[r] = slot_of[q];
+      nsel += __popcll(m);
+      carry = (carry + __shfl(upto, 63)) % 3;
     }
-    __syncthreads();
-    int carry = 0;
-    for (int q = 0; q < total; q++) {
-      if (selection_pushes(hits[q], carry) >= 1) {
-        if (nsel < cap_sel) { if (lane == 0) pick[nsel] = slot_of[q]; nsel++; }
-        else overflow = true;
-      }
-    }
+    if (nsel > cap_sel) { nsel = cap_sel; overflow = true; }
   }
   __syncthreads();
   if (overflow && a.pass == 0 && a.retry_list && lane == 0) a.retry_list[atomicAdd(a.retry_count, 1)] = b;  // second chance
@@ -318,13 +329,23 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     if (lane < nsel) sel[lane] = mine;
     S = nsel;
 #else
+    nsel = __builtin_amdgcn_readfirstlane(nsel);
     Seg mine = seg_default();
-    bool keep = false;
-    if (lane < nsel) {
+    bool keep = lane < nsel;
+    if (keep) {
       mine = all[pick[lane]];
       mine.count = 3;                                      // the reference pushes a counted copy (solve_3d.cc:590)
-      keep = true;
-      for (int i = 0; i < lane; i++) if (same_segment(all[pick[i]], mine)) { keep = false; break; }  // equality is transitive
+    }
+    // a later twin of segment i goes (same_segment; equality is transitive, so "a twin of any earlier one" is the
+    // reference's "a twin of an earlier kept one"): the spans are compared first, the rest only when some lane matches
+    for (int i = 0; i + 1 < nsel; i++) {
+      const bool span = lane > i && lane < nsel && mine.beg_t == __builtin_amdgcn_readlane(mine.beg_t, i) &&
+                        mine.end_t == __builtin_amdgcn_readlane(mine.end_t, i);
+      if (__ballot(span) == 0) continue;
+      if (span && mine.down_bias == readlane_f64(mine.down_bias, i) && mine.down_skew == readlane_f64(mine.down_skew, i) &&
+          mine.upp_bias == readlane_f64(mine.upp_bias, i) && mine.upp_skew == readlane_f64(mine.upp_skew, i) &&
+          mine.beg_l == readlane_f64(mine.beg_l, i) && mine.end_l == readlane_f64(mine.end_l, i))
+        keep = false;
     }
     const unsigned long long kept = __ballot(keep);
     const int pos = __popcll(kept & ((1ull << lane) - 1ull)), n = __popcll(kept);
@@ -340,17 +361,18 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     __syncthreads();                                       // every lane has its copy: all[] may be overwritten
     if (keep) sel[rank] = mine;
     __syncthreads();
-    if (a.variant == 0 && n > 2) {
-      // reorder_segments_core with lane r holding position r's keys: the search for "the first k > j that continues
-      // segment i" is a ballot; a hit swaps the keys (and the source slots) of lanes j and k
+    if (a.variant == 0) {
+      // lane r holds the keys of position r
       double bl = 0.0;
       int bt = 0, et = 0, src = lane;
       if (lane < n) { bl = sel[lane].beg_l; bt = sel[lane].beg_t; et = sel[lane].end_t; }
+      // reorder_segments_core: the search for "the first k > j that continues segment i" is a ballot; a hit swaps
+      // the keys (and the source slots) of lanes j and k
       for (int i = 0; i + 1 < n; i++) {
-        const double bl_i = __shfl(bl, i);
-        const int et_i = __shfl(et, i);
+        const double bl_i = readlane_f64(bl, i);
+        const int et_i = __builtin_amdgcn_readlane(et, i);
         for (int j = i + 1; j < n; j++) {
-          if (j == i + 1 && bl_i == __shfl(bl, j)) break;
+          if (j == i + 1 && bl_i == readlane_f64(bl, j)) break;
           const unsigned long long m = __ballot(lane > j && lane < n && bl == bl_i && bt == et_i);
           if (m == 0) continue;
           const int k = __ffsll((long long)m) - 1;
@@ -360,17 +382,39 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
           if (lane == j || lane == k) { bl = bl_x; bt = bt_x; et = et_x; src = src_x; }
         }
       }
-      Seg moved = seg_default();
       const bool moves = lane < n && src != lane;
-      if (moves) moved = sel[src];
-      __syncthreads();
-      if (moves) sel[lane] = moved;
-      __syncthreads();
-    }
-    // every step of the overlap resolution sees the spans the previous one left: a serial walk over the neighbours
+      if (__any(moves)) {
+        Seg moved = seg_default();
+        if (moves) moved = sel[src];
+        __syncthreads();
+        if (moves) sel[lane] = moved;
+      }
 #ifndef CABL_NOOVERLAP
-    if (lane == 0) overlap_segments_core(a.variant, a.delta, sel, n);
+      // overlap_segments_core, trapezoid: every step sees the spans the previous one left -- a serial walk over the
+      // neighbours, on the keys in the lanes; a span the walk assigned gets its duration recomputed, as there
+      bool assigned = false;
+      for (int i = 0; i + 1 < n; i++) {
+        const int a_bt = __builtin_amdgcn_readlane(bt, i), b_et = __builtin_amdgcn_readlane(et, i + 1);
+        int a_et = __builtin_amdgcn_readlane(et, i), b_bt = __builtin_amdgcn_readlane(bt, i + 1);
+        bool ta = false, tb = false;
+        if (a_bt == b_bt && a_et == b_et) {
+          const int half = (a_et - a_bt) / 2;
+          a_et -= half; b_bt += half; ta = tb = true;
+        } else if (a_bt > b_bt && a_et <= b_et) {
+          const int half = (a_et - a_bt) / 2;
+          if (half > 1) { a_et -= half; ta = true; }
+          b_bt = a_et; tb = true;
+        }
+        if (lane == i && ta) { et = a_et; assigned = true; }
+        if (lane == i + 1 && tb) { bt = b_bt; assigned = true; }
+      }
+      if (lane < n && assigned) { sel[lane].beg_t = bt; sel[lane].end_t = et; sel[lane].t = (et - bt) * a.delta; }
 #endif
+    } else {
+#ifndef CABL_NOOVERLAP
+      if (lane == 0) overlap_segments_core(a.variant, a.delta, sel, n);   // cuboid: every pair of twins, serial
+#endif
+    }
     S = n;
 #endif
   }

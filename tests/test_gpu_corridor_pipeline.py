@@ -190,6 +190,61 @@ def test_device_corridors_on_degenerate_and_non_finite_inputs(variant):
     assert retried_ok >= 1                            # ... and the retry pass produced some of them
 
 
+@pytest.mark.parametrize("N,num_obs,runs", [(310, 5, None), (201, 2, (4, 8)), (512, 2, (40, 80))])
+def test_device_corridors_on_long_horizons_and_many_obstacles(N, num_obs, runs):
+    """The shapes the wave-wide extraction hands to the serial statement -- a slope table that does not fit LDS
+    (310 knots x 5 obstacles), more than 64 base segments per candidate (two obstacles whose slopes change every 4-8
+    knots) -- and the largest horizon the device stage takes.  Same segments as the oracle, field by field."""
+    import torch
+    from spectral_amd import synth
+    from spectral_amd.knots import KnotBatch
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    B = 12
+    rng = np.random.default_rng(N + num_obs)
+    tt = np.arange(N) * 0.1
+    s_bounds = np.zeros((B, num_obs, N, 2)); l_bounds = np.zeros((B, num_obs, N, 2))
+    for b in range(B):
+        for o in range(num_obs):
+            if runs:           # slope changes every runs[0]..runs[1] knots
+                steps = np.repeat(rng.choice([0.0, 0.3, 0.6, 0.9], size=N), rng.integers(runs[0], runs[1] + 1, size=N))[:N]
+                lo = np.round(2.0 * o + np.cumsum(steps), 2)
+            else:              # one ramp that starts late
+                lo = np.round(np.maximum(0.0, 3.0 * (tt - rng.uniform(2, 10))), 2)
+            s_bounds[b, o, :, 0] = lo
+            s_bounds[b, o, :, 1] = lo + np.round(rng.uniform(20, 60), 2)
+            l_bounds[b, o, :, 0] = -3.0 + o                    # one-metre lanes: the reference is inside one at a time
+            l_bounds[b, o, :, 1] = l_bounds[b, o, :, 0] + 1.0
+    s_ref = np.tile(8.0 + 4.0 * tt, (B, 1)) + rng.uniform(0, 3, (B, 1))
+    l_ref = np.tile(np.where(tt < tt[-1] / 2, -1.5, -2.5), (B, 1))
+    kb = KnotBatch(B, N, num_obs, 0.1, s_bounds, l_bounds, np.tile(np.array([0.0, 20.0]), (B, N, 1)),
+                   np.tile(np.array([-3.0, 3.0]), (B, N, 1)), s_ref, l_ref,
+                   np.tile(np.array([0.0, 6.0, 0.0, -1.5, 0.0, 0.0]), (B, 1)), dict(synth.C1_HEADER))
+    usable = 0
+    for variant in (0, 1):
+        rec = solver.corridor_batch(kb, variant, seg_stride=64)
+        torch.cuda.synchronize()
+        seg = rec["seg"].cpu().numpy(); cnt = rec["seg_count"].cpu().numpy()
+        for b in range(B):
+            n, cubes = oracle_pipeline(kb, b, variant)
+            want = n if n > 0 else 0
+            if n > 64 or any(not (c.t > 0) for c in cubes):
+                want = -1
+            per_obstacle = [len(O.corridor_generation(variant, N, 0.1, kb.s_bounds[b, o], kb.l_bounds[b, o]))
+                            for o in range(num_obs)]
+            if max(per_obstacle) > 160 // num_obs:             # beyond the retry pass's lists: reported, not guessed
+                assert cnt[b] == -1, (variant, b, cnt[b], per_obstacle)
+                continue
+            assert cnt[b] == want, (variant, b, cnt[b], n, per_obstacle)
+            if want > 0:
+                usable += 1
+                for k, c in enumerate(cubes):
+                    for f, attr in FIELDS:
+                        got, exp = seg[f, b, k], getattr(c, attr)
+                        assert got == exp, (variant, b, k, attr, got, exp)
+    assert usable >= B // 2
+
+
 @pytest.mark.parametrize("name,variant", [("c_road_s1_3", 0), ("c6", 0), ("c1", 1)])
 def test_hard_jittered_candidates_agree_with_oracle_on_solvability_and_optimum(name, variant):
     """1 024 jittered copies of a bundled scenario, many infeasible or close to it: the device pipeline and the
