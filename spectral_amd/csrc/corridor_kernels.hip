@@ -51,11 +51,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 
 __device__ __forceinline__ double readlane_f64(double v, int l) {  // l: the same in every lane
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(v, d);
-    if (lane >= d) v += t;
-  }
+// Inclusive prefix sum over the 64 lanes on the DPP network (no LDS round trips): shifts by 1, 2, 4, 8 inside each
+// row of 16 (lanes without a source add 0), then the last lane of row 0 / 2 is added to row 1 / 3 (row_bcast:15) and
+// the last lane of row 1 to rows 2 and 3 (row_bcast:31).
+__device__ __forceinline__ int wave_inclusive_scan(int v, int /*lane*/) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
   return v;
 }
 
@@ -63,8 +68,9 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
 // statement, gives the same segments bit for bit and is what the host driver and the fallback below run):
 //  1. breaks: a segment ends at the first knot whose slopes differ from the OPEN segment's by more than 0.2 -- a
 //     recurrence over the knots, but the open segment's slopes only change at a break.  64 knots are compared at a
-//     time against the current pair; ballot + find-first gives the next break, the pair is re-read there and the
-//     window restarts behind it: N/64 + (number of breaks) rounds per obstacle instead of N steps on one lane.
+//     time against the current pair; ballot + find-first gives the next break, the pair becomes that knot's successor
+//     (readlane) and the lanes behind it are compared again: N/64 LDS reads + one ballot per break and obstacle
+//     instead of N steps on one lane.
 //  2. one lane per (obstacle, base segment): bounds at its first knot (independent loads: one memory round trip for
 //     all of them instead of one per segment), duration, number of 1-second pieces; a scan places the pieces.
 //  3. every lane writes the pieces of its base segment (the bias recurrence `bias + 1.0 * skew` step by step).
@@ -79,28 +85,29 @@ __device__ __forceinline__ bool find_breaks_wave(const CorridorArgs &a, int lane
   for (int o = 0; o < O; o++) {
     const double2 *sk = sk2 + (size_t)o * N;
     double2 cur = sk[1];
-    int nb = 1, start = 2;
+    int nb = 1;
     if (lane == 0) brk[o * cap_o] = 0;
-    while (start < N - 1) {
+    for (int start = 2; start < N - 1 && nb > 0; start += 64) {
+      // the window's slopes and their successors are read once; the breaks inside it are found in registers
       const int i = start + lane;
-      bool differs = false;
-      if (i < N - 1) {
-        const double2 v = sk[i];
-        differs = fabs(v.x - cur.x) > threshold || fabs(v.y - cur.y) > threshold;
+      const bool in = i < N - 1;
+      const double2 v = sk[in ? i : N - 2], nx = sk[in ? i + 1 : N - 1];
+      unsigned long long ahead = ~0ull;          // lanes behind the last break
+      for (;;) {
+        const unsigned long long m = __ballot(in && (fabs(v.x - cur.x) > threshold || fabs(v.y - cur.y) > threshold)) & ahead;
+        if (m == 0) break;
+        const int l = __ffsll((long long)m) - 1;
+        if (nb + 1 > cap_o) { nb = -1; break; }
+        if (lane == 0) brk[o * cap_o + nb] = start + l;
+        nb++;
+        cur = make_double2(readlane_f64(nx.x, l), readlane_f64(nx.y, l));   // the slopes at knot start + l + 1
+        ahead = l == 63 ? 0ull : ~0ull << (l + 1);
       }
-      const unsigned long long m = __ballot(differs);
-      if (m == 0) { start += 64; continue; }
-      const int j = start + __ffsll((long long)m) - 1;
-      if (nb + 1 > cap_o) { nb = -1; break; }
-      if (lane == 0) brk[o * cap_o + nb] = j;
-      nb++;
-      cur = sk[j + 1];   // j <= N - 2
-      start = j + 1;
     }
     if (lane == o) my_nb = nb;
   }
   __syncthreads();
-  return __shfl(wave_inclusive_scan(my_nb > 0 ? my_nb : 0, lane), 63) <= 64;
+  return __builtin_amdgcn_readlane(wave_inclusive_scan(my_nb > 0 ? my_nb : 0, lane), 63) <= 64;
 }
 __device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int lane, const double *gs, const double *gl,
                                                     const double *slopes, Seg *all, int cap_o, int *ocount, const int *brk,
@@ -112,7 +119,7 @@ __device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int l
   if (lane < O) ocount[lane] = my_nb < 0 ? -1 : 0;
   int mo = -1, mk = 0, mn = 0;
   for (int o = 0; o < O; o++) {
-    const int n = __shfl(nbp, o), q0 = __shfl(incl, o) - n;
+    const int n = __builtin_amdgcn_readlane(nbp, o), q0 = __builtin_amdgcn_readlane(incl, o) - n;
     if (lane >= q0 && lane < q0 + n) { mo = o; mk = lane - q0; mn = n; }
   }
   Seg s = seg_default();
@@ -313,7 +320,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
       const int r = nsel + __popcll(m & ((1ull << lane) - 1ull));
       if (take && r < cap_sel) pick[r] = slot_of[q];
       nsel += __popcll(m);
-      carry = (carry + __shfl(upto, 63)) % 3;
+      carry = (carry + __builtin_amdgcn_readlane(upto, 63)) % 3;
     }
     if (nsel > cap_sel) { nsel = cap_sel; overflow = true; }
   }
@@ -350,12 +357,12 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     const unsigned long long kept = __ballot(keep);
     const int pos = __popcll(kept & ((1ull << lane) - 1ull)), n = __popcll(kept);
     int rank = pos;
-    if (a.variant == 0) {
-      if (keep) key[pos] = mine.beg_t;
-      __syncthreads();
-      if (keep) {
-        rank = 0;
-        for (int i = 0; i < n; i++) rank += (key[i] < mine.beg_t || (key[i] == mine.beg_t && i < pos)) ? 1 : 0;
+    if (a.variant == 0) {  // stable rank by beg_t among the kept ones
+      rank = 0;
+      for (int i = 0; i < nsel; i++) {
+        if (!((kept >> i) & 1ull)) continue;
+        const int bt_i = __builtin_amdgcn_readlane(mine.beg_t, i);
+        rank += (bt_i < mine.beg_t || (bt_i == mine.beg_t && i < lane)) ? 1 : 0;
       }
     }
     __syncthreads();                                       // every lane has its copy: all[] may be overwritten
@@ -368,13 +375,15 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
       if (lane < n) { bl = sel[lane].beg_l; bt = sel[lane].beg_t; et = sel[lane].end_t; }
       // reorder_segments_core: the search for "the first k > j that continues segment i" is a ballot; a hit swaps
       // the keys (and the source slots) of lanes j and k
-      for (int i = 0; i + 1 < n; i++) {
+      // (positions without a continuation further on -- the usual case -- cost one ballot: the j loop of the serial
+      //  statement does nothing once no lane beyond j matches)
+      for (int i = 0; i + 2 < n; i++) {
         const double bl_i = readlane_f64(bl, i);
         const int et_i = __builtin_amdgcn_readlane(et, i);
-        for (int j = i + 1; j < n; j++) {
-          if (j == i + 1 && bl_i == readlane_f64(bl, j)) break;
+        if (bl_i == readlane_f64(bl, i + 1)) continue;       // its `break` at j = i + 1
+        for (int j = i + 1; j + 1 < n; j++) {
           const unsigned long long m = __ballot(lane > j && lane < n && bl == bl_i && bt == et_i);
-          if (m == 0) continue;
+          if (m == 0) break;
           const int k = __ffsll((long long)m) - 1;
           const int other = lane == j ? k : j;       // only lanes j and k take the exchanged values
           const double bl_x = __shfl(bl, other);
