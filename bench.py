@@ -118,8 +118,9 @@ def workload_label(name, B, S, variant, world, scaling):
             "change tiled to %d one-second segments; onset -1/0/+1 s, speed +-1 m/s, v0 ~ U(5,9) per candidate)" % S
             if name == "scenario1" else "generic corridors (smooth random speed profile, random margins and ramps, one lane change; "
             "feasible by construction)")
+    config = 4 if variant == 1 else (2 if (B, S) == (4096, 10) else 3)
     return "BASELINE.json config %d: batch=%d %s%s, %d segments, order 5, %s constraints, arg-min over all candidates" % (
-        3 if variant == 0 else 4, B, what, " per GPU" if scaling == "weak" else " in total over %d GPU(s)" % world, S,
+        config, B, what, " per GPU" if scaling == "weak" else " in total over %d GPU(s)" % world, S,
         "trapezoid-prism" if variant == 0 else "cuboid")
 
 
