@@ -62,7 +62,12 @@ def main():
     for name in ("mpc_warm", "mpc_cold", "mpc_warm_minfirst05", "mpc_cold_minfirst05", "pipeline", "pipeline_scenario1", "pipeline_prisms",
                  "bench_config2", "bench_config4", "bench_generic", "bench_2rank_gloo_strong"):
         if os.path.exists(os.path.join(src, name + ".json")):
-            shutil.copy(os.path.join(src, name + ".json"), os.path.join(dst, f"{tag}_{name}.json"))
+            # the tools print ONE JSON line; libraries may print before it (gloo announces its ranks on stdout)
+            lines = [l for l in open(os.path.join(src, name + ".json")).read().splitlines() if l.lstrip().startswith("{")]
+            if not lines:
+                sys.exit("no JSON line in %s/%s.json" % (src, name))
+            with open(os.path.join(dst, f"{tag}_{name}.json"), "w") as fh:
+                fh.write(lines[-1] + "\n")
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
     wl = dict(bench["config"]); wl["workload"] = wl.get("generator", "generic")      # the key bench.py matches on
     wl["label"] = bench["config"]["workload"]
