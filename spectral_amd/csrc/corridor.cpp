@@ -116,7 +116,7 @@ bool select_segments(int variant, double delta, const std::vector<std::vector<Se
       const Seg c = to_seg(c0);
       int hits = 0;
       for (size_t i = 0; i < s_ref.size(); i++) hits += knot_inside(c, s_ref[i], l_ref[i], double(i), delta) ? 1 : 0;
-      if (selection_pushes(hits, carry) >= 1) { Seg t = c; t.count = 3; sel.push_back(t); }
+      for (int copies = selection_copies(selection_pushes(hits, carry), c); copies > 0; copies--) { Seg t = c; t.count = 3; sel.push_back(t); }
     }
   if (sel.empty()) return false;
   const int n = order_segments_core(variant, delta, sel.data(), (int)sel.size());

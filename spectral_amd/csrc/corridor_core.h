@@ -18,6 +18,13 @@
 
 #include <math.h>
 
+// Expression by expression means operation by operation: a fused multiply-add rounds once where the reference rounds
+// twice, and the signs of the edge functions below decide membership on degenerate quads (collapsed or crossing
+// bounds).  hipcc contracts device code by default; from here to the end of the translation unit it does not.
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
 namespace btrapz {
 
 // One corridor segment == the reference's Cube (include/btrapz/cube_type.h:2-24).  POD: usable in LDS.
@@ -172,6 +179,12 @@ BTRAPZ_HD int selection_pushes(int hits_inside, int &carry) {
   const int total = carry + hits_inside;
   carry = total % 3;
   return total / 3;
+}
+
+// How many of those copies survive the reference's de-dup pass: one -- unless the segment does not compare equal to
+// itself (a NaN among the fields same_segment compares: garbage input, but the count is the reference's), then all.
+BTRAPZ_HD int selection_copies(int pushes, const Seg &c) {
+  return pushes < 1 ? 0 : (pushes >= 2 && !same_segment(c, c) ? pushes : 1);
 }
 
 // De-dup (keep first), then ordering and time-overlap resolution: solve_3d.cc:617-703 (trapezoid),

@@ -296,30 +296,31 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   if (!overflow) {
     // One lane per segment, its fields in registers.  A knot before beg_t or after end_t cannot be inside: with
     // upp_bias > down_bias and the upper end above the lower end, the edge functions d0 and d2 of knot_inside
-    // (whose first products are exact zeros for a finite reference) have opposite signs there -- so the lane only
-    // visits its own knots.  A segment that fails those conditions, or a reference that is not finite, takes all.
+    // (whose first products are exact zeros for a finite reference and finite bounds: an infinite bias or slope makes
+    // them NaN, hence the finite gaps) have opposite signs there -- so the lane only visits its own knots.  A segment
+    // that fails those conditions, or a reference that is not finite, takes all.
     // The reference's running hit counter (selection_pushes): its value when it reaches a segment is the number of
     // hits before it, mod 3 -- a scan over the lanes instead of a walk over the segments.
     int carry = 0;
     for (int q0 = 0; q0 < total; q0 += 64) {
       const int q = q0 + lane;
       int h = 0;
+      Seg twin = seg_default();   // the fields same_segment compares
       if (q < total) {
         const Seg c = all[slot_of[q]];
-        const bool own_range = refs_finite && (c.upp_bias - c.down_bias) > 0.0 &&
-                               (c.down_skew * a.delta + c.down_bias - c.upp_skew * a.delta - c.upp_bias) < 0.0 &&
-                               c.beg_t <= c.end_t;
+        twin = c;
+        const double gap0 = c.upp_bias - c.down_bias, gap1 = c.down_skew * a.delta + c.down_bias - c.upp_skew * a.delta - c.upp_bias;
+        const bool own_range = refs_finite && gap0 > 0.0 && gap0 < 1e300 && gap1 < 0.0 && gap1 > -1e300 && c.beg_t <= c.end_t;
         const int i_lo = own_range ? (c.beg_t > 0 ? c.beg_t : 0) : 0;
         const int i_hi = own_range ? (c.end_t < N - 1 ? c.end_t : N - 1) : N - 1;
         for (int i = i_lo; i <= i_hi; i++) h += knot_inside(c, sref[i], lref[i], (double)i, a.delta) ? 1 : 0;
       }
       const int upto = wave_inclusive_scan(h, lane);
       int counter = (carry + upto - h) % 3;
-      const bool take = q < total && selection_pushes(h, counter) >= 1;
-      const unsigned long long m = __ballot(take);
-      const int r = nsel + __popcll(m & ((1ull << lane) - 1ull));
-      if (take && r < cap_sel) pick[r] = slot_of[q];
-      nsel += __popcll(m);
+      const int copies = q < total ? selection_copies(selection_pushes(h, counter), twin) : 0;   // 1, but for NaN segments
+      const int placed = wave_inclusive_scan(copies, lane);
+      for (int j = 0, r = nsel + placed - copies; j < copies && r < cap_sel; j++, r++) pick[r] = slot_of[q];
+      nsel += __builtin_amdgcn_readlane(placed, 63);
       carry = (carry + __builtin_amdgcn_readlane(upto, 63)) % 3;
     }
     if (nsel > cap_sel) { nsel = cap_sel; overflow = true; }

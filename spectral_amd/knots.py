@@ -54,6 +54,23 @@ def parse_corridor_file(path):
     return KnotBatch(1, N, O, delta, sb[None], lb[None], dsb[None], dlb[None], s_ref[None], l_ref[None], init[None], hdr)
 
 
+def write_corridor_file(path, kb, b=0):
+    """Candidate b of a KnotBatch as the text file find_traj reads (the inverse of parse_corridor_file; numbers at
+    full precision, nan / inf as strtod reads them)."""
+    h = kb.header
+    r = lambda v: repr(float(v))
+    pairs = lambda a: " ".join("%s %s" % (r(x), r(y)) for x, y in a)
+    with open(path, "w") as f:
+        f.write("%d %s\n" % (kb.N, r(kb.delta)))
+        f.write(" ".join(r(v) for v in kb.init[b]) + "\n%d\n" % kb.num_obs)
+        f.write("%s %s\n" % (r(h["ds_ref"]), r(h["dl_ref"])))
+        f.write(" ".join("%s %s" % (r(h[k][0]), r(h[k][1])) for k in ("dds", "ddds", "ddl", "dddl")) + "\n")
+        for o in range(kb.num_obs):
+            f.write(pairs(kb.s_bounds[b, o]) + "\n" + pairs(kb.l_bounds[b, o]) + "\n")
+        f.write(pairs(kb.ds_bounds[b]) + "\n" + pairs(kb.dl_bounds[b]) + "\n")
+        f.write(" ".join(r(v) for v in kb.s_ref[b]) + "\n" + " ".join(r(v) for v in kb.l_ref[b]) + "\n")
+
+
 def jittered(kb, B, seed=0, s_shift=0.4, l_shift=0.05):
     """B candidates around a parsed file: per-candidate shifts of the corridor bounds and of the
     reference (obstacle position / lane offset jitter).  Shifts are applied to whole obstacles so the

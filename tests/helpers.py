@@ -56,3 +56,58 @@ def oracle_qp_from_batch(batch, sh, b):
     p = O.Params(sh.w_s[2], sh.w_s[3], sh.w_l[2], sh.w_l[3], sh.w_s[0], sh.w_s[1], sh.w_l[0], sh.w_l[1],
                  sh.weight_end_s, sh.weight_end_l, 0)
     return O.AssembledQp(sh.variant, cubes, p, src)
+
+
+def fuzz_knot_batch(seed, B=16):
+    """A random corridor-stage input: horizon and obstacle count from the edges of the device stage's range, s bounds
+    with slope changes in runs of random length (some below, some above the 0.2 threshold), now and then an upper bound
+    with breaks of its own, moving l bounds, collapsed bounds, nan / inf entries, a nan reference knot.  The shapes that
+    found three disagreements between the device stage and the reference's arithmetic (twins with a NaN field survive
+    the reference's de-dup; fused multiply-adds flip the sign of a degenerate edge function; an infinite slope voids
+    the device's 'own knots only' shortcut)."""
+    from spectral_amd import synth
+    from spectral_amd.knots import KnotBatch
+    rng = np.random.default_rng(seed)
+    N = int(rng.choice([3, 4, 5, 11, 21, 64, 65, 66, 71, 101, 128, 129, 130, 201, 257, 300, 512]))
+    num_obs = int(rng.choice([1, 2, 3, 5, 8, 13, 64])) if N <= 130 else int(rng.choice([1, 2, 3, 5]))
+    tt = np.arange(N) * 0.1
+    sb = np.zeros((B, num_obs, N, 2)); lb = np.zeros((B, num_obs, N, 2))
+    for b in range(B):
+        for o in range(num_obs):
+            lo_run, hi_run = rng.choice([(1, 3), (3, 12), (10, 40), (40, 200)])
+            steps = np.repeat(rng.choice([0.0, 0.0, 0.01, 0.019, 0.021, 0.3, -0.2, 0.6], size=N), rng.integers(lo_run, hi_run + 1, size=N))[:N]
+            lo = np.round(rng.uniform(0, 10) + np.cumsum(steps), 3)
+            width = np.round(rng.uniform(1, 60), 2)
+            if rng.random() < 0.3:
+                steps2 = np.repeat(rng.choice([0.0, 0.05, 0.3, -0.1], size=N), rng.integers(lo_run, hi_run + 1, size=N))[:N]
+                hi = lo + width + np.round(np.cumsum(steps2), 3)
+            else:
+                hi = lo + width
+            sb[b, o, :, 0] = lo; sb[b, o, :, 1] = hi
+            l0 = np.round(rng.uniform(-4, 2), 1)
+            lb[b, o, :, 0] = l0; lb[b, o, :, 1] = l0 + np.round(rng.uniform(0.5, 4), 1)
+            if rng.random() < 0.2:
+                lb[b, o, :, 0] += np.round(0.05 * np.arange(N) * rng.choice([0, 1, -1]), 2)
+            if rng.random() < 0.05:
+                i0 = int(rng.integers(0, N)); sb[b, o, i0:i0 + 5, 1] = sb[b, o, i0:i0 + 5, 0]
+            if rng.random() < 0.03:
+                sb[b, o, int(rng.integers(0, N)), int(rng.integers(0, 2))] = rng.choice([np.nan, np.inf, -np.inf])
+    s_ref = np.tile(rng.uniform(2, 12) + rng.uniform(0, 6) * tt, (B, 1)) + rng.uniform(-2, 2, (B, 1))
+    l_ref = rng.uniform(-3, 3, (B, 1)) + np.where(tt < tt[N // 2], 0.0, rng.uniform(-2, 2))[None, :]
+    if rng.random() < 0.1:
+        s_ref[rng.integers(0, B), rng.integers(0, N)] = np.nan
+    return KnotBatch(B, N, num_obs, 0.1, sb, lb, np.tile(np.array([0.0, 20.0]), (B, N, 1)) + rng.uniform(0, 1, (B, N, 2)),
+                     np.tile(np.array([-3.0, 3.0]), (B, N, 1)), s_ref, l_ref, np.tile(np.array([0.0, 6.0, 0.0, 0.0, 0.0, 0.0]), (B, 1)),
+                     dict(synth.C1_HEADER))
+
+
+def oracle_corridor(kb, b, variant, per_obstacle_cap=None):
+    """The oracle's corridor stage on candidate b: (n, cubes), or (None, None) when an obstacle's list exceeds
+    per_obstacle_cap (the device reports such a candidate as unusable)."""
+    try:
+        lists = [O.corridor_generation(variant, kb.N, kb.delta, kb.s_bounds[b, o], kb.l_bounds[b, o]) for o in range(kb.num_obs)]
+    except RuntimeError:
+        return None, None
+    if per_obstacle_cap is not None and max(len(l) for l in lists) > per_obstacle_cap:
+        return None, None
+    return O.collision_check(variant, kb.N, kb.delta, lists, kb.s_ref[b], kb.l_ref[b])

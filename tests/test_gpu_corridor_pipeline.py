@@ -245,6 +245,56 @@ def test_device_corridors_on_long_horizons_and_many_obstacles(N, num_obs, runs):
     assert usable >= B // 2
 
 
+@pytest.mark.parametrize("seed0", [0, 1, 2])
+def test_device_corridors_equal_oracle_on_random_inputs(seed0):
+    """200 random inputs per seed (tests/helpers.py fuzz_knot_batch: horizons from 3 to 512 knots, 1 to 64 obstacles,
+    nan / inf / collapsed bounds), 16 candidates each, both variants: count and every field of the batch record as
+    the oracle computes them -- including the ds range and the reference line the kernel derives on the way."""
+    import torch
+    from helpers import fuzz_knot_batch, oracle_corridor
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    checked = usable = 0
+    for rd in range(200):
+        kb = fuzz_knot_batch(seed0 * 1000 + rd)
+        N = kb.N
+        for variant in (0, 1):
+            rec = solver.corridor_batch(kb, variant, seg_stride=64)
+            torch.cuda.synchronize()
+            seg = rec["seg"].cpu().numpy(); cnt = rec["seg_count"].cpu().numpy()
+            for b in range(kb.B):
+                n, cubes = oracle_corridor(kb, b, variant, per_obstacle_cap=160 // kb.num_obs)
+                checked += 1
+                if n is None:                                   # beyond the retry pass's lists: reported, not guessed
+                    assert cnt[b] == -1, (seed0, rd, variant, b, cnt[b])
+                    continue
+                want = n if n > 0 else 0
+                if n > 64 or any(not (c.t > 0) for c in cubes):
+                    want = -1
+                if cnt[b] == -1 and n > 32:
+                    continue                                    # more than 64 selected before the de-dup: also reported
+                assert cnt[b] == want, (seed0, rd, variant, b, cnt[b], want)
+                if want <= 0:
+                    continue
+                usable += 1
+                for k, c in enumerate(cubes):
+                    for f, attr in FIELDS:
+                        got, exp = seg[f, b, k], getattr(c, attr)
+                        assert got == exp or (np.isnan(got) and np.isnan(exp)), (seed0, rd, variant, b, k, attr, got, exp)
+                    lo, hi = 0.0, 1000.0                        # solve_3d.cc:835-841
+                    for i in range(c.beg_t, c.end_t + 1):
+                        ii = min(max(i, 0), N - 1)
+                        lo = np.fmax(kb.ds_bounds[b, ii, 0], lo); hi = np.fmin(kb.ds_bounds[b, ii, 1], hi)
+                    i0, i1 = min(10 * k, N - 1), min(10 * k + 1, N - 1)   # :1161-1165, clamped
+                    derived = {L.F_DS_LO: lo, L.F_DS_HI: hi, L.F_X_SKEW: (kb.s_ref[b, i1] - kb.s_ref[b, i0]) / kb.delta,
+                               L.F_X_BIAS: kb.s_ref[b, i0], L.F_Y_SKEW: (kb.l_ref[b, i1] - kb.l_ref[b, i0]) / kb.delta,
+                               L.F_Y_BIAS: kb.l_ref[b, i0]}
+                    for f, exp in derived.items():
+                        got = seg[f, b, k]
+                        assert got == exp or (np.isnan(got) and np.isnan(exp)), (seed0, rd, variant, b, k, f, got, exp)
+    assert checked == 200 * 2 * 16 and usable >= 1500
+
+
 @pytest.mark.parametrize("name,variant", [("c_road_s1_3", 0), ("c6", 0), ("c1", 1)])
 def test_hard_jittered_candidates_agree_with_oracle_on_solvability_and_optimum(name, variant):
     """1 024 jittered copies of a bundled scenario, many infeasible or close to it: the device pipeline and the
