@@ -1396,11 +1396,18 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
     }
     mu = mi ? mu / (2.0 * mi) : 0;
     double score = fmax(fmax(vnorm_inf(rd, n) / (1 + qn), rpn / (1 + bn)), mu);
+    {  /* fmax() skips NaN: an iterate or a residual that is not finite must not pass for a small score */
+      int finite = isfinite(mu) && isfinite(bn) && isfinite(qn);
+      for (int j = 0; j < n && finite; j++) finite = isfinite(rd[j]) && isfinite(x[j]);
+      for (int i = 0; i < m && finite; i++) finite = isfinite(Ax[i]);
+      for (int r = 0; r < mi && finite; r++) finite = isfinite(rpl[r]) && isfinite(rpu[r]);
+      if (!finite) score = 1e300;
+    }
     if (iter == 0 || score < best_score) {
       best_score = score; best_it = iter; memcpy(bx, x, sizeof(double) * n);
       for (int i = 0; i < m; i++) by[i] = iseq[i] ? nu[rowpos[i]] : (lu_[rowpos[i]] - ll[rowpos[i]]);
     }
-    if (score < eps || (best_score < 1e-5 && iter - best_it >= 3)) break;
+    if (score < eps || (best_score < 1e-5 && iter - best_it >= 3) || !(score < 1e299)) break;
     /* K = [P + G'WG, E'; E, 0] */
     memset(K, 0, sizeof(double) * (size_t)Nk * Nk);
     for (int i = 0; i < n; i++) memcpy(K + (size_t)i * Nk, Pd + (size_t)i * n, sizeof(double) * n);

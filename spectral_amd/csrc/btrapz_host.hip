@@ -31,6 +31,13 @@ using namespace btrapz;
 // 21.5 iterations on average; (10, 6) 0 lost, 19.5; (8, 5) 3 lost; (8, 4) 18 lost; (6, 3) 87 lost.
 #define BTRAPZ_STALL_START 10
 #define BTRAPZ_STALL_LENGTH 6
+// "Without progress" = no better score AND no residual (the score without its complementarity part) below
+// BTRAPZ_STALL_FACTOR times the smallest one so far.  The score alone lost solvable candidates on corridors with runs
+// of short segments, where mu climbs for ten iterations while the residuals fall 40-fold (found by a fuzz of find_traj
+// against the oracle): 49 of the 48 821 solvable ones of the cuboid bench batch, 1 of 16 384 jittered c6.txt.  Lost
+// with factor 0.3 / 0.5 / 0.7..1.0: 17 / 5 / 0; infeasible candidates of the jittered c_road_s1_3.txt end after
+// 19.4 / 20.1 / 22.2-24.1 iterations (18.4 with the score alone).
+#define BTRAPZ_STALL_FACTOR 0.8f
 // Rescue pass (btrapz_options.elastic): penalty parameter of the relaxed rows and the violation still accepted.
 // delta: the relaxed solution is within delta * |multipliers| (1e2..1e4 here) of the least-violation limit; 1e-8 keeps
 // that below 1e-4 and the interior-point method still converges in 25-40 iterations (1e-10: 40+, scores near 1e-7).
@@ -148,6 +155,7 @@ static void fill_parameters(KernelArgs &a, const btrapz_shared *sh, const btrapz
   a.tau = (opt && opt->step_fraction > 0 && opt->step_fraction < 1) ? opt->step_fraction : BTRAPZ_DEFAULT_STEP_FRACTION;
   a.tau_iters = BTRAPZ_AGGRESSIVE_ITERATIONS;
   a.stall_start = BTRAPZ_STALL_START; a.stall_len = BTRAPZ_STALL_LENGTH;
+  a.stall_factor = BTRAPZ_STALL_FACTOR;
   a.tau_thr = (opt && opt->step_threshold > 0) ? opt->step_threshold : BTRAPZ_DEFAULT_STEP_THRESHOLD;
   a.x0 = warm ? warm->x0 : nullptr; a.lam0 = warm ? warm->lam0 : nullptr; a.lam_out = warm ? warm->lam_out : nullptr;
   a.mu0 = (warm && warm->mu0 > 0) ? warm->mu0 : 1e-4;

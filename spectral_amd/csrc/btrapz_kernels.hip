@@ -297,6 +297,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   int it0 = 0;                                   // iteration at which the current start was made
   double best_score = 1e300, Xb[3] = {0.0, 0.0, 0.0};
   int best_it = 0, iters = 0;
+  float best_res = 3e38f;          // smallest residual part of the score so far and when (the stall test)
+  int res_it = 0;
   bool done = true;
   // The group's own iteration count.  (Warm-start instantiations: when one group of the wavefront restarts cold the
   // others lose that pass of the loop; queue: the groups of a wavefront are at different iterations.  A candidate's
@@ -372,9 +374,11 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       const double lb = rec.lb, ls = rec.ls, ub = rec.ub, us = rec.us;
       plo0 = lb; dplo = ls * 0.2 * t; phi0 = ub; dphi = us * 0.2 * t;
       if (variant == BTRAPZ_CUBOID) {
-        if (axis == 0) {  // cuboid_3d.cc:677-689: inscribed interval, clamped to [0,100]
-          const double lo = fmax(0.0, fmax(lb, lb + ls * t));
-          const double hi = fmin(100.0, fmin(ub, ub + us * t));
+        if (axis == 0) {  // cuboid_3d.cc:677-689: inscribed interval, clamped to [0,100].  Its max / min run over
+          // bias + skew * (i / 5) * t, i = 0..5, and skip a NaN term: with an infinite slope the i = 0 term is NaN
+          // (inf * 0), not the bias -- hence `skew * 0.0` spelled out; the terms between the ends add nothing
+          const double lo = fmax(0.0, fmax(ls * 0.0 + lb, lb + ls * t));
+          const double hi = fmin(100.0, fmin(us * 0.0 + ub, ub + us * t));
           plo0 = lo; phi0 = hi;
         } else {  // cuboid_3d.cc:826-827
           plo0 = rec.begl; phi0 = rec.endl;
@@ -503,7 +507,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     // register budget; kept live it costs the allocator nothing measurable (6.67 -> 6.32 ms).
     LOAD_P(Pk)
     best_score = 1e300; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2];
-    best_it = 0; iters = 0;
+    best_it = 0; iters = 0; best_res = 3e38f; res_it = 0;
     done = !valid || infeasible_bounds || no_solution;
   };
   auto write_back = [&]() {
@@ -658,19 +662,24 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     // KKT score: dual residual relative to (1+|q|) with a round-off floor, primal residual
     // relative to the bound scale, complementarity absolute.
     const double rd_eff = fmax(rr.b - 2e-13 * rr.d, 0.0);
-    const double score = fmax(fmax(rd_eff / (1.0 + qn), rr.c / (1.0 + bnorm)), mu);
+    const double res = fmax(rd_eff / (1.0 + qn), rr.c / (1.0 + bnorm));
+    const double score = fmax(res, mu);
     bool restart_now = false;
     if (!done) {
       iters = eit;
       if (score < best_score) { best_score = score; best_it = eit; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
+      if ((float)res < a.stall_factor * best_res) { best_res = (float)res; res_it = eit; }
 #ifndef ABL_FIXED
       // stop: converged; at the round-off floor (best < 1e-5, 3 iterations without progress); diverging or
-      // infeasible (stall_len iterations without progress after the first stall_start); not finite.  A warm-started group
+      // infeasible (stall_len iterations without progress after the first stall_start); not finite.  "Progress" is a
+      // smaller score OR residuals smaller by stall_factor: on a hard but solvable corridor (a run of 0.2-0.5 s segments)
+      // the complementarity part of the score climbs for ten iterations while the residuals fall by a factor of 40 -- the
+      // score alone called that a stall; an infeasible one leaves both where they are.  A warm-started group
       // that ends in the last two ways, or is still far from converged after 12 iterations (a useful guess
       // needs about 5, a cold start 8-14; below 1e-4 the method is in its fast final phase), or is still running
       // after 24, is restarted once from the cold start: a bad guess must neither turn a solvable candidate
       // into a failure nor cost more than a bounded number of iterations.
-      const bool stalled = (eit - it0 >= a.stall_start && eit - best_it >= a.stall_len) || !(score < 1e299);
+      const bool stalled = (eit - it0 >= a.stall_start && eit - best_it >= a.stall_len && eit - res_it >= a.stall_len) || !(score < 1e299);
       if (score < eps || (best_score < 1e-5 && eit - best_it >= 3)) done = true;
       else if (WARM && !restarted && (stalled || (eit - it0 >= 12 && best_score > 1e-4) || eit - it0 >= 24)) restart_now = true;
       else if (stalled) done = true;
@@ -684,7 +693,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // restarts as a whole (the score is group-uniform), so the DPP reads inside cold_start stay in the group.
       if (restart_now) {
         cold_start();
-        best_score = 1e300; best_it = eit + 1; it0 = eit + 1; restarted = true;
+        best_score = 1e300; best_it = eit + 1; it0 = eit + 1; restarted = true; best_res = 3e38f; res_it = eit + 1;
         Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2];
         ++eit;       // (the other groups did not take a step in this pass: their count stands)
       }
@@ -891,7 +900,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 #define ROW_STEP(gd, b) (ELASTIC ? ((gd) - edelta * (b)) * rcp(1.0 + edelta * (ll * isl + lu * isu)) : (gd))
 
     double dca[6], dX[3];
-    double sigma_mu;
+    double sigma_mu, second_order;   // second_order: -1, or 0 when the corrector leaves that term out (below)
     {
       // predictor.  rc = s*lambda  ->  tv = lambda_l (s_l + rp_l)/s_l - lambda_u (s_u - rp_u)/s_u
       backward_u(up, dX, dca);   // right-hand side from the Newton-matrix loop, forward sweep done in the factorisation loop
@@ -916,14 +925,22 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       const double mua = ((1.0 - ad) * rr.a + (ap - ad - ap * ad) * ra.a - ap * ad * ra.b) * inv_m;
       const double sr = mua / mu;
       sigma_mu = sr * sr * sr * mu;
+      // Mehrotra's second-order term ds_aff * dlambda_aff describes the affine step; where that step is blocked at
+      // less than a tenth of its length it describes nothing, and late in a solve the method can settle into a
+      // two-cycle with it (blocked predictor / long corrector step, mu going 5e-4 <-> 1.5e-3 while the residuals reach
+      // 1e-11): 2 of the 262 144 candidates of the four bench batches ended that way where the oracle finds x*.
+      // On such an iteration the corrector leaves the term out (a factor in the fused multiply-add that subtracts it):
+      // they converge in 11-16.  Early blocked steps (a cold start's first two or three) keep it, where it saves
+      // iterations on average.
+      second_order = (fmin(ap, ad) < 0.1 && eit - it0 >= 5) ? 0.0 : -1.0;
     }
     {
-      // corrector.  rc = s*lambda + ds_aff*dlambda_aff - sigma*mu , dlambda_aff = -lambda (1 + ds_aff/s)
+      // corrector.  rc = s*lambda + [ds_aff*dlambda_aff] - sigma*mu , dlambda_aff = -lambda (1 + ds_aff/s)
 #define ROW_CORR(r)                                                                               \
       const double ga = ROW_STEP(row_dot<r>(dca, t), (ll - lu) + (ll * isl) * rpl + (lu * isu) * rpu); \
       const double dsa = ga + rpl, dua = -ga - rpu;                                                 \
-      const double rcl = __builtin_fma(sl[SI(r)], ll, -sigma_mu) - (ll * dsa) * (1.0 + dsa * isl);      \
-      const double rcu = __builtin_fma(su[SI(r)], lu, -sigma_mu) - (lu * dua) * (1.0 + dua * isu);      \
+      const double rcl = __builtin_fma(second_order, (ll * dsa) * (1.0 + dsa * isl), __builtin_fma(sl[SI(r)], ll, -sigma_mu)); \
+      const double rcu = __builtin_fma(second_order, (lu * dua) * (1.0 + dua * isu), __builtin_fma(su[SI(r)], lu, -sigma_mu)); \
       const double el = rcl * isl, eu = rcu * isu, wl = ll * isl, wu = lu * isu;
       double h[6], dc[6];
           double el_[NR], eu_[NR];   // rc/s of the corrected complementarity targets, reused by the two loops below
