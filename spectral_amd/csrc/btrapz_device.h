@@ -45,6 +45,7 @@ struct KernelArgs {
   int tau_iters;            // iterations (since the start) during which tau may be used
   int stall_start, stall_len; // divergence test: after stall_start iterations, stall_len without a better score
   float stall_factor;         // ... and without residuals smaller by this factor
+  float diverge_factor;       // mu above this multiple of the best score: the iterate has left for good
   // warm start (btrapz_warm): all optional
   const double *x0;         // [B][2][seg_stride][3] joint states at the end of every segment
   const double *lam0;       // [2][36][B][seg_stride] multipliers of an earlier solve

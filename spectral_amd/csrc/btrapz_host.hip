@@ -38,6 +38,12 @@ using namespace btrapz;
 // with factor 0.3 / 0.5 / 0.7..1.0: 17 / 5 / 0; infeasible candidates of the jittered c_road_s1_3.txt end after
 // 19.4 / 20.1 / 22.2-24.1 iterations (18.4 with the score alone).
 #define BTRAPZ_STALL_FACTOR 0.8f
+// An infeasible solve does not just stall: a few iterations after its residuals stop falling mu explodes (1 -> 45 ->
+// 500 -> 1e5 -> ... on the jittered c_road_s1_3.txt).  mu above BTRAPZ_DIVERGE_FACTOR times the best score so far ends
+// the solve at once.  The largest climb seen on a candidate that then converged is 10x; with 1e4 / 1e3 / 1e2 / 30 no
+// solvable candidate of the sets above is lost and the infeasible ones of c_road_s1_3.txt end after 17.2 / 16.9 / 16.0 /
+// 15.5 iterations (22.7 without the test).
+#define BTRAPZ_DIVERGE_FACTOR 1e3f
 // Rescue pass (btrapz_options.elastic): penalty parameter of the relaxed rows and the violation still accepted.
 // delta: the relaxed solution is within delta * |multipliers| (1e2..1e4 here) of the least-violation limit; 1e-8 keeps
 // that below 1e-4 and the interior-point method still converges in 25-40 iterations (1e-10: 40+, scores near 1e-7).
@@ -156,6 +162,7 @@ static void fill_parameters(KernelArgs &a, const btrapz_shared *sh, const btrapz
   a.tau_iters = BTRAPZ_AGGRESSIVE_ITERATIONS;
   a.stall_start = BTRAPZ_STALL_START; a.stall_len = BTRAPZ_STALL_LENGTH;
   a.stall_factor = BTRAPZ_STALL_FACTOR;
+  a.diverge_factor = BTRAPZ_DIVERGE_FACTOR;
   a.tau_thr = (opt && opt->step_threshold > 0) ? opt->step_threshold : BTRAPZ_DEFAULT_STEP_THRESHOLD;
   a.x0 = warm ? warm->x0 : nullptr; a.lam0 = warm ? warm->lam0 : nullptr; a.lam_out = warm ? warm->lam_out : nullptr;
   a.mu0 = (warm && warm->mu0 > 0) ? warm->mu0 : 1e-4;

@@ -680,7 +680,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // needs about 5, a cold start 8-14; below 1e-4 the method is in its fast final phase), or is still running
       // after 24, is restarted once from the cold start: a bad guess must neither turn a solvable candidate
       // into a failure nor cost more than a bounded number of iterations.
-      const bool stalled = (eit - it0 >= a.stall_start && eit - best_it >= a.stall_len && eit - res_it >= a.stall_len) || !(score < 1e299);
+      const bool stalled = (eit - it0 >= a.stall_start && eit - best_it >= a.stall_len && eit - res_it >= a.stall_len) ||
+                           mu > (double)a.diverge_factor * best_score || !(score < 1e299);
       if (score < eps || (best_score < 1e-5 && eit - best_it >= 3)) done = true;
       else if (WARM && !restarted && (stalled || (eit - it0 >= 12 && best_score > 1e-4) || eit - it0 >= 24)) restart_now = true;
       else if (stalled) {
