@@ -342,6 +342,22 @@ def main():
                 t1 = time.perf_counter(); cst, _, ctl = native.find_traj_mem(a.variant, prm, kb1); lat_f.append(time.perf_counter() - t1)
             out["p50_find_traj_mem_ms"] = float(np.percentile(np.array(lat_f[5:]) * 1e3, 50))
             out["find_traj_mem_segments"] = None if ctl is None else int(len(ctl) // 12)
+            # ... and the replanning loop it sits in: consecutive calls on nearly the same scene, each starting from
+            # the state the previous call of this thread left on the device (BTRAPZ_WARM=1; opt-in
+            # because the last digits of a result then depend on the call history)
+            from spectral_amd import knots as _knots
+            near = _knots.jittered(kb1, 4, seed=5, s_shift=0.0, l_shift=0.0)        # four copies of the scene ...
+            rs = np.random.default_rng(5)                                          # ... whose reference lines differ by centimetres
+            near.s_ref += rs.uniform(-0.02, 0.02, (4, 1)) * np.linspace(0, 1, near.N)[None, :]
+            near.l_ref += rs.uniform(-0.01, 0.01, (4, 1))
+            os.environ["BTRAPZ_WARM"] = "1"
+            lat_w, ok_w = [], 0
+            for i in range(max(30, a.latency_reps // 2)):
+                t1 = time.perf_counter(); cst, _, _ = native.find_traj_mem(a.variant, prm, near, i % 4); lat_w.append(time.perf_counter() - t1)
+                ok_w += cst < 1e10
+            del os.environ["BTRAPZ_WARM"]
+            out["p50_find_traj_mem_replanning_ms"] = float(np.percentile(np.array(lat_w[5:]) * 1e3, 50))
+            out["find_traj_mem_replanning_solved"] = ok_w / len(lat_w)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, shared, a.cpu_seconds)
         else:
