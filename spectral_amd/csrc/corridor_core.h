@@ -183,9 +183,10 @@ BTRAPZ_HD int selection_pushes(int hits_inside, int &carry) {
 
 // How many of those copies survive the reference's de-dup pass: one -- unless the segment does not compare equal to
 // itself (a NaN among the fields same_segment compares: garbage input, but the count is the reference's), then all.
-BTRAPZ_HD int selection_copies(int pushes, const Seg &c) {
-  return pushes < 1 ? 0 : (pushes >= 2 && !same_segment(c, c) ? pushes : 1);
+BTRAPZ_HD int selection_copies(int pushes, bool equals_itself) {
+  return pushes < 1 ? 0 : (pushes >= 2 && !equals_itself ? pushes : 1);
 }
+BTRAPZ_HD int selection_copies(int pushes, const Seg &c) { return selection_copies(pushes, same_segment(c, c)); }
 
 // De-dup (keep first), then ordering and time-overlap resolution: solve_3d.cc:617-703 (trapezoid),
 // cuboid_3d.cc:538-567 (cuboid: no sort, no reorder, every later twin, a third of the span).  Separate steps so that

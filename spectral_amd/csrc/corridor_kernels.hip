@@ -305,10 +305,10 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     for (int q0 = 0; q0 < total; q0 += 64) {
       const int q = q0 + lane;
       int h = 0;
-      Seg twin = seg_default();   // the fields same_segment compares
+      bool equals_itself = true;  // false with a NaN among the fields same_segment compares
       if (q < total) {
         const Seg c = all[slot_of[q]];
-        twin = c;
+        equals_itself = same_segment(c, c);
         const double gap0 = c.upp_bias - c.down_bias, gap1 = c.down_skew * a.delta + c.down_bias - c.upp_skew * a.delta - c.upp_bias;
         const bool own_range = refs_finite && gap0 > 0.0 && gap0 < 1e300 && gap1 < 0.0 && gap1 > -1e300 && c.beg_t <= c.end_t;
         const int i_lo = own_range ? (c.beg_t > 0 ? c.beg_t : 0) : 0;
@@ -317,7 +317,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
       }
       const int upto = wave_inclusive_scan(h, lane);
       int counter = (carry + upto - h) % 3;
-      const int copies = q < total ? selection_copies(selection_pushes(h, counter), twin) : 0;   // 1, but for NaN segments
+      const int copies = q < total ? selection_copies(selection_pushes(h, counter), equals_itself) : 0;   // 1, but for NaN segments
       const int placed = wave_inclusive_scan(copies, lane);
       for (int j = 0, r = nsel + placed - copies; j < copies && r < cap_sel; j++, r++) pick[r] = slot_of[q];
       nsel += __builtin_amdgcn_readlane(placed, 63);
