@@ -313,6 +313,28 @@ def main():
                                 "solved_fraction": float(np.mean((st2 == 1) | (st2 == 2))),
                                 "mean_ipm_iterations": float(np.mean(o2["iters"].cpu().numpy() + 1))}
             del d2
+        # the other named configurations, in the same (driver-timed) run: BASELINE config 5 (receding horizon, one GPU)
+        # and the knot-level pipeline through the tools that profiles/ documents
+        if world == 1 and not a.no_secondary:
+            import contextlib, importlib.util, io
+            def tool(name, argv):
+                spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+                mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+                with contextlib.redirect_stdout(io.StringIO()):     # (this process prints ONE line)
+                    return mod.main(argv)
+            keep = lambda d, keys: {k: d[k] for k in keys if k in d}
+            try:
+                m = tool("mpc_bench", ["--steps", "150"])
+                out["config5_one_gpu"] = keep(m, ("workload", "achieved_hz", "target_hz", "p50_step_ms", "p99_step_ms",
+                                                  "mean_ipm_iterations", "solved_fraction_mean", "candidates_per_s"))
+                pl = tool("pipeline_bench", ["--reps", "3"])
+                out["pipeline_knots_to_control_points"] = keep(pl, ("workload", "corridor_ms", "ragged_solve_ms",
+                                                                    "end_to_end_candidates_per_s", "solved_fraction", "corridor_roofline"))
+                pp = tool("pipeline_bench", ["--reps", "3", "--prisms"])
+                out["pipeline_prisms_to_control_points"] = keep(pp, ("workload", "prism_ms", "corridor_ms", "ragged_solve_ms",
+                                                                     "end_to_end_scenes_per_s", "prism_roofline", "corridor_roofline"))
+            except Exception as e:                                  # the headline must not depend on the extras
+                out["extras_error"] = repr(e)[:200]
         # p50 latency of ONE solve (B = 1), inputs resident, including the sync
         if a.latency_reps > 0:
             one = solver.upload(batch.slice(0, 1))

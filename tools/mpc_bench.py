@@ -30,7 +30,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def main(argv=None):
+    """Runs the tool; returns the dict it prints as ONE JSON line (bench.py calls it in-process)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=250)
     ap.add_argument("--dt", type=float, default=0.02, help="replanning period in seconds (50 Hz)")
@@ -49,7 +50,7 @@ def main():
     ap.add_argument("--roll", default="cold", choices=["lam", "x0", "cold"],
                     help="what a step that rolls the window starts from: previous plan + rolled multipliers, plan only, nothing")
     ap.add_argument("--trace", action="store_true", help="per-step latency / iterations on stderr")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
 
     import torch
     from spectral_amd import layout as L
@@ -150,7 +151,7 @@ def main():
     wall = time.perf_counter() - wall0
     lat = np.array(lat)
     steady = lat[1:] if len(lat) > 1 else lat
-    print(json.dumps({
+    result = {
         "workload": "BASELINE.json config 5: %d agents x %d candidates, %d segments, replanned every %.0f ms, %d steps, %s"
                     % (G, C, S, 1e3 * a.dt, a.steps, "cold start every step" if a.cold else "warm start"),
         "mode": "cold" if a.cold else "warm", "min_first_segment_s": a.min_first,
@@ -162,9 +163,11 @@ def main():
         "solved_fraction_mean": float(np.mean(solved)), "solved_fraction_min": float(np.min(solved)),
         "candidates_per_s": B * 1e3 / float(steady.mean()),
         "dumped_winners": len(dumped),
-    }))
+    }
+    print(json.dumps(result))
     if a.dump:
         np.savez(a.dump, **{"%s_%d" % (k, i): v for i, d_ in enumerate(dumped) for k, v in d_.items()}, n=len(dumped))
+    return result
 
 
 if __name__ == "__main__":

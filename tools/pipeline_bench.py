@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def main(argv=None):
+    """Runs the tool; returns the dict it prints as ONE JSON line (bench.py calls it in-process)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--input", default="c_road_s1_3", help="bundled corridor file (tests/golden/inputs/<name>.txt)")
     ap.add_argument("--batch", type=int, default=65536)
@@ -31,7 +32,7 @@ def main():
     ap.add_argument("--prisms", action="store_true",
                     help="start one stage earlier (SURVEY 8f rank 4): B scenes of two obstacle prisms (the harness's "
                          "constellation, cart_frenet.py:1536-1546, jittered) -> btrapz_prism_bounds_device -> corridors -> QP")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     import torch
     from spectral_amd import knots, synth, layout as L
     from spectral_amd.solver import BatchSolver
@@ -109,7 +110,7 @@ def main():
                                    "unit": "GB/s", "frac": pb / (prism_ms * 1e-3) / 1e9 / 8000.0}
         extra["prism_ms"] = prism_ms
         extra["end_to_end_scenes_per_s"] = B / (prism_ms + float(np.median(tc)) + float(np.median(ts))) * 1e3
-    print(json.dumps({**extra,
+    result = {**extra,
         "workload": "%s (N = %d knots, %d obstacles), %s constraints" %
                     (label, kb.N, kb.num_obs, "trapezoid" if a.variant == 0 else "cuboid"),
         "corridor_ms": c_ms, "ragged_solve_ms": s_ms, "end_to_end_candidates_per_s": B / (c_ms + s_ms) * 1e3,
@@ -119,7 +120,9 @@ def main():
                               "algorithmic_bytes_per_candidate": (in_bytes + out_bytes) / B,
                               "achieved": (in_bytes + out_bytes) / (c_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                               "frac": (in_bytes + out_bytes) / (c_ms * 1e-3) / 1e9 / 8000.0},
-    }))
+    }
+    print(json.dumps(result))
+    return result
 
 
 if __name__ == "__main__":
