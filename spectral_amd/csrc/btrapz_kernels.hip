@@ -403,7 +403,14 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       if (!last) {
         const bool own_ok = mplo <= mphi && mvlo <= mvhi && nplo <= nphi && nvlo <= nvhi;
         mplo = fmax(mplo, nplo); mphi = fmin(mphi, nphi); mvlo = fmax(mvlo, nvlo); mvhi = fmin(mvhi, nvhi);
-        joint_empty = own_ok && (mplo > mphi || mvlo > mvhi);   // two consistent rows that contradict each other
+        // Two consistent rows that contradict each other -- by more than round-off: where the corridor changes lane the
+        // two sides often just touch, and the same boundary computed as bias + skew * t on one side and as a bias on the
+        // other differs in the last digit ([-1.2, 1.6] | [1.6000000000000001, 3.8]: "empty" by 2e-16; the reference's
+        // solver and the oracle put the joint on the boundary).  Such a joint is pinned to the common point.
+        const double ptol = 1e-9 * (1.0 + fmax(fabs(mplo), fabs(mphi))), vtol = 1e-9 * (1.0 + fmax(fabs(mvlo), fabs(mvhi)));
+        joint_empty = own_ok && (mplo > mphi + ptol || mvlo > mvhi + vtol);
+        if (mplo > mphi && !(mplo > mphi + ptol)) { mplo = 0.5 * (mplo + mphi); mphi = mplo; }
+        if (mvlo > mvhi && !(mvlo > mvhi + vtol)) { mvlo = 0.5 * (mvlo + mvhi); mvhi = mvlo; }
       }
     }
     t3 = t * t * t; it3 = it * it * it; t2 = t * t;
