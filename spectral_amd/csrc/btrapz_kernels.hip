@@ -678,6 +678,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       if (score < best_score) { best_score = score; best_it = eit; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
       if ((float)res < a.stall_factor * best_res) { best_res = (float)res; res_it = eit; }
 #ifndef ABL_FIXED
+      // (the divergence test is for the plain problem: in the relaxed one the multipliers of rows that end up violated
+      //  grow to violation / delta, 1e7 and more, and mu with them, on the way to the solution)
       // stop: converged; at the round-off floor (best < 1e-5, 3 iterations without progress); diverging or
       // infeasible (stall_len iterations without progress after the first stall_start); not finite.  "Progress" is a
       // smaller score OR residuals smaller by stall_factor: on a hard but solvable corridor (a run of 0.2-0.5 s segments)
@@ -688,7 +690,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // after 24, is restarted once from the cold start: a bad guess must neither turn a solvable candidate
       // into a failure nor cost more than a bounded number of iterations.
       const bool stalled = (eit - it0 >= a.stall_start && eit - best_it >= a.stall_len && eit - res_it >= a.stall_len) ||
-                           mu > (double)a.diverge_factor * best_score || !(score < 1e299);
+                           (!ELASTIC && mu > (double)a.diverge_factor * best_score) || !(score < 1e299);
       if (score < eps || (best_score < 1e-5 && eit - best_it >= 3)) done = true;
       else if (WARM && !restarted && (stalled || (eit - it0 >= 12 && best_score > 1e-4) || eit - it0 >= 24)) restart_now = true;
       else if (stalled) {
