@@ -1,0 +1,81 @@
+"""find_traj (in-memory) against the oracle's restatement of the same call on many knot-level inputs: decision
+(trajectory or sentinel), control points vs x*, the sample-count check of solve_3d.cc:1407.
+
+    python tests/fuzz/find_traj_vs_oracle.py SEED CALLS [ELASTIC]     # needs a GPU; ~12 s per 600 calls
+
+Inputs, in turn: scenario_1 scenes of 2-24 segments (synth.scenario1_knots), jittered copies of the bundled corridor
+files, fuzz_knot_batch garbage (tests/helpers.py).  ELASTIC = 0 (default here): the plain solve against the oracle's
+exact solve; 1: the product's default, rescue pass on, against "exact, else orc_elastic_solve within elastic_tol"
+(inputs within 0.02 of the tolerance are skipped).  A disagreement is printed with the kernel's own account
+(BTRAPZ_VERBOSE) and its input is written to gpurun_out/ftfuzz/.  Round 2: 7 200 / 7 200 agree (ELASTIC 0), 4 794 /
+4 800 (ELASTIC 1); see DESIGN.md sections 3.4, 3.7, 5.
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import sys, os, time, numpy as np, tempfile
+ELASTIC = sys.argv[3] if len(sys.argv) > 3 else "0"
+os.environ["BTRAPZ_ELASTIC"] = ELASTIC
+from oracle import oracle as O
+from spectral_amd import synth, knots, native
+if len(sys.argv) > 4: native.LIB_PATH = sys.argv[4]
+GOLD = os.path.join(ROOT, 'tests', 'golden'); W = np.loadtxt(GOLD + '/inputs/weights.txt')
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+rng = np.random.default_rng(seed0)
+files = ["c1", "c2", "c3", "c4", "c6", "c7", "c7_7", "c_road_s1", "c_road_s1_3"]
+tmp = tempfile.mkdtemp()
+agree = acc = rej = bad = 0
+worst = 0.0
+t0 = time.time()
+for it in range(count):
+    mode = it % 3
+    if mode == 0:
+        S = int(rng.integers(2, 25)); kb = synth.scenario1_knots(4, S, seed=int(rng.integers(1 << 30))); b = int(rng.integers(4))
+    elif mode == 1:
+        name = files[int(rng.integers(len(files)))]
+        kb = knots.jittered(knots.parse_corridor_file(GOLD + '/inputs/%s.txt' % name), 4, seed=int(rng.integers(1 << 30)),
+                            s_shift=float(rng.choice([0.1, 0.4, 1.0])), l_shift=float(rng.choice([0.01, 0.05, 0.2]))); b = int(rng.integers(4))
+    else:
+        from helpers import fuzz_knot_batch
+        kb = fuzz_knot_batch(int(rng.integers(1 << 30)), B=2); b = 0
+        kb.init[b, 0] = kb.s_ref[b, 0] if np.isfinite(kb.s_ref[b, 0]) else 0.0; kb.init[b, 3] = kb.l_ref[b, 0]
+    variant = int(rng.integers(2))
+    params = native.CParams(*[float(v) for v in W], 3)
+    cost, traj, ctrl = native.find_traj_mem(variant, params, kb, b)
+    # the oracle on the same input, through its own parser
+    path = os.path.join(tmp, "c.txt"); knots.write_corridor_file(path, kb, b)
+    want_accept = False; x = None; skipped = False; tol_x = 1e-5
+    try:
+        inp = O.ParsedInput(path)
+        n, cubes = O.pipeline(variant, inp)
+        if 1 <= n <= 64 and all(c.t > 0 for c in cubes):
+            qp = O.AssembledQp(variant, cubes, O.params_from_weights(W), inp)
+            x, _, info = qp.solve_exact()
+            want_accept = info.status in (1, 2)
+            tol_x = 1e-5
+            if not want_accept and ELASTIC == "1" and not (qp.l > qp.u + 1e-12).any() and np.isfinite(qp.l).all() and np.isfinite(qp.u).all():
+                x, _, info, viol = qp.solve_elastic()
+                if abs(viol - 0.5) < 0.02: skipped = True
+                want_accept = info.status in (1, 2) and viol <= 0.5
+                tol_x = 1e-4
+            if want_accept:   # the reference's CHECK_EQ(var_index, num_of_points_) (solve_3d.cc:1407) aborts: a failure here
+                rc, smp = O.sample(cubes, inp.delta, x, inp.init_s, inp.init_l)
+                want_accept = rc == 0
+    except Exception as e:
+        want_accept = False
+    got_accept = cost != 100000000000.0
+    if skipped: continue
+    if got_accept != want_accept:
+        bad += 1; print("DECISION", it, mode, variant, "hip", got_accept, "oracle", want_accept, "N", kb.N, "obs", kb.num_obs, "segments", n, "oracle status/iters", (info.status, info.iter) if x is not None else None, "t", [round(c.t, 2) for c in cubes][:12] if n > 0 else None, flush=True)
+        os.makedirs(os.path.join(ROOT, 'gpurun_out', 'ftfuzz'), exist_ok=True); knots.write_corridor_file(os.path.join(ROOT, 'gpurun_out', 'ftfuzz', 's%d_it%d_v%d.txt') % (seed0, it, variant), kb, b)
+        os.environ["BTRAPZ_VERBOSE"] = "1"; native.find_traj_mem(variant, params, kb, b); os.environ["BTRAPZ_VERBOSE"] = "0"; sys.stderr.flush()
+        continue
+    agree += 1
+    if not got_accept: rej += 1; continue
+    acc += 1
+    err = np.abs(ctrl - x).max() / max(1e-300, np.abs(x).max())
+    worst = max(worst, err)
+    if not (ctrl.shape == x.shape and err <= tol_x):
+        bad += 1; print("XSTAR", it, mode, variant, err)
+print("calls", count, "agree", agree, "accepted", acc, "rejected", rej, "mismatches", bad, "worst rel err %.2e" % worst, "seconds %.1f" % (time.time() - t0))
