@@ -114,8 +114,12 @@ enum {
 enum {
   BTRAPZ_SOLVED = 1,
   BTRAPZ_SOLVED_INACCURATE = 2,
-  BTRAPZ_MAX_ITER_REACHED = -2,
-  BTRAPZ_PRIMAL_INFEASIBLE = -3,
+  BTRAPZ_MAX_ITER_REACHED = -2,  /* no optimum reached: iteration limit; a solve that stalls or diverges (what an
+                                    infeasible corridor does); an initial state outside segment 0's rows or a
+                                    joint whose two sides share no value (reported before the first iteration);
+                                    the rescue pass (btrapz_options.elastic) takes these over */
+  BTRAPZ_PRIMAL_INFEASIBLE = -3, /* a row with l > u (e.g. an empty inscribed interval of the cuboid variant), or a
+                                    segment with t <= 0; after a rescue pass: violation above elastic_tol */
   BTRAPZ_NO_CORRIDOR = -5 /* ragged batches: the corridor stage selected no segment, more than
                              seg_stride / 64 segments, or a segment with t <= 0 (the reference's
                              find_traj fails or aborts on these: solve_3d.cc:617, :1407) */
