@@ -348,9 +348,13 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     KernelArgs e = a;
     e.order = lists; e.seg_count = seg_count; e.cand_prefix = c->d_rescue_meta; e.wave_prefix = c->d_rescue_meta + 66;
     e.bucket_S = 0; e.x0 = nullptr; e.lam0 = nullptr; e.lam_out = nullptr;
-    e.max_iter = a.max_iter < 80 ? 80 : a.max_iter;   // least-violation problems take 25-40 iterations
+    // Least-violation problems take 25-40 iterations, and up to 60 where a row's violation is fixed by the data (an
+    // initial state outside segment 0's rows): its multiplier has to grow to violation / delta before the score moves.
+    // The pass is rare and not on the throughput path: be patient (the oracle's relaxed solve is; with these limits every
+    // one of 6 000 fuzzed find_traj calls decides as it does, with 80 / 2x / 2x six of 4 800 did not).
+    e.max_iter = a.max_iter < 120 ? 120 : a.max_iter;
     e.tau_iters = 0;                                  // conservative step rule throughout
-    e.stall_start = 2 * BTRAPZ_STALL_START; e.stall_len = 2 * BTRAPZ_STALL_LENGTH;
+    e.stall_start = 4 * BTRAPZ_STALL_START; e.stall_len = 4 * BTRAPZ_STALL_LENGTH;
     const int smax = seg_count ? (S < 64 ? S : 64) : S;
     const unsigned eblocks = 2u * (unsigned)(B / (64 / smax) + 65);
     hipLaunchKernelGGL(ipm_solve_elastic_kernel, dim3(eblocks), dim3(64), 0, stream, e, (const double *)c->d_mqm);

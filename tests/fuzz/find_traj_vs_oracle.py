@@ -7,8 +7,8 @@ Inputs, in turn: scenario_1 scenes of 2-24 segments (synth.scenario1_knots), jit
 files, fuzz_knot_batch garbage (tests/helpers.py).  ELASTIC = 0 (default here): the plain solve against the oracle's
 exact solve; 1: the product's default, rescue pass on, against "exact, else orc_elastic_solve within elastic_tol"
 (inputs within 0.02 of the tolerance are skipped).  A disagreement is printed with the kernel's own account
-(BTRAPZ_VERBOSE) and its input is written to gpurun_out/ftfuzz/.  Round 2: 7 200 / 7 200 agree (ELASTIC 0), 4 794 /
-4 800 (ELASTIC 1); see DESIGN.md sections 3.4, 3.7, 5.
+(BTRAPZ_VERBOSE) and its input is written to gpurun_out/ftfuzz/.  Round 2: 7 200 / 7 200 agree (ELASTIC 0), 6 000 /
+6 000 (ELASTIC 1); see DESIGN.md sections 3.4, 3.7, 5.
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
