@@ -231,3 +231,21 @@ def test_fuzz_regressions(monkeypatch):
         cost, traj, ctrl = native.find_traj_mem(0, params, knots.parse_corridor_file(path))
         assert info.status == 1 and cost < 1e10 and len(ctrl) == 12 * n, name
         assert np.abs(ctrl - x).max() <= 1e-5 * np.abs(x).max(), name
+
+
+@pytest.mark.parametrize("elastic", ["0", "1"])
+def test_find_traj_fuzz_against_the_oracle(elastic):
+    """tests/fuzz/find_traj_vs_oracle.py, 240 calls on a seed of its own: scenario_1 scenes of 2-24 segments, jittered
+    bundled files, fuzz_knot_batch garbage.  elastic 0: the plain solve decides as the oracle's exact solve; 1 (the
+    product's default): as "exact, else the relaxed solve within elastic_tol".  Accepted control points are the oracle's
+    (the script checks 1e-5, 1e-4 for rescued ones)."""
+    import re
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(__file__), "fuzz", "find_traj_vs_oracle.py")
+    p = subprocess.run([sys.executable, script, "31", "240", elastic], capture_output=True, text=True, timeout=600)
+    last = [l for l in p.stdout.splitlines() if l.startswith("calls ")]
+    assert p.returncode == 0 and last, (p.returncode, p.stdout[-500:], p.stderr[-500:])
+    m = re.match(r"calls (\d+) agree (\d+) accepted (\d+) rejected (\d+) mismatches (\d+)", last[-1])
+    assert m and int(m.group(1)) == 240 and int(m.group(5)) == 0, last[-1]
+    assert int(m.group(3)) >= 100 and int(m.group(4)) >= 40, last[-1]      # both decisions are exercised
