@@ -86,6 +86,16 @@ double btrapz_find_traj_mem(int variant, const btrapz_traj_input *in, const Para
  * left on the device (the replanning loop cart_frenet.py:1516-1571 solves a problem close to the previous one at every
  * step), which shows here as fewer iterations; the result is x* to solver accuracy either way. */
 int btrapz_find_traj_last_iterations(void);
+/* Status of the calling thread's last find_traj / btrapz_find_traj_mem call, and what tells a rescued result from an
+ * exact one: viol[4] (if not NULL) receives the largest violation of a position / velocity / acceleration / jerk row by
+ * the returned trajectory, in the rows' own units.
+ *   BTRAPZ_SOLVED (1), or BTRAPZ_SOLVED_INACCURATE (2) with viol all zero: the trajectory is the QP's optimum (2: the
+ *     solve ended at its round-off floor, KKT score between 1e-7 and 1e-5);
+ *   BTRAPZ_SOLVED_INACCURATE (2) with a non-zero viol: the QP has no solution, the trajectory is the rescue pass's
+ *     least-violation one (btrapz_options.elastic) and leaves its rows by viol;
+ *   a negative status: the call returned 1e11.  0: no call yet.
+ * The reference's find_traj cannot tell these apart (it returns a_cost for OSQP's status 1 and 2 alike). */
+int btrapz_find_traj_last_status(double *viol);
 
 /* Host-side corridor stage of find_traj alone (CorridorGeneration + CorridorSplit per obstacle,
  * then CollisionCheck: src/solve_3d.cc:323-486,729-772,488-714 ; src/cuboid_3d.cc:301-573).
@@ -155,6 +165,8 @@ typedef struct btrapz_shared {
 } btrapz_shared;
 
 typedef struct btrapz_options {
+  int struct_size;       /* sizeof(btrapz_options) of the caller's build: set by btrapz_options_init().  A value the
+                            library does not know is rejected (BTRAPZ_EINVAL) instead of being read past its end. */
   int max_iter;          /* interior-point iterations; 0 -> default (60) */
   double eps;            /* KKT score target; 0 -> default (1e-9) */
   double step_fraction;  /* fraction of the step to the boundary taken per iteration, in (0,1); 0 -> default (0.9999) */
@@ -162,17 +174,21 @@ typedef struct btrapz_options {
                             (blocked steps, and every step after the 12th iteration, take 0.995 of it, which
                             keeps the iterates centred); 0 -> default (0.9) */
   /* Rescue of stalled candidates (acceptance, solve_3d.cc:1251-1277 / trp_wrapper.cpp:191-200).  The reference
-   * accepts OSQP's status 2: on a marginally infeasible corridor (e.g. src/c7.txt) that is an ADMM iterate which
-   * violates rows by up to ~0.5 in their own units, and find_traj returns a trajectory.  An exact method has no
-   * such iterate -- the QP has no solution -- so the equivalent here is explicit: an axis problem whose
-   * interior-point solve stalls is solved again with every inequality row relaxed, l <= g'x - d <= u, and
-   * sum d^2 / (2 elastic_delta) added to the objective (equalities -- continuity, initial state -- stay exact):
-   * the least-squares violation of the rows, the reference's objective deciding among its minimisers.
+   * accepts OSQP's status 2: on a marginally infeasible corridor (src/c7.txt) that is an ADMM iterate which stays
+   * within 1e-4 m of its position rows and violates acceleration rows by 0.49, and find_traj returns a trajectory.
+   * An exact method has no such iterate -- the QP has no solution -- so the equivalent here is explicit: an axis
+   * problem whose interior-point solve stalls is solved again with every inequality row relaxed, l <= g'x - d <= u,
+   * and sum (d / |g|)^2 / (2 elastic_delta) added to the objective (equalities -- continuity, initial state -- stay
+   * exact): the least-squares violation of the rows, each measured in its own norm |g| (t for a position row t c_i,
+   * sqrt(50) for a velocity row, sqrt(2400) for an acceleration row, sqrt(72000) for a jerk row: the distance the
+   * control points would have to move), the reference's objective deciding among its minimisers.
    *   elastic        0: off (stalled candidates keep status -2, cost +inf) -- default of the batched entry points;
    *                  1: rescue pass over the stalled axis problems after the solve; 2: every candidate is solved
    *                  with elastic rows straight away.  find_traj uses 1 (BTRAPZ_ELASTIC=0 turns it off).
-   *   elastic_tol    a rescued problem whose largest row violation is at most this is reported as
-   *                  BTRAPZ_SOLVED_INACCURATE (2), beyond it as BTRAPZ_PRIMAL_INFEASIBLE (-3); 0 -> default (0.5)
+   *   elastic_tol    a rescued problem whose largest row violation / |g| is at most this is reported as
+   *                  BTRAPZ_SOLVED_INACCURATE (2), beyond it as BTRAPZ_PRIMAL_INFEASIBLE (-3); 0 -> default (0.0125:
+   *                  at most 0.0125 t metres outside a position row, 0.088 on a velocity row, 0.61 on an acceleration
+   *                  row -- the reference's accepted iterate on src/c7.txt is at 0.492 = 0.01004 |g| -- 3.4 on a jerk row)
    *   elastic_delta  0 -> default (1e-8) */
   int elastic;
   double elastic_tol;
@@ -182,7 +198,15 @@ typedef struct btrapz_options {
    * counts spread widely (batches with stalling candidates: -10 %), costs where they do not (+6 %); 0 -> off.
    * Results do not depend on it. */
   int queue;
+  /* Few candidates: the split form of the solve kernel -- ONE candidate per wavefront, every segment's rows spread over
+   * three lanes (uniform cold batches of at most 21 segments).  Per solve it takes ~0.7 of the time of the
+   * three-candidates-per-wavefront form and 2-3 times its machine share, so it pays while the batch leaves SIMDs idle.
+   * 0 -> automatic (used when 2 B wavefronts fit the device's SIMDs at once); 1 -> whenever the batch qualifies;
+   * -1 -> never.  Same problem, same method: results agree to rounding (the row sums are taken in another order). */
+  int split;
 } btrapz_options;
+/* Zeroes *opt (every field: "use the default") and sets struct_size.  Call it before filling the struct in. */
+void btrapz_options_init(btrapz_options *opt);
 
 /* A context owns the per-launch workspace of one device: it is NOT thread-safe (one context per calling
  * thread; launches of one context must be issued in stream order). */
@@ -208,6 +232,13 @@ int btrapz_solve_batch_device(btrapz_ctx *ctx, const btrapz_shared *shared,
                               const double *init, const double *ref_end,
                               const double *dl_bounds, double *ctrl, double *cost,
                               int *status, int *iters, void *stream);
+
+/* Row violations of the candidates the context's LAST solve with btrapz_options.elastic != 0 handed to the rescue pass
+ * (0 for every other candidate): viol [B][4] = largest violation of a position / velocity / acceleration / jerk row
+ * by the returned control points, in the rows' own units (t c_i in metres, 5 (c_i+1 - c_i), 20 (c_i - 2 c_i+1 + c_i+2),
+ * 60 (...): solve_3d.cc:823-888), the larger of the two axes.  A caller that must not leave the corridor by more than
+ * its own margin tests viol[b][0].  Device pointer; stream order. */
+int btrapz_rescue_violations_device(btrapz_ctx *ctx, int B, double *viol, void *stream);
 
 /* Arg-min of cost over contiguous groups of `group` candidates (B % group == 0).
  * best_idx[g] = global candidate index (index_base + local), ties -> lowest index;
@@ -327,6 +358,10 @@ int btrapz_solve_warm_device(btrapz_ctx *ctx, const btrapz_shared *shared, const
 int btrapz_eval_states_device(btrapz_ctx *ctx, int B, int seg_stride, const int *seg_count,
                               const double *seg, const double *ctrl, int n_times, const double *times,
                               double *x, void *stream);
+
+/* Test hook: the batch-invariant M' pQp_d M table (solve_3d.cc:87-143) from the library's host builder (find_traj's
+ * single launch) and from its device builder (the batched entry points): [2][4][21] doubles each, host pointers. */
+int btrapz_debug_mqm_tables(btrapz_ctx *ctx, const btrapz_shared *shared, double *host_table, double *device_table);
 
 /* Host-pointer convenience wrapper: H2D, solve, D2H, synchronous. */
 int btrapz_solve_batch_host(btrapz_ctx *ctx, const btrapz_shared *shared,

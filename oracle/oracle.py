@@ -315,15 +315,36 @@ class AssembledQp:
         lib().orc_ipm_solve(C.byref(self.raw), eps, max_iter, _dp(x), _dp(y), C.byref(info))
         return x, y, info
 
-    def solve_elastic(self, delta=1e-8, eps=1e-9, max_iter=120):
-        """Least-violation solution of the rescue pass (orc_elastic_solve): x, y, info, largest row violation."""
+    def solve_elastic(self, delta=1e-8, eps=1e-9, max_iter=120, normalised=True):
+        """Least-violation solution of the product's rescue pass (btrapz_options.elastic): x, y, info, largest row
+        violation.  normalised (the product's problem since round 3): every inequality row is relaxed in its own norm,
+        penalty (d / |a_i|)^2 / (2 delta) -- orc_elastic_solve on the QP with its inequality rows (and their bounds)
+        divided by |a_i|; the violation returned is in that unit too, `self.class_violations(x)` gives the rows' own.
+        normalised=False: round 2's problem, d^2 / (2 delta) on every row alike."""
         x = np.zeros(self.n); y = np.zeros(self.m); info = Info()
-        lib().orc_elastic_solve(C.byref(self.raw), float(delta), eps, max_iter, _dp(x), _dp(y), C.byref(info))
+        P, A = self.dense()
+        ineq = (self.u - self.l) > 1e-12
+        nrm = np.ones(self.m)
+        if normalised:
+            nrm[ineq] = np.linalg.norm(A[ineq], axis=1)
+            scaled = DenseQp(P, np.array(self.q, dtype=float), A / nrm[:, None], self.l / nrm, self.u / nrm)
+            lib().orc_elastic_solve(C.byref(scaled.raw), float(delta), eps, max_iter, _dp(x), _dp(y), C.byref(info))
+            y = y / nrm
+        else:
+            lib().orc_elastic_solve(C.byref(self.raw), float(delta), eps, max_iter, _dp(x), _dp(y), C.byref(info))
+        Ax = A @ x
+        viol = (np.abs(Ax - np.clip(Ax, self.l, self.u)) / nrm)[ineq].max() if ineq.any() else 0.0
+        return x, y, info, float(viol)
+
+    def class_violations(self, x):
+        """Largest violation of a position / velocity / acceleration / jerk row (1, 2, 3, 4 coefficients per row:
+        solve_3d.cc:823-888) by x, in the rows' own units."""
         _, A = self.dense()
         Ax = A @ x
+        v = np.abs(Ax - np.clip(Ax, self.l, self.u))
         ineq = (self.u - self.l) > 1e-12
-        viol = np.abs(Ax - np.clip(Ax, self.l, self.u))[ineq].max() if ineq.any() else 0.0
-        return x, y, info, float(viol)
+        nnz = (A != 0).sum(axis=1)
+        return [float(v[ineq & (nnz == c)].max()) if (ineq & (nnz == c)).any() else 0.0 for c in (1, 2, 3, 4)]
 
     def kkt(self, x, y):
         res = np.zeros(3)

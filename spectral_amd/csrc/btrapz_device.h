@@ -37,6 +37,7 @@ struct KernelArgs {
   double *axis_obj;         // [2B]
   int *axis_status;         // [2B]
   int *axis_iters;          // [2B]
+  double *axis_viol;        // [2B][4] rescue pass: row violations per class (may be null)
   Shared sh;
   double eps;
   double tau;               // fraction of the step to the boundary ...
@@ -87,10 +88,12 @@ __global__ void ipm_solve_warm_kernel(const KernelArgs a, const double *__restri
 __global__ void ipm_solve_warm_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void ipm_solve_queue_kernel(const KernelArgs a, const double *__restrict__ mqm);         // persistent, candidate queue
 __global__ void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm);       // rescue pass
+__global__ void ipm_solve_split_kernel(const KernelArgs a, const double *__restrict__ mqm);         // one candidate per wavefront, rows over 3 lanes
 __global__ void rescue_keys_kernel(int B, int S, const int *seg_count, const int *axis_status, int *keys, int all);
 __global__ void rescue_init_kernel(int B, int S, const int *seg_count, double *axis_obj, int *axis_status, int *axis_iters);
 struct MqmWeights { double w[2][4]; };   // [axis][ref, dref, acc, jerk]
 __global__ void mqm_table_kernel(MqmWeights w, double *out);
+__global__ void rescue_violations_kernel(int B, const double *axis_viol, double *viol);
 __global__ void finalize_kernel(int B, const double *axis_obj, const int *axis_status, const int *axis_iters,
                                 double *cost, int *status, int *iters);
 __global__ void argmin_kernel(int group, long long index_base, const double *cost, long long *best_idx,
@@ -106,6 +109,8 @@ __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, doubl
 
 __global__ void single_candidate_kernel(const KernelArgs a, const double *__restrict__ mqm, double delta, int max_points,
                                         double *out);
+__global__ void single_candidate_split_kernel(const KernelArgs a, const double *__restrict__ mqm, double delta, int max_points,
+                                              double *out);
 __global__ void single_candidate_warm_kernel(const KernelArgs a, const double *__restrict__ mqm, double delta, int max_points,
                                              double *out);
 

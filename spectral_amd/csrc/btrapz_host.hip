@@ -47,11 +47,14 @@ using namespace btrapz;
 // Rescue pass (btrapz_options.elastic): penalty parameter of the relaxed rows and the violation still accepted.
 // delta: the relaxed solution is within delta * |multipliers| (1e2..1e4 here) of the least-violation limit; 1e-8 keeps
 // that below 1e-4 and the interior-point method still converges in 25-40 iterations (1e-10: 40+, scores near 1e-7).
-// tol: the reference accepted an iterate that violates acceleration rows by 0.49 on src/c7.txt (oracle OSQP port, status
-// 2); the least-squares violation of the c7 family is 0.09 (trapezoid) / 0.02 (cuboid), that of a grossly infeasible
-// input such as src/c_road_s1_2.txt is 15.
+// tol, in the unit of the penalty (violation / |g_r|): the iterate the reference accepted on src/c7.txt (oracle OSQP
+// port, status 2) violates acceleration rows by 0.492 = 0.01004 |g|, velocity rows by 0.013, position rows by 1e-4 m;
+// the least-squares solution of that input in the same norm violates them by 0.477 / 0.027 / 3e-4 m (0.0097 |g|; cuboid:
+// 0.0019 |g|); a grossly infeasible input such as src/c_road_s1_2.txt is at 4.9 |g|.  Default 0.0125: a quarter above
+// what the reference is seen accepting; at most 0.0125 t metres outside a position row.  (Round 2 penalised every row in
+// its own unit and accepted 0.5 of it: the least-squares solution then leaves c7's lateral corridor by 0.09 m.)
 #define BTRAPZ_DEFAULT_ELASTIC_DELTA 1e-8
-#define BTRAPZ_DEFAULT_ELASTIC_TOL 0.5
+#define BTRAPZ_DEFAULT_ELASTIC_TOL 0.0125
 
 struct btrapz_ctx {
   int device = 0;
@@ -59,6 +62,8 @@ struct btrapz_ctx {
   // workspace (grown on demand)
   double *d_axis_obj = nullptr;
   int *d_axis_status = nullptr, *d_axis_iters = nullptr;
+  double *d_axis_viol = nullptr;    // [2B][4] rescue pass: row violations per class
+  size_t viol_valid = 0;            // candidates of the last solve with a rescue pass (0: none)
   size_t axis_cap = 0;
   double *d_mqm = nullptr;          // [2][4][21]
   double h_mqm_w[8] = {NAN, NAN, NAN, NAN, NAN, NAN, NAN, NAN};  // weights the table was built for
@@ -115,7 +120,7 @@ BTRAPZ_EXPORT int btrapz_create(btrapz_ctx **out, int device) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->resident_waves = 4 * cus;
   }
   if (hipMalloc(&c->d_queue, sizeof(int) * 2) != hipSuccess) { (void)hipFree(c->d_mqm); delete c; return BTRAPZ_ENOMEM; }
-  if (hipEventCreateWithFlags(&c->ws_free, hipEventDisableTiming) != hipSuccess) { (void)hipFree(c->d_mqm); delete c; return BTRAPZ_ENOMEM; }
+  if (hipEventCreateWithFlags(&c->ws_free, hipEventDisableTiming) != hipSuccess) { (void)hipFree(c->d_mqm); (void)hipFree(c->d_queue); delete c; return BTRAPZ_ENOMEM; }
   *out = c;
   return BTRAPZ_OK;
 }
@@ -123,7 +128,7 @@ BTRAPZ_EXPORT int btrapz_create(btrapz_ctx **out, int device) {
 BTRAPZ_EXPORT int btrapz_destroy(btrapz_ctx *c) {
   if (!c) return BTRAPZ_EINVAL;
   (void)hipSetDevice(c->device);
-  (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters);
+  (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters); (void)hipFree(c->d_axis_viol);
   (void)hipFree(c->d_mqm); (void)hipFree(c->d_stage); (void)hipFree(c->d_istage); (void)hipFree(c->d_single);
   (void)hipFree(c->d_queue); (void)hipFree(c->d_single_warm);
   (void)hipFree(c->d_order); (void)hipFree(c->d_meta); (void)hipFree(c->d_retry);
@@ -137,13 +142,27 @@ BTRAPZ_EXPORT const char *btrapz_last_error(const btrapz_ctx *c) { return c ? c-
 
 static int ensure_axis_ws(btrapz_ctx *c, size_t nprob) {
   if (nprob <= c->axis_cap) return BTRAPZ_OK;
-  (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters);
-  c->d_axis_obj = nullptr; c->d_axis_status = nullptr; c->d_axis_iters = nullptr; c->axis_cap = 0;
+  (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters); (void)hipFree(c->d_axis_viol);
+  c->d_axis_obj = nullptr; c->d_axis_status = nullptr; c->d_axis_iters = nullptr; c->d_axis_viol = nullptr; c->axis_cap = 0;
+  c->viol_valid = 0;
   HIPCHK(c, hipMalloc(&c->d_axis_obj, sizeof(double) * nprob));
+  HIPCHK(c, hipMalloc(&c->d_axis_viol, sizeof(double) * 4 * nprob));
   HIPCHK(c, hipMalloc(&c->d_axis_status, sizeof(int) * nprob));
   HIPCHK(c, hipMalloc(&c->d_axis_iters, sizeof(int) * nprob));
   c->axis_cap = nprob;
   return BTRAPZ_OK;
+}
+
+BTRAPZ_EXPORT void btrapz_options_init(btrapz_options *opt) {
+  if (!opt) return;
+  memset(opt, 0, sizeof(*opt));
+  opt->struct_size = (int)sizeof(btrapz_options);
+}
+// A caller built against another layout of btrapz_options would make the library read fields that are not there.
+static bool options_ok(btrapz_ctx *c, const btrapz_options *opt) {
+  if (!opt || opt->struct_size == (int)sizeof(btrapz_options)) return true;
+  if (c) c->err = "invalid argument: btrapz_options.struct_size (call btrapz_options_init first)";
+  return false;
 }
 
 // Weights, limits and iteration parameters of a launch (everything of KernelArgs that is not a pointer or a size).
@@ -174,6 +193,7 @@ static void fill_parameters(KernelArgs &a, const btrapz_shared *sh, const btrapz
 
 // M' pQp_d M on the host (solve_3d.cc:87-143): the single-candidate path hands the table over with its inputs.
 void btrapz_mqm_table_host(const btrapz_shared *sh, double *table) {
+#pragma clang fp contract(off)   // the device builder (mqm_table_kernel) evaluates the same expressions: same bits
   static const double M[6][6] = {{1, 0, 0, 0, 0, 0},      {-5, 5, 0, 0, 0, 0},      {10, -20, 10, 0, 0, 0},
                                  {-10, 30, -30, 10, 0, 0}, {5, -20, 30, -20, 5, 0}, {-1, 5, -10, 10, -5, 1}};
   for (int axis = 0; axis < 2; axis++) {
@@ -198,10 +218,27 @@ void btrapz_mqm_table_host(const btrapz_shared *sh, double *table) {
 
 void btrapz_single_forget(btrapz_ctx *c) { if (c) c->single_S = 0; }
 
+// Test hook: the M'QM table as find_traj's single launch receives it (host builder) and as the batched entry points
+// use it (device builder), [2][4][21] each -- the two must agree bit for bit (tests/test_gpu_properties.py).
+BTRAPZ_EXPORT int btrapz_debug_mqm_tables(btrapz_ctx *c, const btrapz_shared *sh, double *host_table, double *device_table) {
+  if (!c || !sh || !host_table || !device_table) return BTRAPZ_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  btrapz_mqm_table_host(sh, host_table);
+  double *d = nullptr;
+  HIPCHK(c, hipMalloc(&d, sizeof(double) * 168));
+  MqmWeights mw;
+  memcpy(mw.w[0], sh->w_s, sizeof(double) * 4); memcpy(mw.w[1], sh->w_l, sizeof(double) * 4);
+  hipLaunchKernelGGL(mqm_table_kernel, dim3(1), dim3(192), 0, nullptr, mw, d);
+  hipError_t e = hipMemcpy(device_table, d, sizeof(double) * 168, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIPCHK(c, e);
+  return BTRAPZ_OK;
+}
+
 int btrapz_launch_single(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int S, const double *in,
                          double *out, int max_points, int warm, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!c || !sh || S < 1 || S > BTRAPZ_MAX_SEGMENTS || !in || !out || max_points < 1) return BTRAPZ_EINVAL;
+  if (!c || !sh || S < 1 || S > BTRAPZ_MAX_SEGMENTS || !in || !out || max_points < 1 || !options_ok(c, opt)) return BTRAPZ_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   KernelArgs a;
   fill_parameters(a, sh, opt, nullptr);
@@ -214,7 +251,7 @@ int btrapz_launch_single(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_op
   if (!c->d_single) HIPCHK(c, hipMalloc(&c->d_single, sizeof(double) * 12 * BTRAPZ_MAX_SEGMENTS));
   if (c->ws_used && c->ws_stream != stream) HIPCHK(c, hipStreamWaitEvent(stream, c->ws_free, 0));
   a.axis_obj = c->d_axis_obj; a.axis_status = c->d_axis_status; a.axis_iters = c->d_axis_iters;
-  a.ctrl = c->d_single; a.queue = nullptr; a.x_out = nullptr;
+  a.ctrl = c->d_single; a.queue = nullptr; a.x_out = nullptr; a.axis_viol = nullptr;
   if (warm) {
     const size_t nx = 2 * 64 * 3, nl = 2 * 36 * 64, set = nx + nl;
     if (!c->d_single_warm) HIPCHK(c, hipMalloc(&c->d_single_warm, sizeof(double) * 2 * set));
@@ -226,7 +263,13 @@ int btrapz_launch_single(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_op
     c->single_flip = 1 - c->single_flip; c->single_S = S; c->single_variant = sh->variant;
     hipLaunchKernelGGL(single_candidate_warm_kernel, dim3(1), dim3(128), 0, stream, a, mqm, sh->delta, max_points, out);
   } else {
-    hipLaunchKernelGGL(single_candidate_kernel, dim3(1), dim3(128), 0, stream, a, mqm, sh->delta, max_points, out);
+    // at most 21 segments: the split form (rows of a segment over three lanes), ~0.7 of the time per iteration
+    const char *split_e = getenv("BTRAPZ_SPLIT");   // (read per call: tests switch it)
+    const bool split_off = split_e && *split_e == '0';
+    if (S <= 21 && !split_off && !(opt && opt->split < 0))
+      hipLaunchKernelGGL(single_candidate_split_kernel, dim3(1), dim3(128), 0, stream, a, mqm, sh->delta, max_points, out);
+    else
+      hipLaunchKernelGGL(single_candidate_kernel, dim3(1), dim3(128), 0, stream, a, mqm, sh->delta, max_points, out);
   }
   c->ws_stream = stream; c->ws_used = true;
   HIPCHK(c, hipEventRecord(c->ws_free, stream));
@@ -244,6 +287,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     c->err = "invalid argument";
     return BTRAPZ_EINVAL;
   }
+  if (!options_ok(c, opt)) return BTRAPZ_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   HIPCHK(c, hipSetDevice(c->device));
   if (c->ws_used && stream != c->ws_stream) HIPCHK(c, hipStreamWaitEvent(stream, c->ws_free, 0));
@@ -266,6 +310,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   a.B = B; a.S = S; a.seg_stride = S; a.order = nullptr; a.seg_count = nullptr; a.cand_prefix = nullptr; a.wave_prefix = nullptr;
   a.seg = seg; a.init = init; a.ref_end = ref_end; a.dl_bounds = dl_bounds; a.mqm = c->d_mqm;
   a.ctrl = ctrl; a.axis_obj = c->d_axis_obj; a.axis_status = c->d_axis_status; a.axis_iters = c->d_axis_iters;
+  a.axis_viol = c->d_axis_viol; c->viol_valid = 0;
   a.x_out = nullptr;
   const int elastic = opt ? opt->elastic : 0;
   if (elastic < 0 || elastic > 2) { c->err = "invalid argument: btrapz_options.elastic"; return BTRAPZ_EINVAL; }
@@ -309,7 +354,15 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     static const int queue_env = [] { const char *q = getenv("BTRAPZ_QUEUE"); return q ? (*q == '0' ? -1 : 1) : 0; }();
     const bool queue_on = queue_env ? queue_env > 0 : (opt && opt->queue > 0);
     a.queue = c->d_queue;
-    if (queue_on && !a.order && !warm_kernel && blocks >= 3u * (unsigned)c->resident_waves) {
+    // Few candidates: one per wavefront, rows over three lanes (btrapz_options.split; ipm_solve_split_kernel)
+    const char *split_q = getenv("BTRAPZ_SPLIT");
+    const int split_env = split_q ? (*split_q == '0' ? -1 : 1) : 0;
+    const int split_opt = split_env ? split_env : (opt ? opt->split : 0);
+    const bool split_on = !a.order && !warm_kernel && S <= 21 &&
+                          (split_opt > 0 || (split_opt == 0 && 2u * (unsigned)B <= (unsigned)c->resident_waves));
+    if (split_on) {
+      hipLaunchKernelGGL(ipm_solve_split_kernel, dim3(2u * (unsigned)B), dim3(64), 0, stream, a, (const double *)c->d_mqm);
+    } else if (queue_on && !a.order && !warm_kernel && blocks >= 3u * (unsigned)c->resident_waves) {
       HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int) * 2, stream));
       hipLaunchKernelGGL(ipm_solve_queue_kernel, dim3((unsigned)c->resident_waves & ~1u), dim3(64), 0, stream, a,
                          (const double *)c->d_mqm);
@@ -328,6 +381,8 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       c->rescue_cap = 2 * (size_t)B;
     }
     if (!c->d_rescue_meta) HIPCHK(c, hipMalloc(&c->d_rescue_meta, sizeof(int) * 2 * 198));
+    HIPCHK(c, hipMemsetAsync(c->d_axis_viol, 0, sizeof(double) * 8 * (size_t)B, stream));
+    c->viol_valid = (size_t)B;
     int *keys = c->d_rescue, *lists = c->d_rescue + 2 * (size_t)B;
     const unsigned nb = (unsigned)((B + 255) / 256);
     if (elastic == 2)
@@ -391,6 +446,18 @@ BTRAPZ_EXPORT int btrapz_solve_warm_device(btrapz_ctx *c, const btrapz_shared *s
                                         void *stream) {
   return solve_common(c, sh, opt, warm, B, seg_stride, seg_count, seg, init, ref_end, dl_bounds, ctrl, cost, status,
                       iters, stream);
+}
+
+BTRAPZ_EXPORT int btrapz_rescue_violations_device(btrapz_ctx *c, int B, double *viol, void *stream_) {
+  if (!c) return BTRAPZ_EINVAL;
+  if (B < 1 || !viol) { c->err = "invalid argument"; return BTRAPZ_EINVAL; }
+  if ((size_t)B != c->viol_valid) { c->err = "the context's last solve of B candidates had no rescue pass (btrapz_options.elastic)"; return BTRAPZ_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  if (c->ws_used && stream != c->ws_stream) HIPCHK(c, hipStreamWaitEvent(stream, c->ws_free, 0));
+  hipLaunchKernelGGL(rescue_violations_kernel, dim3((4 * B + 255) / 256), dim3(256), 0, stream, B, (const double *)c->d_axis_viol, viol);
+  HIPCHK(c, hipGetLastError());
+  return BTRAPZ_OK;
 }
 
 BTRAPZ_EXPORT int btrapz_eval_states_device(btrapz_ctx *c, int B, int seg_stride, const int *seg_count, const double *seg,
@@ -483,7 +550,7 @@ BTRAPZ_EXPORT int btrapz_argmin_device(btrapz_ctx *c, int B, int group, long lon
     }
     if (c->ws_used && stream != c->ws_stream) HIPCHK(c, hipStreamWaitEvent(stream, c->ws_free, 0));
   }
-  hipLaunchKernelGGL(argmin_kernel, dim3(chunks, groups), dim3(256), 0, stream, group, index_base, cost, best_idx, best_cost,
+  hipLaunchKernelGGL(argmin_kernel, dim3(groups, chunks), dim3(256), 0, stream, group, index_base, cost, best_idx, best_cost,
                      c->d_argmin_cost, c->d_argmin_idx);
   if (chunks > 1) {
     hipLaunchKernelGGL(argmin_final_kernel, dim3(groups), dim3(256), 0, stream, chunks, index_base,

@@ -116,6 +116,15 @@ template <bool FULL> __host__ __device__ constexpr int state_index(int r) {   //
 template <bool FULL> __host__ __device__ constexpr int next_row(int r) {      // the kept row after r, -1 after the last
   return r >= 17 ? -1 : (FULL ? r + 1 : (r + 1 == 6 || r + 1 == 11) ? r + 2 : r + 1);
 }
+// Split form (SPLIT in ipm_solve_body): which lane group j = 0..2 owns row r of a segment, and in which of its five
+// slots.  Slot 0: jerk row 15 + j; 1: acceleration row 12 + j; 2: velocity row 7 + j; 3: position row 1 / 3 / 5;
+// 4: position row 2 / 4 for j = 0 / 1, velocity row 10 for j = 2 (rows 0, 6, 11 are not kept: rows_kept).
+__host__ __device__ constexpr int split_owner_j(int r) {
+  return r >= 15 ? r - 15 : r >= 12 ? r - 12 : (r >= 7 && r <= 9) ? r - 7 : r == 10 ? 2 : (r & 1) ? (r - 1) / 2 : (r - 2) / 2;
+}
+__host__ __device__ constexpr int split_owner_slot(int r) {
+  return r >= 15 ? 0 : r >= 12 ? 1 : (r >= 7 && r <= 9) ? 2 : r == 10 ? 4 : (r & 1) ? 3 : 4;
+}
 #define FOR_ROWS(r) static_for<NR>([&](auto r##_c) { constexpr int r = row_id<FULL>(decltype(r##_c)::value);
 #define END_ROWS });
 #define SI(r) state_index<FULL>(r)
@@ -223,6 +232,10 @@ __device__ __forceinline__ Red4 group_reduce(double (*red)[64], int lane, int gb
 // lambda_l)) leaves the same iteration with three changes per row: the row value is g'c - delta (lambda_u - lambda_l),
 // the row's weight in the Newton matrix is w / (1 + delta w), and the step of the row value is
 // (g'dc - delta b) / (1 + delta w), b the row's entry of the right-hand side.  delta = 0 is the plain method.
+// The relaxation of a row is measured in the row's own norm: delta_r = elastic_delta * |g_r|^2 (position rows t^2,
+// velocity 50, acceleration 2400, jerk 72000), i.e. the penalty is on d_r / |g_r|, the distance the control points
+// would have to move -- a violation of 0.01 in that unit is 0.01 t metres on a position row, 0.07 on a velocity row,
+// 0.49 on an acceleration row (what the reference's own status-2 iterate on src/c7.txt shows), 2.7 on a jerk row.
 // wave_id: the wavefront's number in the launch (wavefront w solves axis w & 1 of the candidates of pair w >> 1);
 // lds: this wavefront's private [L_ROWS][64] block of LDS; lane: 0..63.
 // QUEUE = true (uniform cold batches): the wavefront is persistent.  Its group slots draw candidates from a counter in
@@ -231,14 +244,25 @@ __device__ __forceinline__ Red4 group_reduce(double (*red)[64], int lane, int gb
 // holds (on the scenario_1 batch the slowest of three needs 11 iterations against a mean of 9.7).  The counter is read
 // one candidate ahead, so its latency is hidden behind ten iterations; which slot solves a candidate has no influence
 // on its result.
-template <bool WARM, bool ORDERED, bool ELASTIC = false, bool QUEUE = false>
+// SPLIT = true (uniform cold batches, S <= 21): the latency form.  ONE candidate per wavefront; its three lane groups
+// hold the same axis problem and share its row work -- lane (j, k), j = 0..2, owns five of segment k's fifteen rows
+// (slots: jerk row j, acceleration row j + 1, velocity row j + 1, and two of the remaining position / velocity rows, see
+// split_owner_*), keeps their slacks and multipliers in registers and publishes one scalar per row and phase through
+// LDS; every lane then gathers the fifteen scalars of its segment and forms gradient, Newton block and right-hand
+// sides exactly as the one-lane-per-segment form does, so the block LDL^T, its sweeps, the reductions and every
+// decision run (redundantly, bit for bit alike) in all three groups.  Row passes cost a third; everything sequential
+// costs the same per wavefront but serves one problem instead of three -- lower latency for few candidates, lower
+// throughput for many (measured: DESIGN.md 3.6).
+template <bool WARM, bool ORDERED, bool ELASTIC = false, bool QUEUE = false, bool SPLIT = false>
 __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double *__restrict__ mqm, double (*lds)[64],
                                                const int wave_id, const int lane) {
   static_assert(!QUEUE || (!WARM && !ORDERED && !ELASTIC), "the queue serves uniform cold batches");
+  static_assert(!SPLIT || (!WARM && !ORDERED && !ELASTIC && !QUEUE), "the split form serves uniform cold batches");
   constexpr bool CACHE_RP = !ELASTIC;   // see the main loop
   constexpr bool FULL = ELASTIC;                 // rows kept: see rows_kept()
   constexpr int NR = rows_kept<FULL>();
-  constexpr int L_LL = 0, L_LU = NR, L_ISL = 2 * NR, L_ISU = 3 * NR, L_RED = 4 * NR;
+  constexpr int L_LL = 0, L_LU = NR, L_ISL = 2 * NR, L_ISU = 3 * NR, L_RED = SPLIT ? 17 : 4 * NR;
+  [[maybe_unused]] constexpr int L_XCH = 0;   // split form: 15 row scalars + 2 statistics per lane, rewritten phase by phase
   // the axis is wave-uniform
   const int axis = __builtin_amdgcn_readfirstlane(wave_id & 1);
   int S, pair = wave_id >> 1, ncand = a.B, cand0 = 0;
@@ -260,7 +284,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     S = a.S;
   }
   S = __builtin_amdgcn_readfirstlane(S);
-  const int gpw = 64 / S;
+  const int gpw = SPLIT ? 3 : 64 / S;   // split form: three copies of one problem (3 S <= 64, the host checks)
   const int g = lane / S;
   const int k = lane - g * S;
   const bool lane_in_group = g < gpw;
@@ -279,7 +303,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   const double *__restrict__ mq = mqm + axis * 84;
   const size_t lam_row = (size_t)a.B * a.seg_stride;
   const double eps = a.eps;
-  [[maybe_unused]] const double edelta = ELASTIC ? a.elastic_delta : 0.0;
+  [[maybe_unused]] const double edelta0 = ELASTIC ? a.elastic_delta : 0.0;
+  // |g_r|^2 of row r (solve_3d.cc:823-888: t c_i ; 5 (c_i+1 - c_i) ; 20 (1, -2, 1) ; 60 (-1, 3, -3, 1))
+#define ROW_N2(r) ((r) < 6 ? t2 : (r) < 11 ? 50.0 : (r) < 15 ? 2400.0 : 72000.0)
+#define ED(r) (edelta0 * ROW_N2(r))
   const double inv_m = 1.0 / ((double)(2 * NR) * (double)S);
 
   // ---- everything that belongs to the candidate a group is solving (set by begin_candidate) ----
@@ -293,6 +320,33 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   double q[6], Xinit[3], Pk[21], qn = 0.0, bnorm = 0.0;
   bool infeasible_bounds = false, no_solution = false;
   double X[3] = {0.0, 0.0, 0.0}, Xcold0 = 0.0, sl[NR], su[NR];
+  // split form: this lane's five rows -- slacks, multipliers, bounds -- and where the lanes of its segment sit
+  [[maybe_unused]] double sl5[5], su5[5], ll5[5], lu5[5], lo5[5], up5[5];
+  [[maybe_unused]] const int sj = gl;                         // which third of the rows
+  [[maybe_unused]] const int Lj[3] = {k, S + k, 2 * S + k};   // lanes (0, k), (1, k), (2, k)
+  // (two flags the optimiser cannot trace back to one index: it otherwise turns every three-way choice into an array
+  //  on the stack indexed by j -- scratch loads in the middle of every row pass)
+  [[maybe_unused]] int sjf0 = sj == 0, sjf1 = sj == 1;
+  asm volatile("" : "+v"(sjf0), "+v"(sjf1));
+  [[maybe_unused]] const bool sj0 = sjf0 != 0, sj1 = sjf1 != 0;
+#define SEL3(x0, x1, x2) (sj0 ? (x0) : sj1 ? (x1) : (x2))
+  // values of the lane's five rows for control points c (the expressions of row_dot, on the lane's window c[j..j+3])
+  [[maybe_unused]] auto slot_vals = [&](const double (&cc_)[6], double (&v)[5]) {
+    // (values pinned in registers first: a choice between elements of an array in memory becomes a load from a chosen
+    //  address, and the array then lives in scratch)
+    double c_[6];
+    UNROLL for (int i = 0; i < 6; i++) c_[i] = cc_[i];
+    opaque6(c_);
+    const double w0 = SEL3(c_[0], c_[1], c_[2]), w1 = SEL3(c_[1], c_[2], c_[3]), w2 = SEL3(c_[2], c_[3], c_[4]), w3 = SEL3(c_[3], c_[4], c_[5]);
+    v[0] = 60.0 * ((w3 - w0) + 3.0 * (w1 - w2));            // jerk row 15 + j
+    v[1] = 20.0 * ((w1 - 2.0 * w2) + w3);                   // acceleration row 12 + j
+    v[2] = 5.0 * (w2 - w1);                                 // velocity row 7 + j
+    v[3] = t * SEL3(c_[1], c_[3], c_[5]);                   // position rows 1, 3, 5
+    const double pv = t * (sj0 ? c_[2] : c_[4]), vv = 5.0 * (c_[5] - c_[4]);
+    v[4] = SEL3(pv, pv, vv);                                // position rows 2, 4; velocity row 10
+  };
+  // scalar `base + slot` of row r of this lane's segment, as published by the lane that owns the row
+#define XR(base, r) lds[L_XCH + (base) + split_owner_slot(r)][Lj[split_owner_j(r)]]
   bool warm_started = false, restarted = true;   // a warm-started group that stalls gets ONE cold restart
   int it0 = 0;                                   // iteration at which the current start was made
   double best_score = 1e300, Xb[3] = {0.0, 0.0, 0.0};
@@ -328,11 +382,20 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(X[i]); Xp[i] = first ? Xinit[i] : v; }
     U_apply(nm, Xp, c[0], c[1], c[2]);
     V_apply(nm, X, c[3], c[4], c[5]);
-    FOR_ROWS(r)
-      const double gc_r = row_dot<r>(c, t);
-      sl[SI(r)] = fmax(gc_r - LO(r), 1.0); su[SI(r)] = fmax(UP(r) - gc_r, 1.0);
-      LL(r) = 1.0; LU(r) = 1.0;
-    END_ROWS
+    if constexpr (SPLIT) {
+      double v5[5];
+      slot_vals(c, v5);
+      UNROLL for (int i = 0; i < 5; i++) {
+        sl5[i] = fmax(v5[i] - lo5[i], 1.0); su5[i] = fmax(up5[i] - v5[i], 1.0);
+        ll5[i] = 1.0; lu5[i] = 1.0;
+      }
+    } else {
+      FOR_ROWS(r)
+        const double gc_r = row_dot<r>(c, t);
+        sl[SI(r)] = fmax(gc_r - LO(r), 1.0); su[SI(r)] = fmax(UP(r) - gc_r, 1.0);
+        LL(r) = 1.0; LU(r) = 1.0;
+      END_ROWS
+    }
   };
 
   // What a lane reads of its candidate: its segment's fields for the wavefront's axis and the candidate's per-axis
@@ -412,6 +475,12 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         if (mplo > mphi && !(mplo > mphi + ptol)) { mplo = 0.5 * (mplo + mphi); mphi = mplo; }
         if (mvlo > mvhi && !(mvlo > mvhi + vtol)) { mvlo = 0.5 * (mvlo + mvhi); mvhi = mvlo; }
       }
+    }
+    if constexpr (SPLIT) {   // bounds of this lane's five rows (split_owner_*)
+      lo5[0] = LO(15); up5[0] = UP(15); lo5[1] = LO(12); up5[1] = UP(12);
+      lo5[2] = SEL3(LO(7), LO(8), LO(9)); up5[2] = SEL3(UP(7), UP(8), UP(9));
+      lo5[3] = SEL3(LO(1), LO(3), LO(5)); up5[3] = SEL3(UP(1), UP(3), UP(5));
+      lo5[4] = SEL3(LO(2), LO(4), LO(10)); up5[4] = SEL3(UP(2), UP(4), UP(10));
     }
     t3 = t * t * t; it3 = it * it * it; t2 = t * t;
     pend = last ? 2.0 * (axis == 0 ? sh.weight_end_s : sh.weight_end_l) * t2 : 0.0;  // :164-168
@@ -548,16 +617,24 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         UNROLL for (int j = 0; j < 6; j++) s += HSYM(Pm, i, j) * c[j];
         obj += c[i] * (0.5 * s + q[i]);
       }
-      // rescue pass: largest violation of an original row by the returned control points
-      double viol = 0.0;
+      // rescue pass: largest violation of an original row by the returned control points -- in the row's own unit
+      // (viol) and per class of rows (position, velocity, acceleration, jerk: vcls), and in the unit of the penalty,
+      // divided by |g_r| (vnorm): the acceptance test below is on the latter
+      double viol = 0.0, vnorm = 0.0;
+      [[maybe_unused]] double vcls[4] = {0.0, 0.0, 0.0, 0.0};
       if constexpr (ELASTIC) {
+        const double inorm[4] = {it, 0.1414213562373095, 0.02041241452319315, 0.003726779962499649};   // 1 / |g_r|
         FOR_ROWS(r)
+          constexpr int cls = r < 6 ? 0 : r < 11 ? 1 : r < 15 ? 2 : 3;
           const double gcr = row_dot<r>(c, t);
-          viol = fmax(viol, fmax(LO(r) - gcr, gcr - UP(r)));
+          const double v = fmax(LO(r) - gcr, gcr - UP(r));
+          viol = fmax(viol, v); vcls[cls] = fmax(vcls[cls], v); vnorm = fmax(vnorm, v * inorm[cls]);
         END_ROWS
       }
-      const Red4 ro = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, obj, viol, 0.0, 0.0);
-      if (valid) {
+      const Red4 ro = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, obj, viol, vnorm, 0.0);
+      [[maybe_unused]] Red4 rv = {0.0, 0.0, 0.0, 0.0};
+      if constexpr (ELASTIC) rv = group_reduce<1, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, vcls[0], vcls[1], vcls[2], vcls[3]);
+      if (valid && (!SPLIT || g == 0)) {
         // control points in the reference's order: s axis (6 S), then l axis (6 S); rows are 12*seg_stride apart
         double *dst = a.ctrl + (size_t)b * 12 * a.seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
         UNROLL for (int i = 0; i < 6; i++) dst[i] = c[i];
@@ -570,9 +647,15 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
           if constexpr (ELASTIC) {
             // converged on the relaxed problem: feasible after all (rows kept to 1e-7) -> as solved; least violation
             // within the caller's tolerance -> the reference's "solved inaccurate"; beyond it -> infeasible
-            if (st > 0 && ro.b > 1e-7 * (1.0 + bnorm)) st = ro.b <= a.elastic_tol ? BTRAPZ_SOLVED_INACCURATE : BTRAPZ_PRIMAL_INFEASIBLE;
+            if (st > 0 && ro.b > 1e-7 * (1.0 + bnorm)) st = ro.c <= a.elastic_tol ? BTRAPZ_SOLVED_INACCURATE : BTRAPZ_PRIMAL_INFEASIBLE;
           }
           const long long prob = 2LL * b + axis;
+          if constexpr (ELASTIC) {
+            if (a.axis_viol) {   // per class of rows, in the rows' own units (0 where the rows hold)
+              double *vo = a.axis_viol + prob * 4;
+              vo[0] = fmax(rv.a, 0.0); vo[1] = fmax(rv.b, 0.0); vo[2] = fmax(rv.c, 0.0); vo[3] = fmax(rv.d, 0.0);
+            }
+          }
           a.axis_obj[prob] = ro.a;
           a.axis_status[prob] = st;
           a.axis_iters[prob] = ELASTIC ? iters + a.axis_iters[prob] + 1 : iters;   // rescue: on top of the first attempt's
@@ -592,7 +675,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   if constexpr (QUEUE) {
     if (first && lane_in_group) next_cand = atomicAdd(a.queue + axis, 1);
   } else {
-    long long cand = (long long)pair * gpw + gl;
+    long long cand = SPLIT ? (long long)pair : (long long)pair * gpw + gl;
     const bool valid0 = lane_in_group && cand < ncand;
     if (cand >= ncand) cand = ncand - 1;
     const int b0 = ORDERED ? a.order[cand0 + (int)cand] : (int)cand;
@@ -623,7 +706,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     // Row residuals r_l = G c - s_l - l, r_u = G c + s_u - u: constant within an iteration and needed by six row
     // loops.  Cached (36 doubles; the allocator parks them in AGPRs) they save ~100 instructions per row loop:
     // 6.29 -> 6.04 ms.  The warm-start instantiations carry more state and would spill, so they recompute.
-    double c[6], gc[6], rpl_[CACHE_RP ? NR : 1], rpu_[CACHE_RP ? NR : 1];
+    double c[6], gc[6], rpl_[(CACHE_RP && !SPLIT) ? NR : 1], rpu_[(CACHE_RP && !SPLIT) ? NR : 1];
+    [[maybe_unused]] double rpl5[5], rpu5[5], isl5[5], isu5[5];   // split form: residuals and reciprocal slacks of the own rows
     double mu_part = 0.0, rp_part = 0.0, dscale = 0.0;
     {
       double Xp[3];
@@ -631,16 +715,41 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       U_apply(nm, Xp, c[0], c[1], c[2]);
       V_apply(nm, X, c[3], c[4], c[5]);
       UNROLL for (int i = 0; i < 6; i++) gc[i] = 0.0;
+      if constexpr (SPLIT) {
+        // own rows: residuals, reciprocal slacks, and the three scalars per row the segment's gradient, Newton block and
+        // predictor right-hand side are made of -- published, then gathered by every lane of the segment
+        double v5[5];
+        slot_vals(c, v5);
+        wave_lds_sync();
+        UNROLL for (int i = 0; i < 5; i++) {
+          rpl5[i] = v5[i] - sl5[i] - lo5[i]; rpu5[i] = v5[i] + su5[i] - up5[i];
+          rp_part = fmax(rp_part, fmax(fabs(rpl5[i]), fabs(rpu5[i])));
+          mu_part += sl5[i] * ll5[i] + su5[i] * lu5[i];
+          isl5[i] = rcp(sl5[i]); isu5[i] = rcp(su5[i]);
+          const double wl = ll5[i] * isl5[i], wu = lu5[i] * isu5[i];
+          lds[L_XCH + i][lane] = lu5[i] - ll5[i];
+          lds[L_XCH + 5 + i][lane] = wl + wu;
+          lds[L_XCH + 10 + i][lane] = wl * (sl5[i] + rpl5[i]) - wu * (su5[i] - rpu5[i]);
+        }
+        lds[L_XCH + 15][lane] = mu_part; lds[L_XCH + 16][lane] = rp_part;
+        wave_lds_sync();
+        FOR_ROWS(r)
+          row_scatter<r>(XR(0, r), t, gc);
+        END_ROWS
+        mu_part = (lds[L_XCH + 15][Lj[0]] + lds[L_XCH + 15][Lj[1]]) + lds[L_XCH + 15][Lj[2]];
+        rp_part = fmax(fmax(lds[L_XCH + 16][Lj[0]], lds[L_XCH + 16][Lj[1]]), lds[L_XCH + 16][Lj[2]]);
+      } else {
       FOR_ROWS(r)
         const double ll = LL(r), lu = LU(r);
         double gcr = row_dot<r>(c, t);
-        if constexpr (ELASTIC) gcr -= edelta * (lu - ll);
+        if constexpr (ELASTIC) gcr -= ED(r) * (lu - ll);
         const double rpl = gcr - sl[SI(r)] - LO(r), rpu = gcr + su[SI(r)] - UP(r);
         if constexpr (CACHE_RP) { rpl_[CACHE_RP ? SI(r) : 0] = rpl; rpu_[CACHE_RP ? SI(r) : 0] = rpu; }
         rp_part = fmax(rp_part, fmax(fabs(rpl), fabs(rpu)));
         mu_part += sl[SI(r)] * ll + su[SI(r)] * lu;
         row_scatter<r>(lu - ll, t, gc);
       END_ROWS
+      }
       UNROLL for (int i = 0; i < 6; i++) dscale = fmax(dscale, fabs(gc[i]));
       double Pm[21];
       UNROLL for (int i_ = 0; i_ < 21; i_++) Pm[i_] = Pk[i_];
@@ -734,6 +843,12 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // needs exactly what this loop has in its hands -- the fresh reciprocals, the multipliers, G c -- so it is
       // accumulated here instead of in a row loop of its own (one pass over the rows and 72 LDS reads less).
       UNROLL for (int i = 0; i < 6; i++) hp[i] = gc[i];
+      if constexpr (SPLIT) {
+        FOR_ROWS(r)
+          row_outer<r>(XR(5, r), t2, H);
+          row_scatter<r>(XR(10, r), t, hp);
+        END_ROWS
+      } else {
       FOR_ROWS(r)
         const double isl = rcp(sl[SI(r)]), isu = rcp(su[SI(r)]);
         const double ll = LL(r), lu = LU(r);
@@ -743,11 +858,11 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         if constexpr (CACHE_RP) { rpl = rpl_[CACHE_RP ? SI(r) : 0]; rpu = rpu_[CACHE_RP ? SI(r) : 0]; }
         else {
           double gcr = row_dot<r>(c, t);
-          if constexpr (ELASTIC) gcr -= edelta * (lu - ll);
+          if constexpr (ELASTIC) gcr -= ED(r) * (lu - ll);
           rpl = gcr - sl[SI(r)] - LO(r); rpu = gcr + su[SI(r)] - UP(r);
         }
         if constexpr (ELASTIC) {
-          const double ef = rcp(1.0 + edelta * (wl + wu));
+          const double ef = rcp(1.0 + ED(r) * (wl + wu));
           row_outer<r>((wl + wu) * ef, t2, H);
           row_scatter<r>((wl * (sl[SI(r)] + rpl) - wu * (su[SI(r)] - rpu)) * ef, t, hp);
         } else {
@@ -755,6 +870,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
           row_scatter<r>(wl * (sl[SI(r)] + rpl) - wu * (su[SI(r)] - rpu), t, hp);
         }
       END_ROWS
+      }
       reduce_rhs(hp, up);
       double w0[3], w1[3], w2[3], col[3], M00[6];
       // M00 = U' H00 U
@@ -910,14 +1026,84 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       if constexpr (CACHE_RP) { rpl = rpl_[CACHE_RP ? SI(r) : 0]; rpu = rpu_[CACHE_RP ? SI(r) : 0]; }                  \
       else {                                                                                        \
         double gcr = row_dot<r>(c, t);                                                              \
-        if constexpr (ELASTIC) gcr -= edelta * (lu - ll);                                           \
+        if constexpr (ELASTIC) gcr -= ED(r) * (lu - ll);                                           \
         rpl = gcr - sl[SI(r)] - LO(r); rpu = gcr + su[SI(r)] - UP(r);                                       \
       }
     // elastic rows: the step of the row value, g' dc -> (g' dc - delta b) / (1 + delta w)
-#define ROW_STEP(gd, b) (ELASTIC ? ((gd) - edelta * (b)) * rcp(1.0 + edelta * (ll * isl + lu * isu)) : (gd))
+#define ROW_STEP(r, gd, b) (ELASTIC ? ((gd) - ED(r) * (b)) * rcp(1.0 + ED(r) * (ll * isl + lu * isu)) : (gd))
 
     double dca[6], dX[3];
     double sigma_mu, second_order;   // second_order: -1, or 0 when the corrector leaves that term out (below)
+    if constexpr (SPLIT) {
+      // The same predictor / corrector / step as below (see the comments there) on the lane's own five rows; what a
+      // row contributes to a right-hand side, and the statistics of the three lanes of a segment, go through LDS.
+      backward_u(up, dX, dca);
+      double ga5[5];
+      slot_vals(dca, ga5);
+      double qmin = 0.0, qmax = -1.0, S1 = 0.0, S4 = 0.0;
+      UNROLL for (int i = 0; i < 5; i++) {
+        const double dsl = ga5[i] + rpl5[i], dsu = -ga5[i] - rpu5[i];
+        const double ql = dsl * isl5[i], qu = dsu * isu5[i];
+        qmin = fmin(qmin, fmin(ql, qu)); qmax = fmax(qmax, fmax(ql, qu));
+        const double al = ll5[i] * dsl, au = lu5[i] * dsu;
+        S1 += al + au;
+        S4 += al * ql + au * qu;
+      }
+      wave_lds_sync();
+      lds[L_XCH + 0][lane] = S1; lds[L_XCH + 1][lane] = S4; lds[L_XCH + 2][lane] = qmax; lds[L_XCH + 3][lane] = qmin;
+      wave_lds_sync();
+      S1 = (lds[L_XCH + 0][Lj[0]] + lds[L_XCH + 0][Lj[1]]) + lds[L_XCH + 0][Lj[2]];
+      S4 = (lds[L_XCH + 1][Lj[0]] + lds[L_XCH + 1][Lj[1]]) + lds[L_XCH + 1][Lj[2]];
+      qmax = fmax(fmax(lds[L_XCH + 2][Lj[0]], lds[L_XCH + 2][Lj[1]]), lds[L_XCH + 2][Lj[2]]);
+      qmin = fmin(fmin(lds[L_XCH + 3][Lj[0]], lds[L_XCH + 3][Lj[1]]), lds[L_XCH + 3][Lj[2]]);
+      const Red4 ra = group_reduce<0, 0, 1, 2>(lds + L_RED, lane, gbase, k, S, S1, S4, qmax, qmin);
+      const double ap = 1.0 / fmax(-ra.d, 1.0), ad = 1.0 / fmax(1.0 + ra.c, 1.0);
+      const double mua = ((1.0 - ad) * rr.a + (ap - ad - ap * ad) * ra.a - ap * ad * ra.b) * inv_m;
+      const double sr = mua / mu;
+      sigma_mu = sr * sr * sr * mu;
+      second_order = (plain && fmin(ap, ad) < 0.1) ? 0.0 : -1.0;
+      // corrector
+      double el5[5], eu5[5], h[6], dc[6];
+      wave_lds_sync();
+      UNROLL for (int i = 0; i < 5; i++) {
+        const double dsa = ga5[i] + rpl5[i], dua = -ga5[i] - rpu5[i];
+        const double rcl = __builtin_fma(second_order, (ll5[i] * dsa) * (1.0 + dsa * isl5[i]), __builtin_fma(sl5[i], ll5[i], -sigma_mu));
+        const double rcu = __builtin_fma(second_order, (lu5[i] * dua) * (1.0 + dua * isu5[i]), __builtin_fma(su5[i], lu5[i], -sigma_mu));
+        el5[i] = rcl * isl5[i]; eu5[i] = rcu * isu5[i];
+        lds[L_XCH + i][lane] = (el5[i] - eu5[i]) + ((ll5[i] * isl5[i]) * rpl5[i] + (lu5[i] * isu5[i]) * rpu5[i]);
+      }
+      wave_lds_sync();
+      UNROLL for (int i = 0; i < 6; i++) h[i] = gc[i];
+      FOR_ROWS(r)
+        row_scatter<r>(XR(0, r), t, h);
+      END_ROWS
+      solve_dc(h, dX, dc);
+      // step to the boundary
+      double gd5[5], dsl5[5], dsu5[5], dll5[5], dlu5[5], pr = 0.0, dr = 0.0;
+      slot_vals(dc, gd5);
+      UNROLL for (int i = 0; i < 5; i++) {
+        dsl5[i] = gd5[i] + rpl5[i]; dsu5[i] = -gd5[i] - rpu5[i];
+        dll5[i] = -el5[i] - (ll5[i] * isl5[i]) * dsl5[i]; dlu5[i] = -eu5[i] - (lu5[i] * isu5[i]) * dsu5[i];
+        pr = fmax(pr, fmax(-dsl5[i] * isl5[i], -dsu5[i] * isu5[i]));
+        dr = fmax(dr, fmax(-dll5[i] * rcp_fast(ll5[i]), -dlu5[i] * rcp_fast(lu5[i])));
+      }
+      wave_lds_sync();
+      lds[L_XCH + 0][lane] = pr; lds[L_XCH + 1][lane] = dr;
+      wave_lds_sync();
+      pr = fmax(fmax(lds[L_XCH + 0][Lj[0]], lds[L_XCH + 0][Lj[1]]), lds[L_XCH + 0][Lj[2]]);
+      dr = fmax(fmax(lds[L_XCH + 1][Lj[0]], lds[L_XCH + 1][Lj[1]]), lds[L_XCH + 1][Lj[2]]);
+      const Red4 rb = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, 0.0, pr, dr, 0.0);
+      const double m_ = fmax(rb.b, rb.c);
+      const double tau = (m_ * a.tau_thr <= 1.0 && eit - it0 < a.tau_iters) ? a.tau : fmin(a.tau, 0.995);
+      const double alpha = fmin(1.0, tau / fmax(m_, tau));
+      if (!done && alpha == alpha) {
+        UNROLL for (int i = 0; i < 3; i++) X[i] += alpha * dX[i];
+        UNROLL for (int i = 0; i < 5; i++) {
+          sl5[i] += alpha * dsl5[i]; su5[i] += alpha * dsu5[i];
+          ll5[i] += alpha * dll5[i]; lu5[i] += alpha * dlu5[i];
+        }
+      }
+    } else {
     {
       // predictor.  rc = s*lambda  ->  tv = lambda_l (s_l + rp_l)/s_l - lambda_u (s_u - rp_u)/s_u
       backward_u(up, dX, dca);   // right-hand side from the Newton-matrix loop, forward sweep done in the factorisation loop
@@ -929,7 +1115,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       ROW_PREFETCH();
       FOR_ROWS(r)
         ROW_BASE(r)
-        const double gd = ROW_STEP(row_dot<r>(dca, t), (ll - lu) + (ll * isl) * rpl + (lu * isu) * rpu);
+        const double gd = ROW_STEP(r, row_dot<r>(dca, t), (ll - lu) + (ll * isl) * rpl + (lu * isu) * rpu);
         const double dsl = gd + rpl, dsu = -gd - rpu;
         const double ql = dsl * isl, qu = dsu * isu;
         qmin = fmin(qmin, fmin(ql, qu)); qmax = fmax(qmax, fmax(ql, qu));
@@ -955,7 +1141,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     {
       // corrector.  rc = s*lambda + [ds_aff*dlambda_aff] - sigma*mu , dlambda_aff = -lambda (1 + ds_aff/s)
 #define ROW_CORR(r)                                                                               \
-      const double ga = ROW_STEP(row_dot<r>(dca, t), (ll - lu) + (ll * isl) * rpl + (lu * isu) * rpu); \
+      const double ga = ROW_STEP(r, row_dot<r>(dca, t), (ll - lu) + (ll * isl) * rpl + (lu * isu) * rpu); \
       const double dsa = ga + rpl, dua = -ga - rpu;                                                 \
       const double rcl = __builtin_fma(second_order, (ll * dsa) * (1.0 + dsa * isl), __builtin_fma(sl[SI(r)], ll, -sigma_mu)); \
       const double rcu = __builtin_fma(second_order, (lu * dua) * (1.0 + dua * isu), __builtin_fma(su[SI(r)], lu, -sigma_mu)); \
@@ -969,7 +1155,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         ROW_BASE(r)
         ROW_CORR(r)
         el_[SI(r)] = el; eu_[SI(r)] = eu;
-        if constexpr (ELASTIC) row_scatter<r>(((el - eu) + (wl * rpl + wu * rpu)) * rcp(1.0 + edelta * (wl + wu)), t, h);
+        if constexpr (ELASTIC) row_scatter<r>(((el - eu) + (wl * rpl + wu * rpu)) * rcp(1.0 + ED(r) * (wl + wu)), t, h);
         else row_scatter<r>((el - eu) + (wl * rpl + wu * rpu), t, h);
       END_ROWS
       solve_dc(h, dX, dc);
@@ -979,7 +1165,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       ROW_PREFETCH();
       FOR_ROWS(r)
         ROW_BASE(r)
-        const double gd = ROW_STEP(row_dot<r>(dc, t), (el_[SI(r)] - eu_[SI(r)]) + (ll * isl) * rpl + (lu * isu) * rpu);
+        const double gd = ROW_STEP(r, row_dot<r>(dc, t), (el_[SI(r)] - eu_[SI(r)]) + (ll * isl) * rpl + (lu * isu) * rpu);
         const double dsl = gd + rpl, dsu = -gd - rpu;
         const double dll = -el_[SI(r)] - (ll * isl) * dsl, dlu = -eu_[SI(r)] - (lu * isu) * dsu;
         pr = fmax(pr, fmax(-dsl * isl, -dsu * isu));
@@ -999,7 +1185,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         ROW_PREFETCH();
         FOR_ROWS(r)
           ROW_BASE(r)
-          const double gd = ROW_STEP(row_dot<r>(dc, t), (el_[SI(r)] - eu_[SI(r)]) + (ll * isl) * rpl + (lu * isu) * rpu);
+          const double gd = ROW_STEP(r, row_dot<r>(dc, t), (el_[SI(r)] - eu_[SI(r)]) + (ll * isl) * rpl + (lu * isu) * rpu);
           const double dsl = gd + rpl, dsu = -gd - rpu;
           sl[SI(r)] += alpha * dsl; su[SI(r)] += alpha * dsu;
           LL(r) = ll + alpha * (-el_[SI(r)] - (ll * isl) * dsl); LU(r) = lu + alpha * (-eu_[SI(r)] - (lu * isu) * dsu);
@@ -1007,6 +1193,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       }
 #undef ROW_CORR
     }
+    }   // (!SPLIT)
 #undef ROW_BASE
 #undef ROW_STEP
 #undef ROW_PREFETCH
@@ -1039,6 +1226,12 @@ __global__ __launch_bounds__(64) void ipm_solve_queue_kernel(const KernelArgs a,
   __shared__ double lds[lds_rows<false>()][64];
   ipm_solve_body<false, false, false, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
+// Few candidates (fewer axis problems than SIMDs), at most 21 segments: one candidate per wavefront, its rows split over
+// three lane groups (SPLIT above).  Wavefront w: axis w & 1 of candidate w >> 1.
+__global__ __launch_bounds__(64) void ipm_solve_split_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  __shared__ double lds[21][64];
+  ipm_solve_body<false, false, false, false, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
+}
 // Rescue pass (btrapz_options.elastic): the stalled axis problems, listed per axis, with elastic rows.
 __global__ __launch_bounds__(64) void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[lds_rows<true>()][64];
@@ -1070,6 +1263,7 @@ __global__ void rescue_init_kernel(int B, int S, const int *seg_count, double *a
 // thread = (axis, derivative d, packed upper-triangle entry): out[axis][d][SYM(i, j)].  pQp_d(a, b) = w_d * prod_{r<d}
 // (a - r)(b - r) / (a + b - 2d + 1) for a, b >= d (:87-113); M = Bernstein -> monomial (:122-127).
 __global__ void mqm_table_kernel(MqmWeights w, double *out) {
+#pragma clang fp contract(off)   // same expressions, same rounding as btrapz_mqm_table_host (find_traj's table)
   const int id = threadIdx.x;
   if (id >= 168) return;
   const int axis = id / 84, d = (id % 84) / 21, e = id % 21;
@@ -1090,6 +1284,14 @@ __global__ void mqm_table_kernel(MqmWeights w, double *out) {
     acc += M[a][i] * t;
   }
   out[id] = acc;
+}
+
+// viol[b][c] = the larger of the two axes' class-c violation (btrapz_rescue_violations_device)
+__global__ void rescue_violations_kernel(int B, const double *axis_viol, double *viol) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * B) return;
+  const int b = i >> 2, c = i & 3;
+  viol[i] = fmax(axis_viol[(size_t)(2 * b) * 4 + c], axis_viol[(size_t)(2 * b + 1) * 4 + c]);
 }
 
 __global__ void finalize_kernel(int B, const double *axis_obj, const int *axis_status, const int *axis_iters,
@@ -1125,15 +1327,16 @@ __device__ __forceinline__ void argmin_block_reduce(double &bc, long long &bi, d
   }
   bc = sc[0]; bi = si[0];
 }
-// grid = (chunks, groups); chunks == 1: writes the result; else partial results part_cost / part_idx [groups][chunks]
+// grid = (groups, chunks) -- groups in x: there may be millions of them, chunks are at most 256; chunks == 1: writes
+// the result; else partial results part_cost / part_idx [groups][chunks]
 __global__ __launch_bounds__(256) void argmin_kernel(int group, long long index_base, const double *cost,
                                                       long long *best_idx, double *best_cost, double *part_cost,
                                                       long long *part_idx) {
   __shared__ double sc[256];
   __shared__ long long si[256];
-  const long long g = blockIdx.y;
-  const int chunks = gridDim.x, per = (group + chunks - 1) / chunks;
-  const int lo = blockIdx.x * per, hi = lo + per < group ? lo + per : group;
+  const long long g = blockIdx.x;
+  const int chunks = gridDim.y, chunk = blockIdx.y, per = (group + chunks - 1) / chunks;
+  const int lo = chunk * per, hi = lo + per < group ? lo + per : group;
   double bc = __builtin_huge_val();
   long long bi = -1;
   for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) {
@@ -1143,7 +1346,7 @@ __global__ __launch_bounds__(256) void argmin_kernel(int group, long long index_
   argmin_block_reduce(bc, bi, sc, si);
   if (threadIdx.x == 0) {
     if (chunks == 1) { best_idx[g] = bi >= 0 ? bi + index_base : -1; best_cost[g] = bc; }
-    else { part_cost[g * chunks + blockIdx.x] = bc; part_idx[g * chunks + blockIdx.x] = bi; }
+    else { part_cost[g * chunks + chunk] = bc; part_idx[g * chunks + chunk] = bi; }
   }
 }
 __global__ __launch_bounds__(256) void argmin_final_kernel(int chunks, long long index_base, const double *part_cost,
@@ -1218,40 +1421,44 @@ __global__ void eval_states_kernel(int B, int seg_stride, const int *seg_count, 
 
 // ---- Bernstein sampling of selected candidates (solve_3d.cc:1279-1392) ---------------------
 // Samples of candidate b, written by threads tid, tid + nthreads, ...; returns the sample count.
-__device__ __forceinline__ int sample_candidate(int B, int seg_stride, int S, double delta, const double *seg,
+// tt: the candidate's S segment durations (the single-candidate launch passes a copy in LDS: its seg lives in host
+// memory mapped into the device, and the loops below would cross PCIe once per segment -- 40 us of a 170 us call).
+__device__ __forceinline__ int sample_candidate(int seg_stride, int S, double delta, const double *tt,
                                                 const double *init, const double *ctrl, long long b, int max_points,
                                                 double *o, int tid, int nthreads) {
-  const size_t BS = (size_t)B * seg_stride;
   // num_of_points_: int accumulated with += double (solve_3d.cc:1279-1282)
   int np = 1;
-  for (int k = 0; k < S; k++) np = (int)((double)np + seg[BTRAPZ_F_T * BS + b * seg_stride + k] / delta);
+  for (int k = 0; k < S; k++) np = (int)((double)np + tt[k] / delta);
   if (tid == 0 && max_points > 0) {
     UNROLL for (int a = 0; a < 6; a++) o[(size_t)a * max_points] = init[b * 6 + a];
   }
   const double bc0[6] = {1, 5, 10, 10, 5, 1}, bc1[5] = {1, 4, 6, 4, 1}, bc2[4] = {1, 3, 3, 1};
-  int base = 1;
-  for (int k = 0; k < S; k++) {
-    const double t = seg[BTRAPZ_F_T * BS + b * seg_stride + k];
-    const int linter = (int)(t / delta);  // :1351
-    for (int l = 1 + tid; l <= linter; l += nthreads) {
-      const int vi = base + l - 1;
-      if (vi >= max_points) continue;
-      const double tau = (double)l / (double)linter, om = 1.0 - tau;
-      double pw[6], qw[6];
-      pw[0] = 1.0; qw[0] = 1.0;
-      UNROLL for (int i = 1; i < 6; i++) { pw[i] = pw[i - 1] * tau; qw[i] = qw[i - 1] * om; }
-      UNROLL for (int ax = 0; ax < 2; ax++) {
-        const double *c = ctrl + (size_t)b * 12 * seg_stride + (size_t)ax * 6 * S + (size_t)k * 6;
-        double x = 0, dx = 0, ddx = 0;
-        UNROLL for (int i = 0; i < 6; i++) x += c[i] * bc0[i] * pw[i] * qw[5 - i];
-        UNROLL for (int i = 0; i < 5; i++) dx += 5.0 * (c[i + 1] - c[i]) * bc1[i] * pw[i] * qw[4 - i];
-        UNROLL for (int i = 0; i < 4; i++) ddx += 20.0 * (c[i + 2] - 2.0 * c[i + 1] + c[i]) * bc2[i] * pw[i] * qw[3 - i];
-        o[(size_t)(3 * ax + 0) * max_points + vi] = x * t;
-        o[(size_t)(3 * ax + 1) * max_points + vi] = dx;
-        o[(size_t)(3 * ax + 2) * max_points + vi] = ddx / t;
-      }
+  // one sample per thread and pass: sample idx of the trajectory lies in the segment k whose samples start at `base`
+  // (the reference's loop over segments and their samples, flattened: a block that walks the segments one after the
+  // other has a tenth of its threads at work and pays one memory round trip per segment)
+  int total = 0;
+  for (int k = 0; k < S; k++) total += (int)(tt[k] / delta);
+  for (int idx = tid; idx < total; idx += nthreads) {
+    int k = 0, base = 1, linter = (int)(tt[0] / delta);  // :1351
+    while (idx >= base - 1 + linter) { base += linter; ++k; linter = (int)(tt[k] / delta); }
+    const double t = tt[k];
+    const int l = idx - (base - 1) + 1;
+    const int vi = base + l - 1;
+    if (vi >= max_points) continue;
+    const double tau = (double)l / (double)linter, om = 1.0 - tau;
+    double pw[6], qw[6];
+    pw[0] = 1.0; qw[0] = 1.0;
+    UNROLL for (int i = 1; i < 6; i++) { pw[i] = pw[i - 1] * tau; qw[i] = qw[i - 1] * om; }
+    UNROLL for (int ax = 0; ax < 2; ax++) {
+      const double *c = ctrl + (size_t)b * 12 * seg_stride + (size_t)ax * 6 * S + (size_t)k * 6;
+      double x = 0, dx = 0, ddx = 0;
+      UNROLL for (int i = 0; i < 6; i++) x += c[i] * bc0[i] * pw[i] * qw[5 - i];
+      UNROLL for (int i = 0; i < 5; i++) dx += 5.0 * (c[i + 1] - c[i]) * bc1[i] * pw[i] * qw[4 - i];
+      UNROLL for (int i = 0; i < 4; i++) ddx += 20.0 * (c[i + 2] - 2.0 * c[i + 1] + c[i]) * bc2[i] * pw[i] * qw[3 - i];
+      o[(size_t)(3 * ax + 0) * max_points + vi] = x * t;
+      o[(size_t)(3 * ax + 1) * max_points + vi] = dx;
+      o[(size_t)(3 * ax + 2) * max_points + vi] = ddx / t;
     }
-    base += linter;
   }
   return np;
 }
@@ -1266,7 +1473,8 @@ __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, doubl
   if (b < 0 || b >= B) { if (threadIdx.x == 0) npoints[j] = 0; return; }
   const int S = seg_count ? seg_count[b] : seg_stride;
   if (S < 1 || S > seg_stride) { if (threadIdx.x == 0) npoints[j] = 0; return; }
-  const int np = sample_candidate(B, seg_stride, S, delta, seg, init, ctrl, b, max_points, o, (int)threadIdx.x, (int)blockDim.x);
+  const int np = sample_candidate(seg_stride, S, delta, seg + (size_t)BTRAPZ_F_T * B * seg_stride + (size_t)b * seg_stride, init, ctrl, b,
+                                  max_points, o, (int)threadIdx.x, (int)blockDim.x);
   if (threadIdx.x == 0) npoints[j] = np;
 }
 
@@ -1277,13 +1485,16 @@ __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, doubl
 // once, results written once -- so the call needs no copy either; what the kernel reads back (control points, per-axis
 // records) lives in device memory (a.ctrl, a.axis_*).  out: [0] cost, [1] status and iterations (two ints), [2]
 // sample count (int), [3 .. 3 + 12 S) control points, then traj [6][max_points].
-template <bool WARM>
+template <bool WARM, bool SPLIT = false>
 __device__ __forceinline__ void single_candidate_body(const KernelArgs &a, const double *__restrict__ mqm, double delta,
                                                       int max_points, double *out) {
   double *res = out, *traj = out + 3 + 12 * a.S;
-  __shared__ double lds[2][lds_rows<false>()][64];
+  __shared__ double lds[2][SPLIT ? 21 : lds_rows<false>()][64];
+  __shared__ double tseg[64], init6[6];   // what the sampling reads of the inputs (see sample_candidate)
+  if ((int)threadIdx.x < a.S) tseg[threadIdx.x] = a.seg[(size_t)BTRAPZ_F_T * a.seg_stride + threadIdx.x];
+  if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 70) init6[threadIdx.x - 64] = a.init[threadIdx.x - 64];
   const int w = (int)threadIdx.x >> 6;
-  ipm_solve_body<WARM, false>(a, mqm, lds[w], w, (int)threadIdx.x & 63);
+  ipm_solve_body<WARM, false, false, false, SPLIT>(a, mqm, lds[w], w, (int)threadIdx.x & 63);
   __threadfence_block();
   __syncthreads();
   const int s0 = a.axis_status[0], s1 = a.axis_status[1];
@@ -1293,7 +1504,7 @@ __device__ __forceinline__ void single_candidate_body(const KernelArgs &a, const
   else st = s0 < s1 ? s0 : s1;
   const double c = a.axis_obj[0] + a.axis_obj[1];
   int np = 0;
-  if (st > 0) np = sample_candidate(1, a.seg_stride, a.S, delta, a.seg, a.init, a.ctrl, 0, max_points, traj, (int)threadIdx.x, 128);
+  if (st > 0) np = sample_candidate(a.seg_stride, a.S, delta, tseg, init6, a.ctrl, 0, max_points, traj, (int)threadIdx.x, 128);
   for (int i = (int)threadIdx.x; i < 12 * a.S; i += 128) out[3 + i] = a.ctrl[i];
   if (threadIdx.x == 0) {
     res[0] = (st > 0 && c == c) ? c : __builtin_huge_val();
@@ -1305,6 +1516,11 @@ __device__ __forceinline__ void single_candidate_body(const KernelArgs &a, const
 __global__ __launch_bounds__(128) void single_candidate_kernel(const KernelArgs a, const double *__restrict__ mqm,
                                                                double delta, int max_points, double *out) {
   single_candidate_body<false>(a, mqm, delta, max_points, out);
+}
+// ... at most 21 segments: the rows of every segment spread over three lanes (SPLIT in ipm_solve_body)
+__global__ __launch_bounds__(128) void single_candidate_split_kernel(const KernelArgs a, const double *__restrict__ mqm,
+                                                                     double delta, int max_points, double *out) {
+  single_candidate_body<false, true>(a, mqm, delta, max_points, out);
 }
 // ... starting from the joint states and multipliers the previous call left on the device (find_traj in a replanning
 // loop, BTRAPZ_WARM=1), and leaving its own for the next one

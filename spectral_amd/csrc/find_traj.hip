@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -31,11 +32,12 @@ const char *kDefaultInput[2] = {"/home/srujan_d/RISS/code/btrapz/src/c_road_s1_2
 const char *kDefaultOutputPrefix[2] = {"/home/srujan_d/RISS/code/btrapz/src/s1_slt_3d_",
                                        "/home/srujan_d/RISS/code/btrapz/src/s1_cub_3d_"};
 
-// find_traj is re-entrant and concurrent: every calling thread gets, on its first call, a context, a stream and the
-// buffers of its own (a btrapz_ctx serves one launch sequence at a time), so concurrent callers -- e.g. parallel Optuna
-// trials of the harness -- neither queue behind a lock nor behind each other on the device's null stream.  The objects
-// live as long as the process (a thread pool's threads come and go rarely; nothing is torn down at thread exit, when the
-// HIP runtime may already be gone).
+// find_traj is re-entrant and concurrent: every calling thread holds, while it lives, a context, a stream and buffers
+// of its own (a btrapz_ctx serves one launch sequence at a time), so concurrent callers -- e.g. parallel Optuna trials of
+// the harness -- neither queue behind a lock nor behind each other on the device's null stream.  A thread that exits
+// hands its set back to a pool (no HIP call at thread exit, when the runtime may already be gone) and the next new
+// thread takes it over: a harness that starts a thread per trial holds as many sets as it has threads alive at once,
+// not one per thread it ever started.
 struct Caller {
   btrapz_ctx *ctx = nullptr;
   hipStream_t stream = nullptr;
@@ -43,28 +45,54 @@ struct Caller {
   size_t pinned_bytes = 0;
   void *scratch = nullptr;                         // device block of the rescue attempt
   size_t scratch_bytes = 0;
-  int last_iters = -1;                             // interior-point iterations of this thread's last call
+  int device = 0;
 };
+// What btrapz_find_traj_last_iterations / _last_status report: per thread, and no reason to create a context.
+struct LastCall { int iters = -1; int status = 0; double viol[4] = {0.0, 0.0, 0.0, 0.0}; };
+thread_local LastCall t_last;
 std::mutex g_callers_mutex;
-std::vector<Caller *> g_callers;     // (kept reachable for leak checkers)
+std::vector<Caller *> g_idle_callers;   // sets whose thread has exited
+
+struct CallerHolder {
+  Caller *c = nullptr;
+  ~CallerHolder() {
+    if (!c) return;
+    std::lock_guard<std::mutex> lk(g_callers_mutex);
+    g_idle_callers.push_back(c);
+  }
+};
 
 Caller *this_caller() {
-  thread_local Caller *me = nullptr;
-  if (!me) {
-    Caller *c = new Caller();
+  thread_local CallerHolder me;
+  if (!me.c) {
     const char *dev = getenv("BTRAPZ_DEVICE");
-    if (btrapz_create(&c->ctx, dev ? atoi(dev) : 0) != BTRAPZ_OK) { delete c; return nullptr; }
+    const int device = dev ? atoi(dev) : 0;
+    {
+      std::lock_guard<std::mutex> lk(g_callers_mutex);
+      for (size_t i = 0; i < g_idle_callers.size(); i++)
+        if (g_idle_callers[i]->device == device) {
+          me.c = g_idle_callers[i];
+          g_idle_callers.erase(g_idle_callers.begin() + (long)i);
+          break;
+        }
+    }
+    if (me.c) { btrapz_single_forget(me.c->ctx); return me.c; }   // (the previous owner's warm-start state is not ours)
+    Caller *c = new Caller();
+    c->device = device;
+    if (btrapz_create(&c->ctx, device) != BTRAPZ_OK) { delete c; return nullptr; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { btrapz_destroy(c->ctx); delete c; return nullptr; }
-    std::lock_guard<std::mutex> lk(g_callers_mutex);
-    g_callers.push_back(c);
-    me = c;
+    me.c = c;
   }
-  return me;
+  return me.c;
 }
 
 bool verbose() { const char *v = getenv("BTRAPZ_VERBOSE"); return v && *v && *v != '0'; }
+// BTRAPZ_VERBOSE=2: where a call's time goes (host stages and the launch), on stderr
+bool timing() { const char *v = getenv("BTRAPZ_VERBOSE"); return v && *v == '2'; }
+double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// BTRAPZ_ELASTIC=0 turns the rescue pass of find_traj off; BTRAPZ_ELASTIC_TOL overrides btrapz_options.elastic_tol.
+// BTRAPZ_ELASTIC=0 turns the rescue pass of find_traj off (strict mode: a QP without a solution is a failure);
+// BTRAPZ_ELASTIC_TOL overrides btrapz_options.elastic_tol (largest accepted row violation / |g|, default 0.01).
 struct ElasticEnv { bool on; double tol; };
 ElasticEnv elastic_env() {
   const char *e = getenv("BTRAPZ_ELASTIC"), *t = getenv("BTRAPZ_ELASTIC_TOL");
@@ -158,12 +186,17 @@ struct TrajResult {
 // Everything of find_traj between the parser and the output file.  Returns a_cost or the failure sentinel.
 double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResult &res) {
   const double FAIL = BTRAPZ_FAIL_SENTINEL;
+  const bool tm = timing();
+  const double t_begin = tm ? now_us() : 0.0;
+  t_last = LastCall();
+  t_last.status = BTRAPZ_NO_CORRIDOR;   // until the solve says otherwise
   // corridor stage (host): trp_wrapper.cpp:176-188
   std::vector<std::vector<Segment>> lists;
   for (int o = 0; o < in.num_obs; o++) lists.push_back(extract_segments(variant, in.N, in.delta, in.s_bounds[o], in.l_bounds[o]));
   std::vector<Segment> seg;
   if (!select_segments(variant, in.delta, lists, in.s_ref, in.l_ref, seg)) return FAIL;
   const int S = (int)seg.size();
+  const double t_corr = tm ? now_us() : 0.0;
   if (S < 1 || S > BTRAPZ_MAX_SEGMENTS) { fprintf(stderr, "btrapz: %d segments not supported (1..%d)\n", S, BTRAPZ_MAX_SEGMENTS); return FAIL; }
   for (const Segment &c : seg) if (!(c.t > 0)) return FAIL;
 
@@ -202,7 +235,7 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   sh.delta = in.delta; sh.variant = variant;
 
   Caller *me = this_caller();
-  if (!me) { fprintf(stderr, "btrapz: no HIP device available (this library has no CPU path)\n"); return FAIL; }
+  if (!me) { fprintf(stderr, "btrapz: no HIP device available (this library has no CPU path)\n"); t_last.status = BTRAPZ_ENODEVICE; return FAIL; }
   btrapz_ctx *ctx = me->ctx;
 
   // expected sample count and the reference's CHECK_EQ(var_index, num_of_points_) (solve_3d.cc:1407)
@@ -245,22 +278,31 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   // off by default: a call's output then depends on its inputs alone.
   const char *warm_env = getenv("BTRAPZ_WARM");
   const bool warm_on = warm_env && *warm_env && *warm_env != '0';
-  if (btrapz_launch_single(ctx, &sh, nullptr, S, d_in, d_out, max_points, warm_on ? 1 : 0, me->stream) != BTRAPZ_OK ||
+  t_last.status = BTRAPZ_EHIP;
+  const double t_launch = tm ? now_us() : 0.0;
+  btrapz_options opt1;
+  btrapz_options_init(&opt1);
+  if (const char *mi = getenv("BTRAPZ_MAX_ITER")) opt1.max_iter = atoi(mi);   // (experiments: cost per iteration)
+  if (btrapz_launch_single(ctx, &sh, &opt1, S, d_in, d_out, max_points, warm_on ? 1 : 0, me->stream) != BTRAPZ_OK ||
       hipStreamSynchronize(me->stream) != hipSuccess) {
     fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
+    btrapz_single_forget(ctx);   // (whatever the failed launch left is no start for the next call)
     return FAIL;
   }
+  const double t_done = tm ? now_us() : 0.0;
   h_cost = h_out[0];
   memcpy(h_status, &h_out[1], 8);
   memcpy(&h_np, &h_out[2], 4);
-  me->last_iters = h_status[1];
+  t_last.iters = h_status[1]; t_last.status = h_status[0];
+  if (tm) fprintf(stderr, "btrapz: timing [us]: corridor stage %.1f, record + table %.1f, launch to results %.1f (%d iterations)\n",
+                  t_corr - t_begin, t_launch - t_corr, t_done - t_launch, h_status[1]);
   if (h_status[0] != BTRAPZ_SOLVED && h_status[0] != BTRAPZ_SOLVED_INACCURATE) btrapz_single_forget(ctx);
   if (h_status[0] == BTRAPZ_MAX_ITER_REACHED && el.on) {
     // Second attempt (no solution to converge to: a marginally infeasible corridor): the rescue pass of
     // btrapz_options.elastic, the counterpart of the reference accepting OSQP's status 2.  Rare, so it simply goes
     // through the batched entry points on a device copy of the inputs.
     if (verbose()) fprintf(stderr, "btrapz: S=%d stalled after %d iterations, rescue pass\n", S, h_status[1]);
-    const size_t n_dev = n_in + n_out + 1;
+    const size_t n_dev = n_in + n_out + 1 + 4;   // (+ the four class violations behind the results)
     if (n_dev * 8 > me->scratch_bytes) {
       if (me->scratch) (void)hipFree(me->scratch);
       me->scratch = nullptr; me->scratch_bytes = 0;
@@ -274,26 +316,37 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
     const long long sel0 = 0;
     memcpy(&h_in[n_in], &sel0, 8);   // (h_in[n_in] is h_out[0]: it stages the selection index until the results overwrite it)
     if (hipMemcpyAsync(s_in, h_in, (n_in + 1) * 8, hipMemcpyHostToDevice, me->stream) != hipSuccess) return FAIL;
-    btrapz_options opt = {};
+    btrapz_options opt;
+    btrapz_options_init(&opt);
     opt.elastic = 1; opt.elastic_tol = el.tol;
+    double *s_viol = s_out + n_out;
+    double h_viol[4] = {0.0, 0.0, 0.0, 0.0};
     if (btrapz_solve_batch_device(ctx, &sh, &opt, 1, S, s_in, s_init, s_init + 6, s_init + 8, s_out + 3, s_out, s_status,
                                   s_status + 1, me->stream) != BTRAPZ_OK ||
         btrapz_sample_device(ctx, 1, S, in.delta, s_in, s_init, s_out + 3, 1, s_sel, max_points, s_out + 3 + 12 * S, s_np,
-                             me->stream) != BTRAPZ_OK) {
+                             me->stream) != BTRAPZ_OK ||
+        btrapz_rescue_violations_device(ctx, 1, s_viol, me->stream) != BTRAPZ_OK) {
       fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
+      t_last.status = BTRAPZ_EHIP;
+      btrapz_single_forget(ctx);
       return FAIL;
     }
     if (hipMemcpyAsync(h_out, s_out, n_out * 8, hipMemcpyDeviceToHost, me->stream) != hipSuccess ||
-        hipStreamSynchronize(me->stream) != hipSuccess) return FAIL;
+        hipMemcpyAsync(h_viol, s_viol, 4 * 8, hipMemcpyDeviceToHost, me->stream) != hipSuccess ||
+        hipStreamSynchronize(me->stream) != hipSuccess) { t_last.status = BTRAPZ_EHIP; btrapz_single_forget(ctx); return FAIL; }
     h_cost = h_out[0];
     memcpy(h_status, &h_out[1], 8);
     memcpy(&h_np, &h_out[2], 4);
+    t_last.iters = h_status[1]; t_last.status = h_status[0];
+    for (int i = 0; i < 4; i++) t_last.viol[i] = h_viol[i];
+    if (verbose()) fprintf(stderr, "btrapz: rescue pass: status %d, row violations pos %.3g vel %.3g acc %.3g jerk %.3g\n", h_status[0],
+                           h_viol[0], h_viol[1], h_viol[2], h_viol[3]);
   }
   std::vector<double> out(h_out + 3 + 12 * S, h_out + n_out);
   if (verbose()) fprintf(stderr, "btrapz: S=%d status=%d iters=%d obj=%.9g\n", S, h_status[0], h_status[1], h_cost);
   // acceptance: solve_3d.cc:1251-1277
   if (h_status[0] != BTRAPZ_SOLVED && h_status[0] != BTRAPZ_SOLVED_INACCURATE) return FAIL;
-  if (h_np != max_points) return FAIL;
+  if (h_np != max_points) { t_last.status = BTRAPZ_NO_CORRIDOR; return FAIL; }
 
   const double *s = &out[0], *ds = &out[(size_t)max_points], *dds = &out[(size_t)2 * max_points];
   const double *l = &out[(size_t)3 * max_points], *dl = &out[(size_t)4 * max_points], *ddl = &out[(size_t)5 * max_points];
@@ -347,9 +400,11 @@ BTRAPZ_EXPORT double btrapz_find_traj(int variant, const char *input_path, const
   return cost;
 }
 
-BTRAPZ_EXPORT int btrapz_find_traj_last_iterations(void) {
-  Caller *me = this_caller();
-  return me ? me->last_iters : -1;
+BTRAPZ_EXPORT int btrapz_find_traj_last_iterations(void) { return t_last.iters; }
+
+BTRAPZ_EXPORT int btrapz_find_traj_last_status(double *viol) {
+  if (viol) for (int i = 0; i < 4; i++) viol[i] = t_last.status == BTRAPZ_SOLVED_INACCURATE ? t_last.viol[i] : 0.0;
+  return t_last.status;
 }
 
 // find_traj without the file side channel: the parsed content of the corridor file comes in as

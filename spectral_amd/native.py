@@ -41,14 +41,16 @@ class CShared(C.Structure):
 
 
 class COptions(C.Structure):
-    _fields_ = [("max_iter", C.c_int), ("eps", C.c_double), ("step_fraction", C.c_double), ("step_threshold", C.c_double),
-                ("elastic", C.c_int), ("elastic_tol", C.c_double), ("elastic_delta", C.c_double), ("queue", C.c_int)]
+    """btrapz_options; struct_size is what btrapz_options_init() sets (the library rejects other layouts)."""
+    _fields_ = [("struct_size", C.c_int), ("max_iter", C.c_int), ("eps", C.c_double), ("step_fraction", C.c_double),
+                ("step_threshold", C.c_double), ("elastic", C.c_int), ("elastic_tol", C.c_double),
+                ("elastic_delta", C.c_double), ("queue", C.c_int), ("split", C.c_int)]
 
 
-def _options(max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, elastic_delta=0.0, queue=0):
-    return COptions(int(max_iter), float(eps), float(os.environ.get("BTRAPZ_STEP_FRACTION", "0")),
+def _options(max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, elastic_delta=0.0, queue=0, split=0):
+    return COptions(C.sizeof(COptions), int(max_iter), float(eps), float(os.environ.get("BTRAPZ_STEP_FRACTION", "0")),
                     float(os.environ.get("BTRAPZ_STEP_THRESHOLD", "0")), int(elastic), float(elastic_tol),
-                    float(elastic_delta), int(queue))
+                    float(elastic_delta), int(queue), int(split))
 
 
 class CWarm(C.Structure):
@@ -103,7 +105,8 @@ EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "bt
            "btrapz_sample_device", "btrapz_solve_batch_host", "btrapz_solve_ragged_device",
            "btrapz_corridor_batch_device", "btrapz_sample_ragged_device", "btrapz_solve_warm_device",
            "btrapz_eval_states_device", "btrapz_find_traj_mem", "btrapz_prism_bounds_device",
-           "btrapz_find_traj_last_iterations", "btrapz_argmin_pairs_device")
+           "btrapz_find_traj_last_iterations", "btrapz_argmin_pairs_device", "btrapz_options_init",
+           "btrapz_rescue_violations_device", "btrapz_find_traj_last_status", "btrapz_debug_mqm_tables")
 
 
 def build(verbose=False):
@@ -165,6 +168,10 @@ def lib():
         l.btrapz_last_error.argtypes = [C.c_void_p]; l.btrapz_last_error.restype = C.c_char_p
         l.btrapz_device_count.restype = C.c_int
         l.btrapz_find_traj_last_iterations.restype = C.c_int
+        l.btrapz_find_traj_last_status.argtypes = [C.c_void_p]; l.btrapz_find_traj_last_status.restype = C.c_int
+        l.btrapz_options_init.argtypes = [C.POINTER(COptions)]; l.btrapz_options_init.restype = None
+        l.btrapz_rescue_violations_device.argtypes = [vp, C.c_int, dp, vp]
+        l.btrapz_debug_mqm_tables.argtypes = [vp, C.POINTER(CShared), dp, dp]
         l.btrapz_solve_batch_device.argtypes = [vp, C.POINTER(CShared), C.POINTER(COptions), C.c_int, C.c_int,
                                                 dp, dp, dp, dp, dp, dp, ip, ip, vp]
         l.btrapz_argmin_device.argtypes = [vp, C.c_int, C.c_int, C.c_longlong, dp, llp, dp, vp]
@@ -214,7 +221,7 @@ class Context:
             raise BtrapzError("%s failed (%d): %s" % (what, rc, lib().btrapz_last_error(self._h).decode()))
 
     # ---- host-pointer path (numpy in, numpy out) ------------------------------------------
-    def solve_host(self, batch, shared, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0):
+    def solve_host(self, batch, shared, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, split=0):
         B, S = batch.B, batch.S
         seg = np.ascontiguousarray(batch.seg, dtype=np.float64)
         init = np.ascontiguousarray(batch.init, dtype=np.float64)
@@ -223,7 +230,7 @@ class Context:
         assert seg.shape == (L.NUM_SEG_FIELDS, B, S)
         ctrl = np.empty((B, 12 * S)); cost = np.empty(B)
         status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32)
-        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol)
+        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol, split=split)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         self._check(lib().btrapz_solve_batch_host(self._h, C.byref(sh), C.byref(opt), B, S, p(seg), p(init),
                                                   p(ref_end), p(dlb), p(ctrl), p(cost), p(status), p(iters)),
@@ -232,8 +239,8 @@ class Context:
 
     # ---- device-pointer path (torch tensors only carry the memory) --------------------------
     def solve_device(self, B, S, shared, seg, init, ref_end, dl_bounds, ctrl, cost, status, iters=None,
-                     stream=None, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, queue=0):
-        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol, queue=queue)
+                     stream=None, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, queue=0, split=0):
+        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol, queue=queue, split=split)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self._check(lib().btrapz_solve_batch_device(self._h, C.byref(sh), C.byref(opt), B, S, ptr(seg), ptr(init),
                                                     ptr(ref_end), ptr(dl_bounds), ptr(ctrl), ptr(cost),
@@ -261,6 +268,18 @@ class Context:
                                                    ptr(seg), ptr(seg_count), ptr(init), ptr(ref_end), ptr(dl_bounds),
                                                    ptr(ctrl), ptr(cost), ptr(status), ptr(iters),
                                                    C.c_void_p(stream or 0)), "btrapz_solve_warm_device")
+
+    def rescue_violations_device(self, B, viol, stream=None):
+        """btrapz_rescue_violations_device: viol [B][4] (position, velocity, acceleration, jerk rows) of the last solve
+        with elastic != 0."""
+        self._check(lib().btrapz_rescue_violations_device(self._h, int(B), C.c_void_p(viol.data_ptr()),
+                                                          C.c_void_p(stream or 0)), "btrapz_rescue_violations_device")
+
+    def debug_mqm_tables(self, shared):
+        sh = CShared.from_shared(shared)
+        h = np.zeros(168); d = np.zeros(168)
+        self._check(lib().btrapz_debug_mqm_tables(self._h, C.byref(sh), h.ctypes.data, d.ctypes.data), "btrapz_debug_mqm_tables")
+        return h, d
 
     def eval_states_device(self, B, seg_stride, seg_count, seg, ctrl, n_times, times, x, stream=None):
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
@@ -313,6 +332,13 @@ def find_traj_native(variant, params, input_path=None, output_path=None):
     cp = params if isinstance(params, CParams) else CParams(*params)
     enc = lambda s: os.fsencode(s) if s else None
     return lib().btrapz_find_traj(int(variant), enc(input_path), enc(output_path), C.byref(cp))
+
+
+def find_traj_last_status():
+    """(status, viol[4]) of the calling thread's last find_traj / find_traj_mem call (btrapz_find_traj_last_status)."""
+    v = (C.c_double * 4)()
+    st = lib().btrapz_find_traj_last_status(C.cast(v, C.c_void_p))
+    return int(st), np.array(v[:])
 
 
 def find_traj_mem(variant, params, kb, b=0, cap=None):

@@ -6,7 +6,7 @@
 Inputs, in turn: scenario_1 scenes of 2-24 segments (synth.scenario1_knots), jittered copies of the bundled corridor
 files, fuzz_knot_batch garbage (tests/helpers.py).  ELASTIC = 0 (default here): the plain solve against the oracle's
 exact solve; 1: the product's default, rescue pass on, against "exact, else orc_elastic_solve within elastic_tol"
-(inputs within 0.02 of the tolerance are skipped).  A disagreement is printed with the kernel's own account
+(in the rows' own norms, tolerance 0.0125 |g|; inputs within 0.0005 of the tolerance are skipped).  A disagreement is printed with the kernel's own account
 (BTRAPZ_VERBOSE) and its input is written to gpurun_out/ftfuzz/.  Round 2: 7 200 / 7 200 agree (ELASTIC 0), 6 000 /
 6 000 (ELASTIC 1); see DESIGN.md sections 3.4, 3.7, 5.
 """
@@ -56,8 +56,8 @@ for it in range(count):
             tol_x = 1e-5
             if not want_accept and ELASTIC == "1" and not (qp.l > qp.u + 1e-12).any() and np.isfinite(qp.l).all() and np.isfinite(qp.u).all():
                 x, _, info, viol = qp.solve_elastic()
-                if abs(viol - 0.5) < 0.02: skipped = True
-                want_accept = info.status in (1, 2) and viol <= 0.5
+                if abs(viol - 0.0125) < 0.0005: skipped = True
+                want_accept = info.status in (1, 2) and viol <= 0.0125
                 tol_x = 1e-4
             if want_accept:   # the reference's CHECK_EQ(var_index, num_of_points_) (solve_3d.cc:1407) aborts: a failure here
                 rc, smp = O.sample(cubes, inp.delta, x, inp.init_s, inp.init_l)

@@ -115,7 +115,7 @@ def test_ragged_batch_equals_uniform_batches():
     out = solver.solve_ragged(rec, sh)
     torch.cuda.synchronize()
     ctrl = out["ctrl"].cpu().numpy(); status = out["status"].cpu().numpy(); cost = out["cost"].cpu().numpy()
-    uni = [solver.ctx.solve_host(pb, sh) for pb, _ in parts]
+    uni = [solver.ctx.solve_host(pb, sh, split=-1) for pb, _ in parts]   # (the packed form: what ragged batches run)
     off = np.cumsum([0] + [p[0].B for p in parts])
     for dst, i in enumerate(perm):
         if dst in (5, 9):

@@ -1,6 +1,8 @@
 """Size-independent properties at BASELINE.json's full sizes (configs 2-4): every candidate
 solved, returned control points feasible for every constraint row, C2-continuous, and no worse
 than the reference algorithm's own answer."""
+import os
+
 import numpy as np
 import pytest
 
@@ -146,3 +148,61 @@ def test_candidate_queue_changes_the_schedule_not_the_results():
     for i in range(10):
         if st[i] == 1:
             assert np.abs(got[i] - xs[i]).max() <= 1e-5 * np.abs(xs[i]).max()
+
+
+def test_host_and_device_builders_of_the_mqm_table_agree_bit_for_bit():
+    """find_traj's single launch takes the batch-invariant M' pQp_d M table (solve_3d.cc:87-143) from the host builder,
+    the batched entry points from the device builder: the same expressions without fused multiply-adds, so the same
+    candidate gives the same bits through both."""
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    rng = np.random.default_rng(3)
+    for trial in range(4):
+        sh = synth.shared_params(0)
+        if trial:
+            sh.w_s = tuple(float(v) for v in rng.uniform(0.01, 50.0, 4)); sh.w_l = tuple(float(v) for v in rng.uniform(0.01, 50.0, 4))
+        h, d = solver.ctx.debug_mqm_tables(sh)
+        assert np.array_equal(h.view(np.int64), d.view(np.int64))
+
+
+def test_argmin_over_very_many_small_groups():
+    """More arg-min groups than a grid's y dimension holds (65 535): groups are the x dimension."""
+    import torch
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    B, group = 8 * 70000, 8
+    g = torch.Generator(device="cpu").manual_seed(1)
+    cost = torch.rand(B, generator=g, dtype=torch.float64).cuda()
+    bi, bc = solver.argmin(cost, group=group)
+    torch.cuda.synchronize()
+    want = cost.view(-1, group).argmin(dim=1) + torch.arange(0, B, group, device=cost.device)
+    assert torch.equal(bi, want)
+
+
+def test_find_traj_threads_hand_their_device_state_on(tmp_path):
+    """Every thread that calls find_traj holds a context, a stream and buffers while it lives; a thread that exits hands
+    them to the next new thread (a harness that starts a thread per trial must not leak a set per thread)."""
+    import threading
+    import torch
+    from spectral_amd import knots, native
+    gold = os.path.join(os.path.dirname(__file__), "golden", "inputs")
+    kb = knots.parse_corridor_file(os.path.join(gold, "c2.txt"))
+    prm = native.CParams(*[float(v) for v in np.loadtxt(os.path.join(gold, "weights.txt"))], 1)
+    res = []
+
+    def call():
+        res.append(native.find_traj_mem(0, prm, kb)[0])
+        assert native.find_traj_last_status()[0] == 1
+
+    call()
+    free0 = torch.cuda.mem_get_info()[0]
+    for i in range(40):                      # forty short-lived threads, one after the other
+        t = threading.Thread(target=call); t.start(); t.join()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert len(set(res)) == 1
+    assert free0 - free1 <= 8 << 20          # at most one more set (a few MiB), not forty
+    # a thread that never called find_traj asks for the last call's record: no context is created for it
+    out = []
+    t = threading.Thread(target=lambda: out.append((native.lib().btrapz_find_traj_last_iterations(), native.find_traj_last_status()[0])))
+    t.start(); t.join()
+    assert out == [(-1, 0)]

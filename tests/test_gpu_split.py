@@ -1,0 +1,88 @@
+"""The split form of the solve kernel (btrapz_options.split; SPLIT in spectral_amd/csrc/btrapz_kernels.hip): one candidate
+per wavefront, every segment's fifteen rows spread over three lanes.  Same QP, same method, same decisions as the
+three-candidates-per-wavefront form -- held to it and to the oracle's x* (solve_3d.cc:1246-1249 is what both replace)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import O, oracle_qp_from_batch
+from spectral_amd import knots, native, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+W = np.loadtxt(os.path.join(GOLD, "inputs", "weights.txt"))
+
+
+def _solve(solver, db, sh, split):
+    import torch
+    o = solver.solve(db, sh, split=split)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy().copy() for k, v in o.items()}
+
+
+@pytest.mark.parametrize("gen,S,variant,B", [("scenario1", 20, 0, 768), ("scenario1", 20, 1, 384), ("generic", 10, 0, 512),
+                                             ("scenario1", 7, 0, 300), ("generic", 21, 0, 96), ("generic", 1, 0, 40),
+                                             ("generic", 2, 0, 40), ("generic", 3, 1, 40)])
+def test_split_form_decides_and_solves_as_the_packed_form(gen, S, variant, B):
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    batch, sh = (synth.make_scenario1_batch(B, S, variant) if gen == "scenario1" else synth.make_batch(B, S, config=2, variant=variant))
+    db = solver.upload(batch)
+    a = _solve(solver, db, sh, -1)
+    b = _solve(solver, db, sh, 1)
+    assert np.array_equal(a["status"] > 0, b["status"] > 0)                 # the same candidates accepted
+    assert np.array_equal(a["status"], b["status"])
+    ok = a["status"] > 0
+    assert ok.any()
+    scale = np.abs(a["ctrl"][ok]).max(axis=1, keepdims=True)
+    assert (np.abs(a["ctrl"][ok] - b["ctrl"][ok]) / scale).max() <= 2e-6  # both within 1e-6 of x*, see below
+    assert np.abs(a["cost"][ok] - b["cost"][ok]).max() <= 1e-7 * np.abs(a["cost"][ok]).max()
+    # same method, same termination tests: iteration counts differ only where rounding moves a score across a threshold
+    assert (np.abs(a["iters"] - b["iters"]) <= 1).mean() >= 0.99
+    # and against the oracle's exact solve
+    xs, obj, st, _ = O.batch_solve(batch, sh, 0, 6, exact=True)
+    for i in range(6):
+        assert (st[i] in (1, 2)) == bool(ok[i])
+        if ok[i]:
+            assert np.abs(b["ctrl"][i] - xs[i]).max() <= 1e-5 * np.abs(xs[i]).max()
+
+
+def test_automatic_choice_takes_the_split_form_for_few_candidates_only():
+    """split = 0: a batch that leaves SIMDs idle (2 B wavefronts fit the device) runs the split form, a large one the
+    packed form; more than 21 segments always the packed form.  Seen through the results: bit-equal to the forced form."""
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    batch, sh = synth.make_scenario1_batch(64, 20, 0)
+    db = solver.upload(batch)
+    auto, split, packed = _solve(solver, db, sh, 0), _solve(solver, db, sh, 1), _solve(solver, db, sh, -1)
+    assert np.array_equal(auto["ctrl"], split["ctrl"]) and not np.array_equal(auto["ctrl"], packed["ctrl"])
+    big, sh2 = synth.make_batch(4096, 10, config=2)
+    db2 = solver.upload(big)
+    auto, packed = _solve(solver, db2, sh2, 0), _solve(solver, db2, sh2, -1)
+    assert np.array_equal(auto["ctrl"], packed["ctrl"])
+    wide, sh3 = synth.make_batch(30, 22, config=2)
+    db3 = solver.upload(wide)
+    forced, packed = _solve(solver, db3, sh3, 1), _solve(solver, db3, sh3, -1)
+    assert np.array_equal(forced["ctrl"], packed["ctrl"])                 # 22 segments: three lanes per segment do not fit
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c6", "c7", "c_road_s1", "c_road_s1_3"])
+def test_find_traj_through_the_split_form(name, monkeypatch):
+    """find_traj's single launch uses the split form up to 21 segments (BTRAPZ_SPLIT=0: the packed one): same decision,
+    same trajectory, and the oracle's x*."""
+    params = native.CParams(*[float(v) for v in W], 3)
+    kb = knots.parse_corridor_file(os.path.join(GOLD, "inputs", name + ".txt"))
+    for variant in (0, 1):
+        monkeypatch.setenv("BTRAPZ_SPLIT", "0")
+        c0, t0, x0 = native.find_traj_mem(variant, params, kb)
+        it0 = native.lib().btrapz_find_traj_last_iterations()
+        monkeypatch.delenv("BTRAPZ_SPLIT")
+        c1, t1, x1 = native.find_traj_mem(variant, params, kb)
+        it1 = native.lib().btrapz_find_traj_last_iterations()
+        assert (c0 == 1e11) == (c1 == 1e11)
+        if c0 == 1e11:
+            continue
+        assert abs(c0 - c1) <= 1e-7 * abs(c0) and np.abs(x0 - x1).max() <= 2e-6 * np.abs(x0).max()
+        assert np.abs(t0 - t1).max() <= 2e-6 * max(1.0, np.abs(t0).max())
+        assert it1 <= it0 + 1                      # (c_road_s1 sits at the round-off floor: 18 packed, 13 split)

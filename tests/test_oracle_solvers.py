@@ -136,20 +136,26 @@ def test_acceptance_table_is_current():
     assert not seen[("c_road_s1_2", 0)]["hip_accepts"] and not seen[("c_road_s1_3", 1)]["hip_accepts"]
 
 
-def test_elastic_solve_is_the_augmented_qp():
+@pytest.mark.parametrize("normalised", [False, True])
+def test_elastic_solve_is_the_augmented_qp(normalised):
     """orc_elastic_solve eliminates the relaxation d analytically; the same problem written out with d as variables
-    (penalty d^2 / (2 delta), rows l <= a'x - d <= u) and solved by the plain method gives the same point."""
+    (penalty d^2 / (2 delta), rows l <= a'x - d <= u) and solved by the plain method gives the same point.  normalised
+    (the product's rescue problem since round 3): penalty (d_i / |a_i|)^2 / (2 delta), every row in its own norm."""
     _, _, qp = load("c7", 0)
     P, A = qp.dense(); n, m = qp.n, qp.m
     ineq = np.nonzero((qp.u - qp.l) > 1e-12)[0]; mi = len(ineq); delta = 1e-3
-    Pa = np.zeros((n + mi, n + mi)); Pa[:n, :n] = P; Pa[n:, n:] = np.eye(mi) / delta
+    nrm = np.linalg.norm(A[ineq], axis=1) if normalised else np.ones(mi)
+    Pa = np.zeros((n + mi, n + mi)); Pa[:n, :n] = P; Pa[n:, n:] = np.diag(1.0 / (delta * nrm ** 2))
     Aa = np.zeros((m, n + mi)); Aa[:, :n] = A; Aa[ineq, n + np.arange(mi)] = -1.0
     aug = O.DenseQp(Pa, np.concatenate([qp.q, np.zeros(mi)]), Aa, qp.l, qp.u)
     xa, _, ia = aug.solve_exact(eps=1e-10, max_iter=200)
-    xe, _, ie, viol = qp.solve_elastic(delta=delta, eps=1e-10)
+    xe, _, ie, viol = qp.solve_elastic(delta=delta, eps=1e-10, normalised=normalised)
     assert ia.status == 1 and ie.status == 1
     assert np.abs(xa[:n] - xe).max() <= 1e-7 * np.abs(xe).max()
-    assert abs(np.abs(xa[n:]).max() - viol) <= 1e-7
+    assert abs((np.abs(xa[n:]) / nrm).max() - viol) <= 1e-7
+    if normalised:   # the relaxation lands where the reference's own accepted iterate has it: on acceleration rows
+        pos, vel, acc, jerk = qp.class_violations(qp.solve_elastic()[0])
+        assert pos < 1e-3 and 0.4 < acc < 0.5 and jerk == 0.0
     # feasible problem: the relaxation vanishes with delta
     _, _, q2 = load("c2", 0)
     xs, _, _ = q2.solve_exact()
