@@ -166,7 +166,7 @@ def main():
     import torch
     import torch.distributed as dist
     from spectral_amd import native
-    from spectral_amd.dist import global_argmin, shard_bounds
+    from spectral_amd.dist import global_argmin_with_winner, shard_bounds
     from spectral_amd.solver import BatchSolver
 
     world = int(world_env or "1")
@@ -204,10 +204,16 @@ def main():
         total_candidates = a.batch
     db = solver.upload(batch)
 
+    def winner(o):
+        bi, bc = solver.argmin(o["cost"], index_base=index_base)       # winner of this rank's shard ...
+        mine = o["ctrl"].index_select(0, (bi - index_base).clamp(min=0))   # ... and its control points [1][12 S]
+        # N > 1: ONE all-gather of (cost, index, control points) = 16 + 96 S bytes per rank over RCCL; every rank ends
+        # up with the global winner's index, cost and control points (spectral_amd/dist.py)
+        return global_argmin_with_winner(bc, bi, mine, ctx=solver.ctx)
+
     def step():
         o = solver.solve(db, shared)                                   # assembly + solve: one launch
-        bi, bc = solver.argmin(o["cost"], index_base=index_base)       # winner of this rank's shard
-        wc, wi = global_argmin(bc, bi, ctx=solver.ctx)                  # N > 1: 16 B per rank over RCCL
+        wc, wi, wctrl = winner(o)
         return o, wi[0], wc[0]
 
     def sync():
@@ -225,8 +231,7 @@ def main():
         ev[i][0].record()                       # torch's current stream == the stream the solve is launched on
         o = solver.solve(db, shared)
         ev[i][1].record()
-        bi, bc = solver.argmin(o["cost"], index_base=index_base)
-        wc, wi = global_argmin(bc, bi, ctx=solver.ctx)
+        wc, wi, wctrl = winner(o)
         win_idx, win_cost = wi[0], wc[0]
     sync()
     elapsed_local = time.perf_counter() - t0
@@ -246,6 +251,24 @@ def main():
     it1 = iters + 1                                         # iters holds the index of the last iteration
     mean_iters = float(np.mean(it1))
 
+    def tool(name, argv):
+        """One of tools/*.py, in-process (this process prints ONE line)."""
+        import contextlib, importlib.util, io
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+        mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+        with contextlib.redirect_stdout(io.StringIO()):
+            return mod.main(argv)
+
+    # N > 1: BASELINE config 5 on the N GPUs in the same run -- the fleet's agents sharded over the ranks, no collective
+    # on the step (tools/mpc_bench.py --gpus N; every rank takes part, rank 0 holds the fleet's figures)
+    mpc_multi = None
+    if world > 1 and not a.no_secondary:
+        try:
+            mpc_multi = tool("mpc_bench", ["--steps", "150", "--gpus", str(world), "--backend", a.backend] +
+                             (["--share-device"] if a.share_device else []))
+        except Exception as e:
+            mpc_multi = {"error": repr(e)[:200]}
+
     out = None
     if rank == 0:
         value = total_candidates * a.steps / elapsed
@@ -264,8 +287,8 @@ def main():
                        "generator": a.workload, "batch_per_gpu": B if a.scaling == "weak" else None,
                        "batch_total": total_candidates, "segments": S, "variant": a.variant,
                        "parallelism": "shard%d" % world,
-                       "collective": "none" if world == 1 else "%s all_gather of one (cost, index) pair = 16 B per rank and step"
-                                     % ("rccl" if a.backend == "nccl" else a.backend)},
+                       "collective": "none" if world == 1 else "%s all_gather of (cost, index, the local winner's control points) = %d B per rank and step"
+                                     % ("rccl" if a.backend == "nccl" else a.backend, 16 + 96 * S)},
             "ms_per_step_by_rank": rank_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
@@ -289,7 +312,9 @@ def main():
             "solved_fraction": solved, "mean_ipm_iterations": mean_iters,
             "ipm_iteration_histogram": {str(i): int(c) for i, c in enumerate(hist) if c},
             "status_counts": {str(int(k)): int((status == k).sum()) for k in np.unique(status)},
-            "winner": {"index": int(win_idx.item()), "cost": float(win_cost.item())},
+            "winner": {"index": int(win_idx.item()), "cost": float(win_cost.item()),
+                       # every rank holds the winner's control points after the step; their checksum and first values
+                       "ctrl_sum": float(wctrl[0].sum().item()), "ctrl_head": [float(v) for v in wctrl[0, :4].tolist()]},
         }
         # second figure: the other workload family, same shape, a short run (not the headline)
         if world == 1 and not a.no_secondary:
@@ -315,14 +340,12 @@ def main():
             del d2
         # the other named configurations, in the same (driver-timed) run: BASELINE config 5 (receding horizon, one GPU)
         # and the knot-level pipeline through the tools that profiles/ documents
+        keep = lambda d, keys: {k: d[k] for k in keys if k in d}
+        if mpc_multi is not None:
+            out["config5_%d_gpus" % world] = keep(mpc_multi, ("workload", "n_gpus", "agents_per_gpu", "parallelism", "achieved_hz",
+                                                              "achieved_hz_by_rank", "target_hz", "p50_step_ms", "p99_step_ms",
+                                                              "mean_ipm_iterations", "solved_fraction_mean", "candidates_per_s", "error"))
         if world == 1 and not a.no_secondary:
-            import contextlib, importlib.util, io
-            def tool(name, argv):
-                spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
-                mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-                with contextlib.redirect_stdout(io.StringIO()):     # (this process prints ONE line)
-                    return mod.main(argv)
-            keep = lambda d, keys: {k: d[k] for k in keys if k in d}
             try:
                 m = tool("mpc_bench", ["--steps", "150"])
                 out["config5_one_gpu"] = keep(m, ("workload", "achieved_hz", "target_hz", "p50_step_ms", "p99_step_ms",

@@ -59,3 +59,71 @@ def global_argmin(best_cost, best_idx, group=None, ctx=None):
     out_k = torch.where(tied, idx_key, torch.full_like(idx_key, big)).min(dim=0).values
     out_i = torch.where(out_k == big, torch.full_like(out_k, -1), out_k)
     return out_c, out_i
+
+
+def global_argmin_with_winner(best_cost, best_idx, local_ctrl, group=None, ctx=None):
+    """global_argmin that also brings the winners' control points to every rank ("only the winner's 1.9 KB
+    is fetched from its owner"), in the SAME collective: every rank contributes, per arg-min group, its local winner's
+    (cost, global index) pair followed by that candidate's control points -- 16 B + 12 S x 8 B = 1 936 B at 20 segments
+    -- and after the one all_gather every rank holds G such records, reduces the pairs as global_argmin does and keeps
+    the record of the rank that owns the winner.  No second collective, and no host round trip to learn the owner (a
+    broadcast from the owner needs its rank on the host, i.e. a device-to-host copy and a synchronisation per step;
+    `fetch_winner` below is that form, for callers that have the index on the host anyway).
+
+    best_cost [n] float64, best_idx [n] int64 (global indices, -1 = none), local_ctrl [n][P] float64: control points of
+    this rank's winner of every group (any finite filler where best_idx is -1).  Returns (cost [n], idx [n],
+    ctrl [n][P]); ctrl rows of groups nobody solved are NaN.  Identical on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    assert best_cost.shape == best_idx.shape and best_cost.dim() == 1 and local_ctrl.dim() == 2 and local_ctrl.shape[0] == best_cost.shape[0]
+    if world == 1:
+        out = local_ctrl.clone()
+        out[best_idx < 0] = float("nan")
+        return best_cost, best_idx, out
+    n, P = local_ctrl.shape
+    rec = torch.cat([best_cost.to(torch.float64).view(torch.int64)[:, None], best_idx.to(torch.int64)[:, None],
+                     local_ctrl.to(torch.float64).contiguous().view(torch.int64)], dim=1).contiguous()   # [n][2 + P] int64
+    dev = rec.device
+    if dist.get_backend(group) == "gloo" and rec.is_cuda:
+        rec = rec.cpu()
+    gathered = [torch.empty_like(rec) for _ in range(world)]
+    dist.all_gather(gathered, rec, group=group)
+    allr = torch.stack(gathered).to(dev)                                  # [world][n][2 + P]
+    pairs = allr[..., :2].contiguous()
+    if ctx is not None and pairs.is_cuda:
+        out_c = torch.empty(n, dtype=torch.float64, device=dev); out_i = torch.empty(n, dtype=torch.int64, device=dev)
+        ctx.argmin_pairs_device(world, n, pairs, out_c, out_i, stream=torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        cost = pairs[..., 0].contiguous().view(torch.float64)
+        idx = pairs[..., 1]
+        big = torch.iinfo(torch.int64).max
+        idx_key = torch.where(idx < 0, torch.full_like(idx, big), idx)
+        cost = torch.where(torch.isnan(cost), torch.full_like(cost, float("inf")), cost)
+        out_c = cost.min(dim=0).values
+        out_k = torch.where(cost == out_c[None], idx_key, torch.full_like(idx_key, big)).min(dim=0).values
+        out_i = torch.where(out_k == big, torch.full_like(out_k, -1), out_k)
+    # the owner of group g's winner: the (one) rank whose record carries the winning index
+    owner = ((pairs[..., 1] == out_i[None]) & (out_i[None] >= 0)).to(torch.int64).argmax(dim=0)          # [n]
+    ctrl = allr[owner, torch.arange(n, device=dev), 2:].contiguous().view(torch.float64)
+    ctrl = torch.where((out_i >= 0)[:, None], ctrl, torch.full_like(ctrl, float("nan")))
+    return out_c, out_i, ctrl
+
+
+def fetch_winner(ctrl, win_idx, per, index_base, group=None):
+    """The winner's control points from its owner by ONE broadcast.  ctrl [B_local][P]: this rank's solved
+    control points; win_idx: the winner's GLOBAL index as a python int (the caller has it on the host), -1 = none;
+    per: candidates per rank (shard_bounds' stride); index_base: global index of this rank's candidate 0.
+    Returns a [P] tensor, identical on every rank, or None when nobody solved a candidate."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    win_idx = int(win_idx)
+    if win_idx < 0:
+        return None
+    owner = min(world - 1, win_idx // per) if world > 1 else 0
+    rank = dist.get_rank(group) if world > 1 else 0
+    P = ctrl.shape[1]
+    buf = ctrl[win_idx - index_base].clone() if rank == owner else torch.empty(P, dtype=ctrl.dtype, device=ctrl.device)
+    if world > 1:
+        if dist.get_backend(group) == "gloo" and buf.is_cuda:
+            host = buf.cpu(); dist.broadcast(host, src=owner, group=group); buf = host.to(ctrl.device)
+        else:
+            dist.broadcast(buf, src=owner, group=group)
+    return buf

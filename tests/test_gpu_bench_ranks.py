@@ -64,3 +64,36 @@ def test_argmin_pairs_kernel_equals_the_torch_reduction():
     want_i = key.min(axis=0); want_i[want_i == np.iinfo(np.int64).max] = -1
     assert np.array_equal(out_c.cpu().numpy(), want_c) and np.array_equal(out_i.cpu().numpy(), want_i)
     assert out_i[5].item() == -1 and out_i[9].item() == min(idx[2, 9], idx[6, 9])
+
+
+def test_winner_control_points_of_two_ranks_are_the_single_rank_ones():
+    """after the arg-min every rank holds the winner's control points (one all_gather carries pair and
+    control points, spectral_amd.dist.global_argmin_with_winner): bit-equal to the 1-rank run of the same batch."""
+    one = run("--gpus", "1", "--scaling", "strong")
+    two = run("--gpus", "2", "--scaling", "strong", "--backend", "gloo", "--share-device")
+    assert two["winner"]["ctrl_sum"] == one["winner"]["ctrl_sum"] and two["winner"]["ctrl_head"] == one["winner"]["ctrl_head"]
+    assert "control points" in two["config"]["collective"] and str(16 + 96 * 20) in two["config"]["collective"]
+
+
+def run_mpc(*args):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mpc_bench.py"), "--steps", "6", "--agents", "6", "--cand", "64",
+                        "--check", "0", *args], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_config5_sharded_by_agent_replans_every_agent_as_one_gpu_does():
+    """BASELINE config 5 over N GPUs: agents sharded over the ranks (dist.shard_bounds), per-agent arg-min local, no
+    collective on the step.  Two ranks on the one GPU of the box: every agent's winner after the last step is the
+    1-rank run's (an agent's replanning does not depend on which other agents share its GPU)."""
+    one = run_mpc("--cold")
+    two = run_mpc("--cold", "--gpus", "2", "--backend", "gloo", "--share-device")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["agents_per_gpu"] == 3
+    assert len(two["achieved_hz_by_rank"]) == 2 and two["achieved_hz"] == min(two["achieved_hz_by_rank"])
+    assert two["last_winners"] == one["last_winners"] and len(one["last_winners"]) == 6
+    assert "no collective" in two["parallelism"]
+    three = run_mpc("--cold", "--gpus", "3", "--backend", "gloo", "--share-device")    # 6 agents over 3 ranks
+    assert three["last_winners"] == one["last_winners"]

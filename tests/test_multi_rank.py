@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from spectral_amd.dist import global_argmin, shard_bounds
+from spectral_amd.dist import fetch_winner, global_argmin, global_argmin_with_winner, shard_bounds
 
 
 def _free_port():
@@ -94,6 +94,55 @@ def test_global_argmin_edge_cases_and_exact_indices():
     for rank, c, i in res:
         assert i.tolist() == [base + 2, base + 77, -1, base + 3]
         assert c[0] == -7.5 and c[1] == 3.0 and np.isinf(c[2]) and c[3] == 5.0
+
+
+def _worker_winner(rank, world, port, costs, ctrl, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, P = ctrl.shape
+    lo, hi = shard_bounds(B, world, rank)
+    per = (B + world - 1) // world
+    local = torch.from_numpy(costs[lo:hi]); lctrl = torch.from_numpy(ctrl[lo:hi])
+    j = int(torch.argmin(local))
+    solved = bool(torch.isfinite(local[j]))
+    bc = local[j:j + 1].clone(); bi = torch.tensor([lo + j if solved else -1], dtype=torch.int64)
+    c, i, w = global_argmin_with_winner(bc, bi, lctrl[j:j + 1])           # one all_gather: pair + control points
+    f = fetch_winner(lctrl, int(i[0]), per, lo)                            # the broadcast form
+    q.put((rank, float(c[0]), int(i[0]), w[0].numpy().copy(), None if f is None else f.numpy().copy()))
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["rank0 wins", "rank1 wins", "nobody solved", "one rank failed"])
+def test_winner_control_points_reach_every_rank(case):
+    """after the arg-min the winner's control points (12 S doubles) travel from their owner to every rank --
+    in the same all_gather as the (cost, index) pair (global_argmin_with_winner), or by one broadcast from the owner
+    (fetch_winner).  Both give the owner's row bit for bit, on every rank."""
+    rng = np.random.default_rng(11)
+    B, P = 1001, 240
+    costs = rng.normal(size=B) * 1e3
+    ctrl = rng.normal(size=(B, P))
+    if case == "rank0 wins": costs[17] = -1e9
+    if case == "rank1 wins": costs[900] = -1e9
+    if case == "nobody solved": costs[:] = np.inf
+    if case == "one rank failed": costs[:501] = np.inf
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_worker_winner, args=(r, 2, port, costs, ctrl, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in range(2)]
+    [p.join(timeout=60) for p in procs]
+    want = int(np.argmin(costs)) if np.isfinite(costs).any() else -1
+    for rank, c, i, w, f in res:
+        assert i == want
+        if want < 0:
+            assert np.isnan(w).all() and f is None and np.isinf(c)
+        else:
+            assert c == costs[want] and np.array_equal(w, ctrl[want]) and np.array_equal(f, ctrl[want])
+
+
+def test_winner_of_a_single_process_is_its_local_winner():
+    c, i, w = global_argmin_with_winner(torch.tensor([2.5], dtype=torch.float64), torch.tensor([7]), torch.arange(6, dtype=torch.float64)[None])
+    assert int(i[0]) == 7 and torch.equal(w[0], torch.arange(6, dtype=torch.float64))
+    assert fetch_winner(torch.arange(12, dtype=torch.float64).view(2, 6), 1, 2, 0).tolist() == [6, 7, 8, 9, 10, 11]
 
 
 def test_strong_scaling_shards_are_the_one_batch():

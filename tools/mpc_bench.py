@@ -2,7 +2,12 @@
 """BASELINE.json config 5: receding-horizon replanning, 128 ego agents x 512 candidate corridors of 20 segments,
 per-agent arg-min, cold vs warm-started solves.
 
-    python tools/mpc_bench.py [--steps 250] [--dt 0.02] [--agents 128] [--cand 512] [--cold] [--check 3]
+    python tools/mpc_bench.py [--steps 250] [--dt 0.02] [--agents 128] [--cand 512] [--cold] [--check 3] [--gpus N]
+
+--gpus N (SURVEY 8e, config 5 on 8 GPUs): the fleet is sharded BY AGENT -- rank r replans the agents
+shard_bounds(agents, N, r) with all their candidates, so every per-agent arg-min is local to a GPU and the step needs
+no collective at all; the ranks only meet after the last step to put their timings together (rank 0 reports the
+fleet's rate = the slowest rank's).  Without a torchrun environment the tool launches its N ranks itself, like bench.py.
 
 World: every candidate has a fixed corridor timeline of 1-s pieces (spectral_amd.synth, agents mode).  At step n
 the horizon starts at now = n*dt: the first segment is the rest of the piece containing `now` (its lines
@@ -50,19 +55,64 @@ def main(argv=None):
     ap.add_argument("--roll", default="cold", choices=["lam", "x0", "cold"],
                     help="what a step that rolls the window starts from: previous plan + rolled multipliers, plan only, nothing")
     ap.add_argument("--trace", action="store_true", help="per-step latency / iterations on stderr")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs; the agents are sharded over them")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (only the final timing gather uses it)")
+    ap.add_argument("--share-device", action="store_true", help="dry run on a 1-GPU box: every rank uses device 0 (with --backend gloo)")
+    ap.add_argument("--master-port", type=int, default=0)
     a = ap.parse_args(argv)
 
+    world_env = os.environ.get("WORLD_SIZE")
+    if a.gpus > 1 and world_env is None:
+        # become the launcher, before anything touches the GPU (bench.py does the same)
+        import socket
+        import subprocess
+        import torch
+        if torch.cuda.device_count() < a.gpus and not a.share_device:
+            sys.stderr.write("mpc_bench.py: --gpus %d but only %d HIP device(s) visible\n" % (a.gpus, torch.cuda.device_count()))
+            raise SystemExit(3)
+        port = a.master_port
+        if not port:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+                                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+                                         + (list(argv) if argv is not None else sys.argv[1:]), env=env))
+    world_n = int(world_env or "1") if a.gpus > 1 else 1
+    rank = int(os.environ.get("RANK", "0")) if world_n > 1 else 0
+    local_rank = 0 if (a.share_device or world_n == 1) else int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world_n != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world_n))
+
     import torch
+    import torch.distributed as dist
     from spectral_amd import layout as L
     from spectral_amd import synth
+    from spectral_amd.dist import shard_bounds
     from spectral_amd.solver import BatchSolver, DeviceBatch
 
-    S, G, C = a.segments, a.agents, a.cand
-    B = G * C
+    own_pg = False
+    if world_n > 1:
+        torch.cuda.set_device(local_rank)
+        if not dist.is_initialized():        # (bench.py calls this tool with its process group up)
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(a.backend)
+            own_pg = True
+    S, G_all, C = a.segments, a.agents, a.cand
     horizon_pieces = S + int(np.ceil(a.steps * a.dt)) + 2
     assert horizon_pieces <= 64
-    world, sh = synth.make_batch(B, horizon_pieces, config=5, variant=a.variant, agents=G, lateral_per_agent=True)
-    solver = BatchSolver(0)
+    # the whole fleet's world from one seed (what a 1-GPU run sees), then this rank's agents
+    world, sh = synth.make_batch(G_all * C, horizon_pieces, config=5, variant=a.variant, agents=G_all, lateral_per_agent=True)
+    g_lo, g_hi = shard_bounds(G_all, world_n, rank)
+    G = g_hi - g_lo
+    if world_n > 1:
+        world = world.slice(g_lo * C, g_hi * C)
+    B = G * C
+    if G < 1:
+        raise SystemExit("rank %d has no agents (%d agents over %d ranks)" % (rank, G_all, world_n))
+    solver = BatchSolver(local_rank)
     dev = solver.device
     wseg = torch.from_numpy(world.seg).to(dev)                       # [F][B][pieces]
     dl_bounds = torch.from_numpy(world.dl_bounds).to(dev)
@@ -144,7 +194,7 @@ def main(argv=None):
             for g in (0, G // 2, G - 1):
                 wi = int(bi[g].item())
                 if wi >= 0:
-                    dumped.append(dict(step=n, agent=g, seg=seg[:, wi].cpu().numpy(), init=db.init[wi].cpu().numpy(),
+                    dumped.append(dict(step=n, agent=g_lo + g, seg=seg[:, wi].cpu().numpy(), init=db.init[wi].cpu().numpy(),
                                        ref_end=ref_end[wi].cpu().numpy(), dl_bounds=world.dl_bounds[wi],
                                        ctrl=out["ctrl"][wi].cpu().numpy()))
         prev = dict(db=db, ctrl=out["ctrl"], lam=out.get("lam"), j0=j0, iters=out["iters"])
@@ -153,7 +203,7 @@ def main(argv=None):
     steady = lat[1:] if len(lat) > 1 else lat
     result = {
         "workload": "BASELINE.json config 5: %d agents x %d candidates, %d segments, replanned every %.0f ms, %d steps, %s"
-                    % (G, C, S, 1e3 * a.dt, a.steps, "cold start every step" if a.cold else "warm start"),
+                    % (G_all, C, S, 1e3 * a.dt, a.steps, "cold start every step" if a.cold else "warm start"),
         "mode": "cold" if a.cold else "warm", "min_first_segment_s": a.min_first,
         "achieved_hz": 1e3 / float(steady.mean()), "target_hz": 1.0 / a.dt,
         "p50_step_ms": float(np.percentile(steady, 50)), "p99_step_ms": float(np.percentile(steady, 99)),
@@ -163,7 +213,32 @@ def main(argv=None):
         "solved_fraction_mean": float(np.mean(solved)), "solved_fraction_min": float(np.min(solved)),
         "candidates_per_s": B * 1e3 / float(steady.mean()),
         "dumped_winners": len(dumped),
+        "n_gpus": world_n, "agents_per_gpu": G, "parallelism": "agents sharded over %d GPU(s), per-agent arg-min local, no collective" % world_n,
+        "last_winners": [int(v) + g_lo * C if v >= 0 else -1 for v in bi.cpu().tolist()],   # global candidate indices, this rank's agents
     }
+    if world_n > 1:
+        # after the last step: the ranks' figures side by side (gloo side group: python objects, not on the data path)
+        side = dist.new_group(backend="gloo")
+        allr = [None] * world_n
+        dist.all_gather_object(allr, result, group=side)
+        if rank == 0:
+            result = dict(allr[0])
+            result["achieved_hz"] = min(r["achieved_hz"] for r in allr)          # a fleet replans as fast as its slowest shard
+            result["achieved_hz_by_rank"] = [r["achieved_hz"] for r in allr]
+            result["p50_step_ms"] = max(r["p50_step_ms"] for r in allr); result["p99_step_ms"] = max(r["p99_step_ms"] for r in allr)
+            result["candidates_per_s"] = sum(r["candidates_per_s"] for r in allr)
+            result["mean_ipm_iterations"] = float(np.mean([r["mean_ipm_iterations"] for r in allr]))
+            result["solved_fraction_mean"] = float(np.mean([r["solved_fraction_mean"] for r in allr]))
+            result["solved_fraction_min"] = min(r["solved_fraction_min"] for r in allr)
+            result["last_winners"] = [w for r in allr for w in r["last_winners"]]
+            result["dumped_winners"] = sum(r["dumped_winners"] for r in allr)
+        dist.barrier()
+        if own_pg:
+            dist.destroy_process_group()
+    if rank != 0:
+        if a.dump:
+            np.savez(a.dump + ".rank%d.npz" % rank, **{"%s_%d" % (k, i): v for i, d_ in enumerate(dumped) for k, v in d_.items()}, n=len(dumped))
+        return result
     print(json.dumps(result))
     if a.dump:
         np.savez(a.dump, **{"%s_%d" % (k, i): v for i, d_ in enumerate(dumped) for k, v in d_.items()}, n=len(dumped))
