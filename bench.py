@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second figure on the other workload")
-    ap.add_argument("--latency-reps", type=int, default=200,
+    ap.add_argument("--latency-reps", type=int, default=1000,
                     help="B=1 launches for the p50 latency (0 skips them, e.g. under rocprofv3 so that the "
                          "kernel's average duration is the batch launch alone)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -371,6 +371,14 @@ def main():
             lat = np.array(lat[20:]) * 1e3
             out["p50_solve_latency_ms"] = float(np.percentile(lat, 50))
             out["p99_solve_latency_ms"] = float(np.percentile(lat, 99))
+            out["solve_latency_reps"] = int(len(lat))
+            # (one candidate runs the split form of the kernel -- one candidate per wavefront, rows over three lanes,
+            #  btrapz_options.split -- when it has at most 21 segments; the packed form beside it)
+            lat_p = []
+            for i in range(a.latency_reps // 2 + 20):
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter(); solver.solve(one, shared, split=-1); torch.cuda.synchronize(dev); lat_p.append(time.perf_counter() - t1)
+            out["p50_solve_latency_packed_form_ms"] = float(np.percentile(np.array(lat_p[20:]) * 1e3, 50))
             lat_h = []
             b1 = batch.slice(0, 1)
             for i in range(max(20, a.latency_reps // 4)):

@@ -77,6 +77,7 @@ struct CorridorArgs {
 };
 
 __global__ void corridor_batch_kernel(const CorridorArgs a, int staged);
+__global__ void corridor_batch_short_kernel(const CorridorArgs a, int staged);   // N <= 128
 // fixed_S = 0: bucket by segment count (ragged batches); > 0: uniform batch of fixed_S segments, bucket by hint class
 __global__ void bucket_hist_kernel(int B, int seg_stride, const int *seg_count, int *meta, int fixed_S);
 __global__ void bucket_prefix_kernel(int *meta, int fixed_S);
@@ -111,6 +112,8 @@ __global__ void single_candidate_kernel(const KernelArgs a, const double *__rest
                                         double *out);
 __global__ void single_candidate_split_kernel(const KernelArgs a, const double *__restrict__ mqm, double delta, int max_points,
                                               double *out);
+__global__ void single_candidate_warm_split_kernel(const KernelArgs a, const double *__restrict__ mqm, double delta, int max_points,
+                                                   double *out);
 __global__ void single_candidate_warm_kernel(const KernelArgs a, const double *__restrict__ mqm, double delta, int max_points,
                                              double *out);
 

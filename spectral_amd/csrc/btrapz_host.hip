@@ -252,6 +252,9 @@ int btrapz_launch_single(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_op
   if (c->ws_used && c->ws_stream != stream) HIPCHK(c, hipStreamWaitEvent(stream, c->ws_free, 0));
   a.axis_obj = c->d_axis_obj; a.axis_status = c->d_axis_status; a.axis_iters = c->d_axis_iters;
   a.ctrl = c->d_single; a.queue = nullptr; a.x_out = nullptr; a.axis_viol = nullptr;
+  // at most 21 segments: the split form (rows of a segment over three lanes), ~0.8 of the time per iteration
+  const char *split_e = getenv("BTRAPZ_SPLIT");   // (read per call: tests switch it)
+  const bool split_form = S <= 21 && !(split_e && *split_e == '0') && !(opt && opt->split < 0);
   if (warm) {
     const size_t nx = 2 * 64 * 3, nl = 2 * 36 * 64, set = nx + nl;
     if (!c->d_single_warm) HIPCHK(c, hipMalloc(&c->d_single_warm, sizeof(double) * 2 * set));
@@ -261,12 +264,12 @@ int btrapz_launch_single(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_op
     a.x0 = have ? rd : nullptr; a.lam0 = have ? rd + nx : nullptr;
     a.x_out = wr; a.lam_out = wr + nx;
     c->single_flip = 1 - c->single_flip; c->single_S = S; c->single_variant = sh->variant;
-    hipLaunchKernelGGL(single_candidate_warm_kernel, dim3(1), dim3(128), 0, stream, a, mqm, sh->delta, max_points, out);
+    if (split_form)
+      hipLaunchKernelGGL(single_candidate_warm_split_kernel, dim3(1), dim3(128), 0, stream, a, mqm, sh->delta, max_points, out);
+    else
+      hipLaunchKernelGGL(single_candidate_warm_kernel, dim3(1), dim3(128), 0, stream, a, mqm, sh->delta, max_points, out);
   } else {
-    // at most 21 segments: the split form (rows of a segment over three lanes), ~0.7 of the time per iteration
-    const char *split_e = getenv("BTRAPZ_SPLIT");   // (read per call: tests switch it)
-    const bool split_off = split_e && *split_e == '0';
-    if (S <= 21 && !split_off && !(opt && opt->split < 0))
+    if (split_form)
       hipLaunchKernelGGL(single_candidate_split_kernel, dim3(1), dim3(128), 0, stream, a, mqm, sh->delta, max_points, out);
     else
       hipLaunchKernelGGL(single_candidate_kernel, dim3(1), dim3(128), 0, stream, a, mqm, sh->delta, max_points, out);
@@ -518,12 +521,14 @@ BTRAPZ_EXPORT int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B
   const bool two_pass = cap_o_small < cap_o_big || cap_sel_small < cap_sel_big;
   a.pass = 0; a.cap_o = cap_o_small; a.cap_sel = cap_sel_small;
   if (!two_pass) { a.retry_list = nullptr; a.retry_count = nullptr; }
-  hipLaunchKernelGGL(corridor_batch_kernel, dim3(B), dim3(64), lds_bytes(a.cap_o, a.cap_sel), stream, a, staged);
+  // (horizons of at most 128 knots: the instantiation that holds half the prefetch registers)
+  auto kernel = N <= 128 ? corridor_batch_short_kernel : corridor_batch_kernel;
+  hipLaunchKernelGGL(kernel, dim3(B), dim3(64), lds_bytes(a.cap_o, a.cap_sel), stream, a, staged);
   HIPCHK(c, hipGetLastError());
   if (two_pass) {
     a.pass = 1; a.cap_o = cap_o_big; a.cap_sel = cap_sel_big;
     const unsigned blocks = B < 1024 ? (unsigned)B : 1024u;
-    hipLaunchKernelGGL(corridor_batch_kernel, dim3(blocks), dim3(64), lds_bytes(a.cap_o, a.cap_sel), stream, a, staged);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds_bytes(a.cap_o, a.cap_sel), stream, a, staged);
   }
   HIPCHK(c, hipGetLastError());
   return BTRAPZ_OK;

@@ -257,7 +257,7 @@ template <bool WARM, bool ORDERED, bool ELASTIC = false, bool QUEUE = false, boo
 __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double *__restrict__ mqm, double (*lds)[64],
                                                const int wave_id, const int lane) {
   static_assert(!QUEUE || (!WARM && !ORDERED && !ELASTIC), "the queue serves uniform cold batches");
-  static_assert(!SPLIT || (!WARM && !ORDERED && !ELASTIC && !QUEUE), "the split form serves uniform cold batches");
+  static_assert(!SPLIT || (!ORDERED && !ELASTIC && !QUEUE), "the split form serves uniform batches");
   constexpr bool CACHE_RP = !ELASTIC;   // see the main loop
   constexpr bool FULL = ELASTIC;                 // rows kept: see rows_kept()
   constexpr int NR = rows_kept<FULL>();
@@ -330,6 +330,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   asm volatile("" : "+v"(sjf0), "+v"(sjf1));
   [[maybe_unused]] const bool sj0 = sjf0 != 0, sj1 = sjf1 != 0;
 #define SEL3(x0, x1, x2) (sj0 ? (x0) : sj1 ? (x1) : (x2))
+  // rows of the lane's five slots (split_owner_*), for the warm-start arrays
+  [[maybe_unused]] const int slot_row[5] = {15 + sj, 12 + sj, 7 + sj, 1 + 2 * sj, sj == 2 ? 10 : 2 + 2 * sj};
   // values of the lane's five rows for control points c (the expressions of row_dot, on the lane's window c[j..j+3])
   [[maybe_unused]] auto slot_vals = [&](const double (&cc_)[6], double (&v)[5]) {
     // (values pinned in registers first: a choice between elements of an array in memory becomes a load from a chosen
@@ -565,6 +567,20 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       U_apply(nm, Xp, c[0], c[1], c[2]);
       V_apply(nm, X, c[3], c[4], c[5]);
       const double smin = a.smin, mu0 = a.mu0;
+      if constexpr (SPLIT) {
+        double v5[5];
+        slot_vals(c, v5);
+        UNROLL for (int i = 0; i < 5; i++) {
+          const double s_l = fmax(v5[i] - lo5[i], smin), s_u = fmax(up5[i] - v5[i], smin);
+          double l_l = 0.0, l_u = 0.0;
+          if (a.lam0) {
+            const double p_l = a.lam0[lam_e + (size_t)slot_row[i] * lam_row], p_u = a.lam0[lam_e + (size_t)(18 + slot_row[i]) * lam_row];
+            l_l = (p_l >= 0.0 && p_l < 1e300) ? p_l : 0.0; l_u = (p_u >= 0.0 && p_u < 1e300) ? p_u : 0.0;
+          }
+          sl5[i] = s_l; su5[i] = s_u;
+          ll5[i] = l_l + mu0 * rcp(s_l); lu5[i] = l_u + mu0 * rcp(s_u);
+        }
+      } else {
       FOR_ROWS(r)
         const double gc_r = row_dot<r>(c, t);
         const double s_l = fmax(gc_r - LO(r), smin), s_u = fmax(UP(r) - gc_r, smin);
@@ -576,6 +592,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         sl[SI(r)] = s_l; su[SI(r)] = s_u;
         LL(r) = l_l + mu0 * rcp(s_l); LU(r) = l_u + mu0 * rcp(s_u);
       END_ROWS
+      }
     } else {
       cold_start();
     }
@@ -591,10 +608,17 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   };
   auto write_back = [&]() {
     // ---------------- write back: multipliers (warm start of a later solve), control points, objective/status ----
-    if (WARM && a.lam_out && valid) {
+    if (WARM && SPLIT && a.lam_out && valid) {   // every lane of a segment writes its own five rows
+      UNROLL for (int i = 0; i < 5; i++) {
+        a.lam_out[lam_e + (size_t)slot_row[i] * lam_row] = ll5[i]; a.lam_out[lam_e + (size_t)(18 + slot_row[i]) * lam_row] = lu5[i];
+      }
+    }
+    if (WARM && !SPLIT && a.lam_out && valid) {
       FOR_ROWS(r)
         a.lam_out[lam_e + (size_t)r * lam_row] = LL(r); a.lam_out[lam_e + (size_t)(18 + r) * lam_row] = LU(r);
       END_ROWS
+    }
+    if (WARM && a.lam_out && valid && (!SPLIT || g == 0)) {
       if constexpr (!FULL) {   // the rows this lane does not keep (their bounds live in the previous segment's last rows)
         UNROLL for (int r0 = 0; r0 < 3; r0++) {
           const int rr_ = r0 == 0 ? 0 : r0 == 1 ? 6 : 11;
@@ -602,7 +626,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         }
       }
     }
-    if (WARM && a.x_out && valid) {   // joint states of the returned iterate: x0 of a later solve of a nearby problem
+    if (WARM && a.x_out && valid && (!SPLIT || g == 0)) {   // joint states of the returned iterate: x0 of a later solve of a nearby problem
       double *xo = a.x_out + (((size_t)b * 2 + axis) * a.seg_stride + k) * 3;
       xo[0] = Xb[0]; xo[1] = Xb[1]; xo[2] = Xb[2];
     }
@@ -1523,6 +1547,10 @@ __global__ __launch_bounds__(128) void single_candidate_kernel(const KernelArgs 
 __global__ __launch_bounds__(128) void single_candidate_split_kernel(const KernelArgs a, const double *__restrict__ mqm,
                                                                      double delta, int max_points, double *out) {
   single_candidate_body<false, true>(a, mqm, delta, max_points, out);
+}
+__global__ __launch_bounds__(128) void single_candidate_warm_split_kernel(const KernelArgs a, const double *__restrict__ mqm,
+                                                                          double delta, int max_points, double *out) {
+  single_candidate_body<true, true>(a, mqm, delta, max_points, out);
 }
 // ... starting from the joint states and multipliers the previous call left on the device (find_traj in a replanning
 // loop, BTRAPZ_WARM=1), and leaving its own for the next one

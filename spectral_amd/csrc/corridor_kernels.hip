@@ -30,22 +30,33 @@ enum { MAX_ALL = 160, MAX_SEL = 64 };   // capacities of the retry pass (see btr
 // Dynamic LDS: Seg all[O * cap_o] (later: Seg sel[cap_sel], same storage) | slopes[O][N][2] (when `staged`; later, same
 //              storage: s_ref[N] | l_ref[N] | ds_bounds[N][2]) |
 //              int hits[O * cap_o] | int ocount[64] | int key[cap_sel] | short slot_of[O * cap_o] | short pick[cap_sel]
+// RB: blocks of 64 knots of the reference and the ds bounds held in registers across the extraction (2 serve N <= 128).
+template <int RB>
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw);
 
 #ifndef CABL_WAVES
 #define CABL_WAVES 4
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 8))) void corridor_batch_kernel(const CorridorArgs a, int staged) {
+template <int RB>
+__device__ __forceinline__ void corridor_batch_body(const CorridorArgs &a, int staged) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   if (a.pass == 0) {
-    corridor_candidate(a, staged, (int)blockIdx.x, lds_raw);
+    corridor_candidate<RB>(a, staged, (int)blockIdx.x, lds_raw);
   } else {  // retry pass: the candidates the first pass could not hold
     const int n = *a.retry_count;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
-      corridor_candidate(a, staged, a.retry_list[i], lds_raw);
+      // (the candidate's number is the same in every lane: say so, or every address derived from it costs vector registers)
+      corridor_candidate<RB>(a, staged, __builtin_amdgcn_readfirstlane(a.retry_list[i]), lds_raw);
       __syncthreads();
     }
   }
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 8))) void corridor_batch_kernel(const CorridorArgs a, int staged) {
+  corridor_batch_body<4>(a, staged);
+}
+// horizons of at most 128 knots (the bundled scenes have 71-121): half the prefetch registers
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 8))) void corridor_batch_short_kernel(const CorridorArgs a, int staged) {
+  corridor_batch_body<2>(a, staged);
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {  // l: the same in every lane
@@ -109,9 +120,12 @@ __device__ __forceinline__ bool find_breaks_wave(const CorridorArgs &a, int lane
   __syncthreads();
   return __builtin_amdgcn_readlane(wave_inclusive_scan(my_nb > 0 ? my_nb : 0, lane), 63) <= 64;
 }
+// after_slopes(): called by every lane once the slope table has been read for the last time (the caller stores the
+// prefetched reference over it there: held in registers any longer, the allocator spills the prefetch to scratch)
+template <class F>
 __device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int lane, const double *gs, const double *gl,
                                                     const double *slopes, Seg *all, int cap_o, int *ocount, const int *brk,
-                                                    short *first, int my_nb) {
+                                                    short *first, int my_nb, F &&after_slopes) {
   const int N = a.N, O = a.num_obs;
   const double2 *sk2 = reinterpret_cast<const double2 *>(slopes);
   const int nbp = my_nb > 0 ? my_nb : 0;
@@ -125,10 +139,12 @@ __device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int l
   Seg s = seg_default();
   int h = 0;
   bool bad = false;
+  double2 slope = make_double2(0.0, 0.0);
+  if (mo >= 0) slope = sk2[(size_t)mo * N + brk[mo * cap_o + mk] + 1];
+  after_slopes();
   if (mo >= 0) {
     const int beg = brk[mo * cap_o + mk];
     const BoundsView sb{gs + (size_t)mo * N * 2}, lb{gl + (size_t)mo * N * 2};
-    const double2 slope = sk2[(size_t)mo * N + beg + 1];
     s.beg_t = beg;
     s.end_t = mk + 1 < mn ? brk[mo * cap_o + mk + 1] : N - 1;
     s.down_skew = slope.x; s.down_bias = sb.lo(beg);
@@ -174,6 +190,7 @@ __device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int l
   }
 }
 
+template <int RB>
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw) {
   const int lane = threadIdx.x;
   const int N = a.N, O = a.num_obs;
@@ -204,12 +221,13 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   const int n2 = O * N;  // (lower, upper) pairs
   const double2 *gs2 = reinterpret_cast<const double2 *>(gs);
   double2 *sk2 = reinterpret_cast<double2 *>(slopes);
-  double2 cur[4], prv[4];
+  double cur_lo[4], cur_hi[4], prv_lo[4], prv_hi[4];
   auto load_pairs = [&](int base) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int i = base + u * 64 + lane, ic = i < n2 ? i : n2 - 1;
-      cur[u] = gs2[ic]; prv[u] = gs2[ic > 0 ? ic - 1 : 0];
+      const double2 c2 = gs2[ic], p2 = gs2[ic > 0 ? ic - 1 : 0];
+      cur_lo[u] = c2.x; cur_hi[u] = c2.y; prv_lo[u] = p2.x; prv_hi[u] = p2.y;
     }
   };
   auto store_slopes = [&](int base) {
@@ -217,7 +235,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     for (int u = 0; u < 4; u++) {
       const int i = base + u * 64 + lane;
       if (i < n2 && i % N > 0)  // (b(i) - b(i-1)) / delta: the expression of SlopesOnTheFly
-        sk2[i] = make_double2((cur[u].x - prv[u].x) / a.delta, (cur[u].y - prv[u].y) / a.delta);
+        sk2[i] = make_double2((cur_lo[u] - prv_lo[u]) / a.delta, (cur_hi[u] - prv_hi[u]) / a.delta);
     }
   };
   if (staged) {
@@ -229,23 +247,23 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   // as the bounds at the segment starts
   const double *gsr = a.s_ref + (size_t)b * N, *glr = a.l_ref + (size_t)b * N;
   const double2 *gds = reinterpret_cast<const double2 *>(a.ds_bounds + (size_t)b * N * 2);
-  double ref_s[4], ref_l[4];
-  double2 ref_ds[4];
+  double ref_s[RB], ref_l[RB], ref_dlo[RB], ref_dhi[RB];   // (scalars: an array of double2 behind a lambda stays in scratch)
   auto load_refs = [&](int base) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < RB; u++) {
       const int i = base + u * 64 + lane, ic = i < N ? i : N - 1;
-      ref_s[u] = gsr[ic]; ref_l[u] = glr[ic]; ref_ds[u] = gds[ic];
+      const double2 d = gds[ic];
+      ref_s[u] = gsr[ic]; ref_l[u] = glr[ic]; ref_dlo[u] = d.x; ref_dhi[u] = d.y;
     }
   };
   bool refs_finite = true;
   auto store_refs = [&](int base) {
     double2 *d2 = reinterpret_cast<double2 *>(dsb);
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < RB; u++) {
       const int i = base + u * 64 + lane;
       if (i < N) {
-        sref[i] = ref_s[u]; lref[i] = ref_l[u]; d2[i] = ref_ds[u];
+        sref[i] = ref_s[u]; lref[i] = ref_l[u]; d2[i] = make_double2(ref_dlo[u], ref_dhi[u]);
         refs_finite = refs_finite && fabs(ref_s[u]) < 1e300 && fabs(ref_l[u]) < 1e300;
       }
     }
@@ -260,8 +278,13 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   int my_nb = 0;
   const bool wide = staged && find_breaks_wave(a, lane, slopes, cap_o, hits, my_nb);
   load_refs(0);
+  bool refs_stored = false;
   if (wide) {
-    build_segments_wave(a, lane, gs, gl, slopes, all, cap_o, ocount, hits, slot_of, my_nb);
+    build_segments_wave(a, lane, gs, gl, slopes, all, cap_o, ocount, hits, slot_of, my_nb, [&]() {
+      __syncthreads();                                     // every lane has its slopes: the table may be overwritten
+      store_refs(0);
+    });
+    refs_stored = true;
   } else {
     __syncthreads();
     if (lane < O) {  // the serial statement: lane o owns obstacle o
@@ -274,8 +297,8 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   }
 #endif
   __syncthreads();                                         // the slope table has been read for the last time
-  store_refs(0);
-  for (int base = 256; base < N; base += 256) { load_refs(base); store_refs(base); }
+  if (!refs_stored) store_refs(0);
+  for (int base = 64 * RB; base < N; base += 64 * RB) { load_refs(base); store_refs(base); }
   refs_finite = __all(refs_finite);
   __syncthreads();
   // ---- selection along the reference (solve_3d.cc:534-596): knots inside every segment, the lanes spread over

@@ -69,6 +69,20 @@ if [ "$QUICK" != "quick" ]; then
   step bench_config4 "$OUT/bench_config4.json" python3 "$BENCH" --variant 1 --no-cpu-baseline
   step bench_generic "$OUT/bench_generic.json" python3 "$BENCH" --workload generic --no-cpu-baseline
   step bench_2rank "$OUT/bench_2rank_gloo_strong.json" python3 "$BENCH" --gpus 2 --backend gloo --share-device --scaling strong --no-cpu-baseline --latency-reps 0
+  # round 3: kernel traces of the other pipelines and of find_traj's single launch; the split form
+  # against the packed one; BASELINE config 5 sharded by agent over two ranks that share the box's one GPU
+  step trace_pipeline_s1 "$OUT/pipeline_scenario1_under_rocprof.json" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_pipeline_s1" -- \
+    python3 "$ROOT/tools/pipeline_bench.py" --scenario1
+  step trace_pipeline_prisms "$OUT/pipeline_prisms_under_rocprof.json" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_pipeline_prisms" -- \
+    python3 "$ROOT/tools/pipeline_bench.py" --prisms
+  step trace_find_traj "$OUT/find_traj_under_rocprof.json" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_find_traj" -- \
+    python3 "$ROOT/tools/find_traj_loop.py"
+  export BTRAPZ_SPLIT=0
+  step trace_find_traj_packed "$OUT/find_traj_packed_under_rocprof.json" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_find_traj_packed" -- \
+    python3 "$ROOT/tools/find_traj_loop.py"
+  unset BTRAPZ_SPLIT
+  step split_bench "$OUT/split_bench.json" python3 "$ROOT/tools/split_bench.py"
+  step mpc_2rank "$OUT/mpc_warm_2rank_gloo.json" python3 "$ROOT/tools/mpc_bench.py" --gpus 2 --backend gloo --share-device
 fi
 # keep only the CSVs (the merge-back limit is 64 MiB)
 find "$OUT" -name "*.db" -delete 2>/dev/null

@@ -29,8 +29,11 @@ def main(argv=None):
     lat = []
     for i in range(a.calls):
         t = time.perf_counter(); cost, traj, ctrl = native.find_traj_mem(0, prm, kb); lat.append(time.perf_counter() - t)
-    print({"p50_ms": float(np.percentile(np.array(lat[10:]) * 1e3, 50)), "iterations": int(native.lib().btrapz_find_traj_last_iterations()),
-           "segments": None if ctrl is None else len(ctrl) // 12})
+    import json
+    print(json.dumps({"p50_ms": float(np.percentile(np.array(lat[10:]) * 1e3, 50)), "calls": a.calls,
+                      "iterations": int(native.lib().btrapz_find_traj_last_iterations()),
+                      "segments": None if ctrl is None else len(ctrl) // 12, "warm": bool(a.warm),
+                      "split_form": os.environ.get("BTRAPZ_SPLIT", "1") != "0"}))
 
 
 if __name__ == "__main__":

@@ -32,12 +32,32 @@ def counter_means(root, pattern="pmc_*", kernel=KERNEL):
                     continue
                 acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
                 acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
-                res = dict(vgpr=row["VGPR_Count"], agpr=row["Accum_VGPR_Count"], sgpr=row["SGPR_Count"],
-                           lds=row["LDS_Block_Size"], scratch=row["Scratch_Size"], grid=row["Grid_Size"])
+                # rocprofv3's register columns are NOT the compiler's VGPR / AGPR counts: on gfx950 it reports the unified
+                # allocation (VGPR + AGPR, rounded up to the granule of 8) divided by two under VGPR_Count and 0 under
+                # Accum_VGPR_Count (256 + 199 -> 456 / 2 = 228).  Kept under names that say so; the compiler's figures
+                # are added by compiler_resources() below.
+                res = dict(rocprof_VGPR_Count_field=row["VGPR_Count"], rocprof_Accum_VGPR_Count_field=row["Accum_VGPR_Count"],
+                           sgpr=row["SGPR_Count"], lds=row["LDS_Block_Size"], scratch=row["Scratch_Size"], grid=row["Grid_Size"])
         for name, per in acc.items():
             vals = list(per.values())
             out[name] = dict(mean=sum(vals) / len(vals), min=min(vals), max=max(vals), launches=len(vals), **res)
     return out
+
+
+def compiler_resources(here, kernel="ipm_solve_kernelE"):
+    """VGPR / AGPR / scratch / LDS of the kernel as the compiler reports them (tools/kernel_resources.sh)."""
+    import re
+    import subprocess
+    try:
+        txt = subprocess.run(["bash", os.path.join(here, "tools", "kernel_resources.sh")], capture_output=True, text=True, timeout=900).stdout
+    except Exception:
+        return None
+    for line in txt.splitlines():
+        if kernel in line:
+            g = lambda pat: int(re.search(pat + r"\s*(\d+)", line).group(1))
+            return dict(vgpr=g(r"VGPRs:"), agpr=g(r"AGPRs:"), sgpr=g(r"TotalSGPRs:"), scratch_bytes_per_lane=g(r"ScratchSize \[bytes/lane\]:"),
+                        lds_bytes_per_block=g(r"LDS Size \[bytes/block\]:"), waves_per_simd=g(r"Occupancy \[waves/SIMD\]:"))
+    return None
 
 
 def main():
@@ -56,11 +76,13 @@ def main():
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
-    pstats = glob.glob(os.path.join(src, "trace_pipeline", "**", "*kernel_stats.csv"), recursive=True)
-    if pstats:
-        shutil.copy(max(pstats, key=os.path.getmtime), os.path.join(dst, f"{tag}_pipeline_kernel_stats.csv"))
+    for sub, name in (("trace_pipeline", "pipeline"), ("trace_pipeline_s1", "pipeline_scenario1"), ("trace_pipeline_prisms", "pipeline_prisms"),
+                      ("trace_find_traj", "find_traj"), ("trace_find_traj_packed", "find_traj_packed")):
+        pstats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+        if pstats:
+            shutil.copy(max(pstats, key=os.path.getmtime), os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
     for name in ("mpc_warm", "mpc_cold", "mpc_warm_minfirst05", "mpc_cold_minfirst05", "pipeline", "pipeline_scenario1", "pipeline_prisms",
-                 "bench_config2", "bench_config4", "bench_generic", "bench_2rank_gloo_strong"):
+                 "bench_config2", "bench_config4", "bench_generic", "bench_2rank_gloo_strong", "split_bench", "mpc_warm_2rank_gloo"):
         if os.path.exists(os.path.join(src, name + ".json")):
             # the tools print ONE JSON line; libraries may print before it (gloo announces its ranks on stdout)
             lines = [l for l in open(os.path.join(src, name + ".json")).read().splitlines() if l.lstrip().startswith("{")]
@@ -91,8 +113,10 @@ def main():
     for k in ("FETCH_SIZE", "WRITE_SIZE"):
         if k in c:
             hbm[k] = dict(launches=c[k]["launches"], mean_KB=c[k]["mean"], min_KB=c[k]["min"], max_KB=c[k]["max"],
-                          **{r: c[k][r] for r in ("vgpr", "agpr", "sgpr", "lds", "scratch", "grid")})
+                          **{r: c[k][r] for r in ("rocprof_VGPR_Count_field", "rocprof_Accum_VGPR_Count_field", "sgpr", "lds", "scratch", "grid")})
+    cres = compiler_resources(here)
     if len(hbm) == 2:
+        hbm["compiler_resources"] = cres
         hbm["workload"] = wl
         hbm["kernel_source_hash"] = stamp
         hbm["calibration"] = calib
@@ -132,7 +156,7 @@ def main():
                             f64.get("SQ_INSTS_VALU_ADD_F64", 0) + f64.get("SQ_INSTS_VALU_TRANS_F64", 0))
             derived["fp64_flops_per_launch_all_lanes"] = flops
             derived["fp64_share_of_valu_instructions"] = sum(f64.values()) / sq["SQ_INSTS_VALU"]
-        json.dump(dict(kernel=KERNEL, workload=wl, kernel_source_hash=stamp, per_launch=sq, derived=derived,
+        json.dump(dict(kernel=KERNEL, workload=wl, kernel_source_hash=stamp, compiler_resources=cres, per_launch=sq, derived=derived,
                        note="rocprofv3 --pmc passes (tools/collect_profiles.sh), means over the launches of one "
                             "bench.py --steps 3 --warmup 1 run; SQ cycle counters are in units of 4 clock cycles."),
                   open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)
