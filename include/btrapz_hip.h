@@ -204,6 +204,11 @@ typedef struct btrapz_options {
    * 0 -> automatic (used when 2 B wavefronts fit the device's SIMDs at once); 1 -> whenever the batch qualifies;
    * -1 -> never.  Same problem, same method: results agree to rounding (the row sums are taken in another order). */
   int split;
+  /* Starting point of a cold solve.  0 (default): the initial state propagated at constant velocity.  1: from there,
+   * one Newton step of the problem WITHOUT its inequality rows first (one block solve with zero row weights, about half
+   * an iteration's work), i.e. the unconstrained optimum, then the usual slacks and multipliers.  The optimum does not
+   * depend on it; the iteration count does (measured: DESIGN.md 3.9). */
+  int start;
 } btrapz_options;
 /* Zeroes *opt (every field: "use the default") and sets struct_size.  Call it before filling the struct in. */
 void btrapz_options_init(btrapz_options *opt);

@@ -52,6 +52,7 @@ struct KernelArgs {
   const double *lam0;       // [2][36][B][seg_stride] multipliers of an earlier solve
   double *lam_out;          // same layout, multipliers at the end of this solve
   double mu0, smin;         // lambda = lam0 + mu0 / s , s = max(gap, smin)
+  int unc_start;            // btrapz_options.start: 1 = first one Newton step of the problem without its inequality rows
   int bucket_S;             // 0: the bucket id IS the segment count (ragged); else buckets are hint classes, S = bucket_S
   // rescue pass (btrapz_options.elastic): order = [2][B] per-axis lists, cand_prefix / wave_prefix = [2][198] tables
   double elastic_delta;     // penalty d^2 / (2 delta) on the relaxation d of every inequality row

@@ -189,6 +189,8 @@ static void fill_parameters(KernelArgs &a, const btrapz_shared *sh, const btrapz
   a.elastic_delta = (opt && opt->elastic_delta > 0) ? opt->elastic_delta : BTRAPZ_DEFAULT_ELASTIC_DELTA;
   a.elastic_tol = (opt && opt->elastic_tol > 0) ? opt->elastic_tol : BTRAPZ_DEFAULT_ELASTIC_TOL;
   a.bucket_S = 0;
+  static const int start_env = [] { const char *e = getenv("BTRAPZ_START"); return e ? atoi(e) : -1; }();
+  a.unc_start = start_env >= 0 ? start_env : (opt ? opt->start : 0);
 }
 
 // M' pQp_d M on the host (solve_3d.cc:87-143): the single-candidate path hands the table over with its inputs.

@@ -356,6 +356,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   float best_res = 3e38f;          // smallest residual part of the score so far and when (the stall test)
   int res_it = 0;
   bool plain = false;              // second chance of a solve whose complementarity is stuck: see the corrector
+  // btrapz_options.start = 1: before the first iteration one Newton step of the UNCONSTRAINED problem (all row weights
+  // zero: the block system is Phi' P Phi, its solution the optimum without the inequality rows), slacks re-initialised
+  // there.  The pass is the loop body up to the predictor's sweep; it is not counted as an iteration.
+  [[maybe_unused]] bool unc_pass = false;
   bool done = true;
   // The group's own iteration count.  (Warm-start instantiations: when one group of the wavefront restarts cold the
   // others lose that pass of the loop; queue: the groups of a wavefront are at different iterations.  A candidate's
@@ -378,8 +382,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 #define LL(r) lds[L_LL + SI(r)][lane]
 #define LU(r) lds[L_LU + SI(r)][lane]
   // cold start of this lane: slacks max(gap, 1), multipliers 1
-  auto cold_start = [&]() {
-    X[0] = Xcold0; X[1] = Xinit[1]; X[2] = 0.0;
+  // slacks max(gap, 1) and multipliers 1 at the current X
+  auto init_slacks = [&]() {
     double Xp[3], c[6];
     UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(X[i]); Xp[i] = first ? Xinit[i] : v; }
     U_apply(nm, Xp, c[0], c[1], c[2]);
@@ -398,6 +402,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         LL(r) = 1.0; LU(r) = 1.0;
       END_ROWS
     }
+  };
+  auto cold_start = [&]() {
+    X[0] = Xcold0; X[1] = Xinit[1]; X[2] = 0.0;
+    init_slacks();
   };
 
   // What a lane reads of its candidate: its segment's fields for the wavefront's axis and the candidate's per-axis
@@ -605,6 +613,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     best_score = 1e300; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2];
     best_it = 0; iters = 0; best_res = 3e38f; res_it = 0; plain = false;
     done = !valid || infeasible_bounds || no_solution;
+    unc_pass = !ELASTIC && !QUEUE && a.unc_start != 0 && !warm_started;
   };
   auto write_back = [&]() {
     // ---------------- write back: multipliers (warm start of a later solve), control points, objective/status ----
@@ -808,7 +817,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     const double res = fmax(rd_eff / (1.0 + qn), rr.c / (1.0 + bnorm));
     const double score = fmax(res, mu);
     bool restart_now = false;
-    if (!done) {
+    if (!done && !unc_pass) {
       iters = eit;
       if (score < best_score) { best_score = score; best_it = eit; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
       if ((float)res < a.stall_factor * best_res) { best_res = (float)res; res_it = eit; }
@@ -869,10 +878,11 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // needs exactly what this loop has in its hands -- the fresh reciprocals, the multipliers, G c -- so it is
       // accumulated here instead of in a row loop of its own (one pass over the rows and 72 LDS reads less).
       UNROLL for (int i = 0; i < 6; i++) hp[i] = gc[i];
+      const double wscale = unc_pass ? 0.0 : 1.0;   // (finite operands: slacks and multipliers are those of the cold start)
       if constexpr (SPLIT) {
         FOR_ROWS(r)
-          row_outer<r>(XR(5, r), t2, H);
-          row_scatter<r>(XR(10, r), t, hp);
+          row_outer<r>(XR(5, r) * wscale, t2, H);
+          row_scatter<r>(XR(10, r) * wscale, t, hp);
         END_ROWS
       } else {
       FOR_ROWS(r)
@@ -892,8 +902,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
           row_outer<r>((wl + wu) * ef, t2, H);
           row_scatter<r>((wl * (sl[SI(r)] + rpl) - wu * (su[SI(r)] - rpu)) * ef, t, hp);
         } else {
-          row_outer<r>(wl + wu, t2, H);
-          row_scatter<r>(wl * (sl[SI(r)] + rpl) - wu * (su[SI(r)] - rpu), t, hp);
+          row_outer<r>((wl + wu) * wscale, t2, H);
+          row_scatter<r>((wl * (sl[SI(r)] + rpl) - wu * (su[SI(r)] - rpu)) * wscale, t, hp);
         }
       END_ROWS
       }
@@ -1060,6 +1070,22 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 
     double dca[6], dX[3];
     double sigma_mu, second_order;   // second_order: -1, or 0 when the corrector leaves that term out (below)
+    if (__any(unc_pass)) {   // (the groups of a wavefront start together: a wave-uniform branch)
+      UNIFORM_BLOCK;
+      backward_u(up, dX, dca);
+      if (unc_pass && !done && fabs(dX[0]) < 1e300 && fabs(dX[1]) < 1e300 && fabs(dX[2]) < 1e300) {
+        UNROLL for (int i = 0; i < 3; i++) X[i] += dX[i];
+      }
+      // (a group takes the step as a whole or not at all: dX of a singular block system is not finite in every lane)
+      {
+        const Red4 rf = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, 0.0,
+                                                 (fabs(dX[0]) < 1e300 && fabs(dX[1]) < 1e300 && fabs(dX[2]) < 1e300) ? 0.0 : 1.0, 0.0, 0.0);
+        if (rf.b > 0.0 && unc_pass && !done) { X[0] = Xcold0; X[1] = Xinit[1]; X[2] = 0.0; }
+      }
+      if (unc_pass) { init_slacks(); Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
+      unc_pass = false;
+      continue;
+    }
     if constexpr (SPLIT) {
       // The same predictor / corrector / step as below (see the comments there) on the lane's own five rows; what a
       // row contributes to a right-hand side, and the statistics of the three lanes of a segment, go through LDS.

@@ -86,3 +86,26 @@ def test_find_traj_through_the_split_form(name, monkeypatch):
         assert abs(c0 - c1) <= 1e-7 * abs(c0) and np.abs(x0 - x1).max() <= 2e-6 * np.abs(x0).max()
         assert np.abs(t0 - t1).max() <= 2e-6 * max(1.0, np.abs(t0).max())
         assert it1 <= it0 + 1                      # (c_road_s1 sits at the round-off floor: 18 packed, 13 split)
+
+
+@pytest.mark.parametrize("gen,S,variant,split", [("scenario1", 20, 0, -1), ("generic", 10, 0, -1), ("scenario1", 20, 1, 1), ("generic", 7, 0, 1)])
+def test_unconstrained_start_reaches_the_same_optimum(gen, S, variant, split):
+    """btrapz_options.start = 1 (one Newton step of the problem without its inequality rows before the first iteration):
+    another starting point of the same strictly convex QP -- same candidates accepted, same optimum."""
+    import torch
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    B = 600
+    batch, sh = (synth.make_scenario1_batch(B, S, variant) if gen == "scenario1" else synth.make_batch(B, S, config=2, variant=variant))
+    db = solver.upload(batch)
+    a = {k: v.cpu().numpy().copy() for k, v in solver.solve(db, sh, split=split).items()}
+    b = {k: v.cpu().numpy().copy() for k, v in solver.solve(db, sh, split=split, start=1).items()}
+    torch.cuda.synchronize()
+    assert np.array_equal(a["status"] > 0, b["status"] > 0)
+    ok = a["status"] > 0
+    assert (np.abs(a["ctrl"][ok] - b["ctrl"][ok]).max(axis=1) / np.abs(a["ctrl"][ok]).max(axis=1)).max() <= 5e-6
+    assert not np.array_equal(a["iters"], b["iters"])          # (it IS another path)
+    xs, obj, st, _ = O.batch_solve(batch, sh, 0, 4, exact=True)
+    for i in range(4):
+        if ok[i]:
+            assert np.abs(b["ctrl"][i] - xs[i]).max() <= 1e-5 * np.abs(xs[i]).max()
