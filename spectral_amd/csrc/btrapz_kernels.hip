@@ -18,12 +18,14 @@
 //     the joint states X_j = (p, v, a), j = 1..S (null-space form, no equality multipliers);
 //   * every inequality row touches one segment only -> the Newton matrix of a primal-dual
 //     (Mehrotra predictor-corrector) interior-point method in X is block tridiagonal, 3x3 blocks.
-// Mapping: one lane per segment, floor(64/S) axis problems per wavefront.  The interior-point
-// state is split between VGPRs (36 slacks per lane) and LDS columns private to the lane (36
-// multipliers, 36 reciprocal slacks); a wavefront holds problems of ONE axis so the
-// batch-invariant M'QM table comes through scalar loads; neighbour exchange is
-// a DPP wave shift; the block LDL^T and its sweeps run two-sided (upper and lower half towards the
-// middle block) in S/2+1 sequential steps in which lanes s and S-1-s own the pivots.  HBM is touched once to load the Cube records and once to store results.
+// Mapping (packed form, the throughput kernel): one lane per segment, floor(64/S) axis problems per wavefront.  Per lane
+// and kept row (15 of a segment's 18: rows_kept) the interior-point state is a slack pair in VGPRs and a multiplier
+// pair plus a reciprocal-slack pair in LDS columns private to the lane (30 + 30 + 30 doubles); a wavefront holds problems
+// of ONE axis so the batch-invariant M'QM table comes through scalar loads; neighbour exchange is a DPP wave shift; the
+// block LDL^T and its sweeps run two-sided (upper and lower half towards the middle block) in S/2+1 sequential steps in
+// which lanes s and S-1-s own the pivots.  HBM is touched once to load the Cube records and once to store results.
+// Split form (few candidates, at most 21 segments; SPLIT in ipm_solve_body): ONE axis problem per wavefront, the rows
+// of every segment spread over three lanes, state in registers only, one scalar per row and phase exchanged through LDS.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>

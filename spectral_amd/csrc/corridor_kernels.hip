@@ -269,6 +269,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     }
   };
   __syncthreads();
+  bool refs_stored = false;
   // ---- per-obstacle extraction: lane o owns obstacle o ----
 #ifdef CABL_NOEXTRACT
   if (lane < O) { ocount[lane] = 1; all[lane * cap_o] = seg_default(); all[lane * cap_o].end_t = N - 1; all[lane * cap_o].t = 1.0; }
@@ -278,7 +279,6 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   int my_nb = 0;
   const bool wide = staged && find_breaks_wave(a, lane, slopes, cap_o, hits, my_nb);
   load_refs(0);
-  bool refs_stored = false;
   if (wide) {
     build_segments_wave(a, lane, gs, gl, slopes, all, cap_o, ocount, hits, slot_of, my_nb, [&]() {
       __syncthreads();                                     // every lane has its slopes: the table may be overwritten

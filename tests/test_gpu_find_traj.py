@@ -249,3 +249,20 @@ def test_find_traj_fuzz_against_the_oracle(elastic):
     m = re.match(r"calls (\d+) agree (\d+) accepted (\d+) rejected (\d+) mismatches (\d+)", last[-1])
     assert m and int(m.group(1)) == 240 and int(m.group(5)) == 0, last[-1]
     assert int(m.group(3)) >= 100 and int(m.group(4)) >= 40, last[-1]      # both decisions are exercised
+
+
+@pytest.mark.parametrize("ref,name,variant", [("s1_slt_3d_30.txt", "c1", 0), ("s1_cub_3d_3.txt", "c1", 1), ("s1_cub_3d_30.txt", "c1", 1)])
+def test_hip_path_reproduces_the_lateral_columns_of_saved_scenario1_files(ref, name, variant):
+    """The weights tests/golden/fit_weights.py found (weight_fit.json) through the HIP path: the l, dl, ddl columns of
+    three trajectory files the reference wrote from src/c1.txt, to print precision (north_star: parity on the bundled
+    scenario_1 corridors)."""
+    import json
+    from spectral_amd import knots
+    fit = json.load(open(os.path.join(GOLD, "weight_fit.json")))["fits"][ref]
+    want = np.loadtxt(os.path.join(GOLD, "ref_outputs", ref))
+    params = native.CParams(*[float(v) for v in fit["weights"]], 1)
+    cost, traj, ctrl = native.find_traj_mem(variant, params, knots.parse_corridor_file(os.path.join(GOLD, "inputs", name + ".txt")))
+    assert cost < 1e10 and traj.shape[1] == want.shape[0]
+    got = traj.T                                             # rows t s l ds dl dds ddl -> columns
+    assert np.abs(got[:, [2, 4, 6]] - want[:, [2, 4, 6]]).max() <= PRINT
+    assert np.abs(got[:, [1, 3, 5]] - want[:, [1, 3, 5]]).max() <= 0.021
