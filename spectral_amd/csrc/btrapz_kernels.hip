@@ -415,27 +415,28 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   // record in registers while the current one iterates (its loads are issued a whole solve ahead of their use).
   struct Record { double t, lb, ls, ub, us, begl, endl, v[10], skew, bias, ref_end, init[3]; };
   auto load_record = [&](const int b_) {
-    // Every load in ONE basic block (field numbers chosen by scalar selects, the 2 + 10 + 2 values only one axis or
-    // variant uses loaded regardless): the record arrives in one memory round trip instead of one per branch -- the
-    // single-candidate launch reads it from host memory over PCIe, ~2 us per dependent round.
+    // (only the fields the wavefront's axis and variant use are read: loading all of them in one basic block -- one
+    //  memory round trip instead of one per branch -- was measured on the single-candidate launch, whose record comes
+    //  over PCIe: no difference, 162.6 against 162.9 us, and 1.31 instead of 1.15 times the algorithmic HBM bytes)
     Record r;
     const size_t e_ = (size_t)b_ * a.seg_stride + k;
-    const bool ax0 = axis == 0;
     r.t = sg[BTRAPZ_F_T * BS + e_];
-    r.lb = sg[(ax0 ? BTRAPZ_F_DOWN_BIAS : BTRAPZ_F_L_DOWN_BIAS) * BS + e_]; r.ls = sg[(ax0 ? BTRAPZ_F_DOWN_SKEW : BTRAPZ_F_L_DOWN_SKEW) * BS + e_];
-    r.ub = sg[(ax0 ? BTRAPZ_F_UPP_BIAS : BTRAPZ_F_L_UPP_BIAS) * BS + e_];   r.us = sg[(ax0 ? BTRAPZ_F_UPP_SKEW : BTRAPZ_F_L_UPP_SKEW) * BS + e_];
-    const double ds_lo = sg[BTRAPZ_F_DS_LO * BS + e_], ds_hi = sg[BTRAPZ_F_DS_HI * BS + e_];
-    const double begl = sg[BTRAPZ_F_BEG_L * BS + e_], endl = sg[BTRAPZ_F_END_L * BS + e_];
-    double dl[10];
-    UNROLL for (int i = 0; i < 10; i++) dl[i] = a.dl_bounds[(size_t)b_ * 10 + i];
-    r.skew = sg[(ax0 ? BTRAPZ_F_X_SKEW : BTRAPZ_F_Y_SKEW) * BS + e_];
-    r.bias = sg[(ax0 ? BTRAPZ_F_X_BIAS : BTRAPZ_F_Y_BIAS) * BS + e_];
+    r.begl = 0.0; r.endl = 0.0;
+    if (axis == 0) {
+      r.lb = sg[BTRAPZ_F_DOWN_BIAS * BS + e_]; r.ls = sg[BTRAPZ_F_DOWN_SKEW * BS + e_];
+      r.ub = sg[BTRAPZ_F_UPP_BIAS * BS + e_];  r.us = sg[BTRAPZ_F_UPP_SKEW * BS + e_];
+      r.v[0] = sg[BTRAPZ_F_DS_LO * BS + e_]; r.v[1] = sg[BTRAPZ_F_DS_HI * BS + e_];
+      UNROLL for (int i = 2; i < 10; i++) r.v[i] = 0.0;
+    } else {
+      r.lb = sg[BTRAPZ_F_L_DOWN_BIAS * BS + e_]; r.ls = sg[BTRAPZ_F_L_DOWN_SKEW * BS + e_];
+      r.ub = sg[BTRAPZ_F_L_UPP_BIAS * BS + e_];  r.us = sg[BTRAPZ_F_L_UPP_SKEW * BS + e_];
+      if (variant == BTRAPZ_CUBOID) { r.begl = sg[BTRAPZ_F_BEG_L * BS + e_]; r.endl = sg[BTRAPZ_F_END_L * BS + e_]; }
+      UNROLL for (int i = 0; i < 10; i++) r.v[i] = a.dl_bounds[(size_t)b_ * 10 + i];
+    }
+    r.skew = sg[(axis == 0 ? BTRAPZ_F_X_SKEW : BTRAPZ_F_Y_SKEW) * BS + e_];
+    r.bias = sg[(axis == 0 ? BTRAPZ_F_X_BIAS : BTRAPZ_F_Y_BIAS) * BS + e_];
     r.ref_end = a.ref_end[(size_t)b_ * 2 + axis];
     UNROLL for (int i = 0; i < 3; i++) r.init[i] = a.init[(size_t)b_ * 6 + axis * 3 + i];
-    const bool cub_l = !ax0 && variant == BTRAPZ_CUBOID;
-    r.begl = cub_l ? begl : 0.0; r.endl = cub_l ? endl : 0.0;
-    r.v[0] = ax0 ? ds_lo : dl[0]; r.v[1] = ax0 ? ds_hi : dl[1];
-    UNROLL for (int i = 2; i < 10; i++) r.v[i] = ax0 ? 0.0 : dl[i];
     return r;
   };
 
