@@ -64,7 +64,7 @@ double btrapz_find_traj(int variant, const char *input_path, const char *output_
  * precision.  Same computation, same return value (a_cost or 1e11) as btrapz_find_traj.
  *   traj [7][cap]: rows t, s, l, ds, dl, dds, ddl (the columns of the reference's output file); at most cap
  *                  samples are written, *n_points receives the trajectory's sample count.
- *   ctrl [12*64] (may be NULL): control points, s axis then l axis; *n_segments receives S. */
+ *   ctrl [12*BTRAPZ_MAX_SEGMENTS_LONG] (may be NULL): control points, s axis then l axis; *n_segments receives S. */
 typedef struct btrapz_traj_input {
   int N, num_obs;
   double delta;
@@ -114,7 +114,7 @@ int btrapz_corridor_from_file(int variant, const char *input_path, btrapz_segmen
 /* ---- error codes ----------------------------------------------------------------- */
 enum {
   BTRAPZ_OK = 0,
-  BTRAPZ_EINVAL = -1,   /* bad argument (B<1, S<1 or S>64, null pointer) */
+  BTRAPZ_EINVAL = -1,   /* bad argument (B<1, S<1 or S beyond the limits above, null pointer) */
   BTRAPZ_ENODEVICE = -2, /* no HIP device / HIP runtime error at create */
   BTRAPZ_EHIP = -3,     /* HIP runtime error during a call (see btrapz_last_error) */
   BTRAPZ_ENOMEM = -4
@@ -150,6 +150,11 @@ enum {
   BTRAPZ_NUM_SEG_FIELDS
 };
 #define BTRAPZ_MAX_SEGMENTS 64
+/* Uniform cold batches (btrapz_solve_batch_device / _host without rescue pass) and find_traj take up to this many
+ * segments per candidate: beyond 64 a candidate is solved by a workgroup of several wavefronts (same method, same
+ * result, much slower per segment -- the reference has no limit, its bundled inputs have at most 14).  Ragged
+ * batches, warm starts and the rescue pass stay at BTRAPZ_MAX_SEGMENTS. */
+#define BTRAPZ_MAX_SEGMENTS_LONG 256
 
 /* Weights (Params) and limits (input-file header, trp_wrapper.cpp:59-64) shared by all
  * candidates of a batch. */

@@ -91,6 +91,7 @@ __global__ void ipm_solve_warm_ordered_kernel(const KernelArgs a, const double *
 __global__ void ipm_solve_queue_kernel(const KernelArgs a, const double *__restrict__ mqm);         // persistent, candidate queue
 __global__ void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm);       // rescue pass
 __global__ void ipm_solve_split_kernel(const KernelArgs a, const double *__restrict__ mqm);         // one candidate per wavefront, rows over 3 lanes
+__global__ void ipm_solve_long_kernel(const KernelArgs a, const double *__restrict__ mqm);          // 65..256 segments: one axis problem per workgroup
 __global__ void rescue_keys_kernel(int B, int S, const int *seg_count, const int *axis_status, int *keys, int all);
 __global__ void rescue_init_kernel(int B, int S, const int *seg_count, double *axis_obj, int *axis_status, int *axis_iters);
 struct MqmWeights { double w[2][4]; };   // [axis][ref, dref, acc, jerk]

@@ -287,7 +287,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
                         int B, int S, const int *seg_count, const double *seg, const double *init, const double *ref_end,
                         const double *dl_bounds, double *ctrl, double *cost, int *status, int *iters, void *stream_) {
   if (!c) return BTRAPZ_EINVAL;
-  if (!sh || B < 1 || S < 1 || (!seg_count && S > BTRAPZ_MAX_SEGMENTS) || !seg || !init || !ref_end || !dl_bounds ||
+  if (!sh || B < 1 || S < 1 || (!seg_count && S > BTRAPZ_MAX_SEGMENTS_LONG) || !seg || !init || !ref_end || !dl_bounds ||
       !ctrl || !cost || !status) {
     c->err = "invalid argument";
     return BTRAPZ_EINVAL;
@@ -343,10 +343,15 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     const int gpw_min = fixed_S ? 64 / fixed_S : 1;
     blocks = 2u * (unsigned)(B / gpw_min + 65);
   } else {
-    const int gpw = 64 / S;  // axis problems per wavefront; wave w: axis w&1 of candidates (w>>1)*gpw + [0,gpw)
+    const int gpw = S <= 64 ? 64 / S : 1;  // axis problems per wavefront; wave w: axis w&1 of candidates (w>>1)*gpw + [0,gpw)
     blocks = 2u * (unsigned)((B + gpw - 1) / gpw);
   }
   const bool warm_kernel = a.x0 || a.lam0 || a.lam_out;   // (a hint alone only reorders the candidates)
+  const bool long_form = !seg_count && S > BTRAPZ_MAX_SEGMENTS;   // one axis problem per workgroup (ipm_solve_long_kernel)
+  if (long_form && (a.order || warm_kernel || elastic)) {
+    c->err = "more than 64 segments: uniform cold solve without rescue pass only";
+    return BTRAPZ_EINVAL;
+  }
   auto kernel = warm_kernel ? (a.order ? ipm_solve_warm_ordered_kernel : ipm_solve_warm_kernel)
                             : (a.order ? ipm_solve_ordered_kernel : ipm_solve_kernel);
   if (elastic != 2) {
@@ -365,7 +370,10 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     const int split_opt = split_env ? split_env : (opt ? opt->split : 0);
     const bool split_on = !a.order && !warm_kernel && S <= 21 &&
                           (split_opt > 0 || (split_opt == 0 && 2u * (unsigned)B <= (unsigned)c->resident_waves));
-    if (split_on) {
+    if (long_form) {
+      hipLaunchKernelGGL(ipm_solve_long_kernel, dim3(2u * (unsigned)B), dim3(64u * (unsigned)((S + 63) / 64)), 0, stream, a,
+                         (const double *)c->d_mqm);
+    } else if (split_on) {
       hipLaunchKernelGGL(ipm_solve_split_kernel, dim3(2u * (unsigned)B), dim3(64), 0, stream, a, (const double *)c->d_mqm);
     } else if (queue_on && !a.order && !warm_kernel && blocks >= 3u * (unsigned)c->resident_waves) {
       HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int) * 2, stream));
@@ -614,7 +622,7 @@ BTRAPZ_EXPORT int btrapz_solve_batch_host(btrapz_ctx *c, const btrapz_shared *sh
                                        const double *seg, const double *init, const double *ref_end,
                                        const double *dl_bounds, double *ctrl, double *cost, int *status, int *iters) {
   if (!c) return BTRAPZ_EINVAL;
-  if (B < 1 || S < 1 || S > BTRAPZ_MAX_SEGMENTS) { c->err = "invalid argument"; return BTRAPZ_EINVAL; }
+  if (B < 1 || S < 1 || S > BTRAPZ_MAX_SEGMENTS_LONG) { c->err = "invalid argument"; return BTRAPZ_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n_seg = (size_t)BTRAPZ_NUM_SEG_FIELDS * B * S, n_init = (size_t)B * 6, n_re = (size_t)B * 2, n_dl = (size_t)B * 10;
   const size_t n_ctrl = (size_t)B * 12 * S, n_cost = B;

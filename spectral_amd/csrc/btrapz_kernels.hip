@@ -48,13 +48,13 @@ __device__ __forceinline__ double rcp_fast(double x) { return __builtin_amdgcn_r
 
 // lane i <- lane i-1 / lane i+1 over the whole wavefront (DPP wave_shr:1 / wave_shl:1, bound_ctrl: the lane
 // without a source reads 0, so the destination needs no initialisation).
-__device__ __forceinline__ double from_prev(double x) {
+__device__ __forceinline__ double dpp_prev(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
   hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double from_next(double x) {
+__device__ __forceinline__ double dpp_next(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
   hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
@@ -194,7 +194,7 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 template <int OP> __device__ __forceinline__ double pair_op(double v, bool has_next) {
-  const double n = from_next(v);
+  const double n = dpp_next(v);
   if constexpr (OP == 0) return v + (has_next ? n : 0.0);
   else if constexpr (OP == 1) return has_next ? fmax(v, n) : v;
   else return has_next ? fmin(v, n) : v;
@@ -226,6 +226,29 @@ __device__ __forceinline__ Red4 group_reduce(double (*red)[64], int lane, int gb
   return r;
 }
 
+// Long form (MULTI in ipm_solve_body: more than 64 segments, one axis problem per WORKGROUP of up to four wavefronts):
+// the reduction goes over all the workgroup's lanes through a shared block rm[4][256] behind the 8 seam slots of wgs.
+enum { WGS_SEAM = 8, WGS_LANES = 256 };
+template <bool MULTI, int O0, int O1, int O2, int O3>
+__device__ __forceinline__ Red4 reduce4(double (*red)[64], double *wgs, int lane, int wv, int gbase, int k, int S, double v0,
+                                        double v1, double v2, double v3) {
+  if constexpr (!MULTI) {
+    return group_reduce<O0, O1, O2, O3>(red, lane, gbase, k, S, v0, v1, v2, v3);
+  } else {
+    double *rm = wgs + WGS_SEAM;
+    const int K = wv * 64 + lane;
+    __syncthreads();
+    rm[K] = v0; rm[WGS_LANES + K] = v1; rm[2 * WGS_LANES + K] = v2; rm[3 * WGS_LANES + K] = v3;
+    __syncthreads();
+    Red4 r = {red_init<O0>(), red_init<O1>(), red_init<O2>(), red_init<O3>()};
+    for (int j = 0; j < S; j++) {   // (fixed order: bit-reproducible; every lane reads the same addresses: broadcasts)
+      r.a = red_op<O0>(r.a, rm[j], true); r.b = red_op<O1>(r.b, rm[WGS_LANES + j], true);
+      r.c = red_op<O2>(r.c, rm[2 * WGS_LANES + j], true); r.d = red_op<O3>(r.d, rm[3 * WGS_LANES + j], true);
+    }
+    return r;
+  }
+}
+
 // -----------------------------------------------------------------------------------------
 // WARM = false: the cold-start kernel (bench path).  WARM = true adds the warm start and the cold restart of a
 // group whose guess did not pay off; a separate instantiation, so the cold kernel keeps its register footprint.
@@ -255,11 +278,40 @@ __device__ __forceinline__ Red4 group_reduce(double (*red)[64], int lane, int gb
 // decision run (redundantly, bit for bit alike) in all three groups.  Row passes cost a third; everything sequential
 // costs the same per wavefront but serves one problem instead of three -- lower latency for few candidates, lower
 // throughput for many (measured: DESIGN.md 3.6).
-template <bool WARM, bool ORDERED, bool ELASTIC = false, bool QUEUE = false, bool SPLIT = false>
+// MULTI = true (uniform cold batches of 65..256 segments): the long form.  ONE axis problem per workgroup of ceil(S / 64)
+// wavefronts, lane l of wavefront wv = segment 64 wv + l.  Same iteration; what crosses a wavefront's edge goes through
+// LDS behind a workgroup barrier: the neighbour exchange at the seams (lane 63 -> lane 0 of the next wavefront and
+// back: two barriers per shifted value) and the reductions (reduce4).  Every lane of the workgroup follows the problem's
+// termination decisions (lanes beyond S compute garbage nobody reads and write nothing), so all wavefronts leave the
+// loop together.  Correctness over speed: the reference has no limit on the segment count (std::vector,
+// solve_3d.cc:323-486), its bundled inputs have at most 14.
+template <bool WARM, bool ORDERED, bool ELASTIC = false, bool QUEUE = false, bool SPLIT = false, bool MULTI = false>
 __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double *__restrict__ mqm, double (*lds)[64],
-                                               const int wave_id, const int lane) {
+                                               const int wave_id, const int lane, double *wgs = nullptr, const int wv = 0) {
   static_assert(!QUEUE || (!WARM && !ORDERED && !ELASTIC), "the queue serves uniform cold batches");
   static_assert(!SPLIT || (!ORDERED && !ELASTIC && !QUEUE), "the split form serves uniform batches");
+  static_assert(!MULTI || (!WARM && !ORDERED && !ELASTIC && !QUEUE && !SPLIT), "the long form serves uniform cold batches");
+  // value of the previous / next segment's lane (0 beyond the ends of the wavefront -- or, long form, of the workgroup)
+  auto from_prev = [&](double x) -> double {
+    double r = dpp_prev(x);
+    if constexpr (MULTI) {
+      __syncthreads();
+      if (lane == 63) wgs[wv] = x;
+      __syncthreads();
+      if (lane == 0 && wv > 0) r = wgs[wv - 1];
+    }
+    return r;
+  };
+  auto from_next = [&](double x) -> double {
+    double r = dpp_next(x);
+    if constexpr (MULTI) {
+      __syncthreads();
+      if (lane == 0) wgs[4 + wv] = x;
+      __syncthreads();
+      if (lane == 63 && wv < 3) r = ((wv + 1) * 64 < (int)blockDim.x) ? wgs[4 + wv + 1] : 0.0;
+    }
+    return r;
+  };
   constexpr bool CACHE_RP = !ELASTIC;   // see the main loop
   constexpr bool FULL = ELASTIC;                 // rows kept: see rows_kept()
   constexpr int NR = rows_kept<FULL>();
@@ -286,9 +338,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     S = a.S;
   }
   S = __builtin_amdgcn_readfirstlane(S);
-  const int gpw = SPLIT ? 3 : 64 / S;   // split form: three copies of one problem (3 S <= 64, the host checks)
-  const int g = lane / S;
-  const int k = lane - g * S;
+  const int gpw = SPLIT ? 3 : MULTI ? 1 : 64 / S;   // split form: three copies of one problem (3 S <= 64, the host checks)
+  const int kk = MULTI ? wv * 64 + lane : lane;     // long form: the workgroup's lanes are the segments
+  const int g = kk / S;
+  const int k = kk - g * S;
   const bool lane_in_group = g < gpw;
   const int gl = lane_in_group ? g : gpw - 1;
   const int gbase = gl * S;
@@ -363,6 +416,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   // there.  The pass is the loop body up to the predictor's sweep; it is not counted as an iteration.
   [[maybe_unused]] bool unc_pass = false;
   bool done = true;
+  [[maybe_unused]] int cand_live = 0;   // long form: the workgroup has a candidate
   // The group's own iteration count.  (Warm-start instantiations: when one group of the wavefront restarts cold the
   // others lose that pass of the loop; queue: the groups of a wavefront are at different iterations.  A candidate's
   // stall / step-rule / iteration bookkeeping must not depend on which candidates share its wavefront.)
@@ -547,19 +601,31 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     // ---------------- starting point: constant-velocity propagation of the initial state, or the caller's
     // joint states (warm start; a lane whose values are not finite keeps the cold start) -----
     {
-      wave_lds_sync();
-      lds[L_RED][lane] = t;
-      wave_lds_sync();
       double tsum = 0.0;
-      for (int j = 0; j < S; j++) tsum += (j <= k) ? lds[L_RED][gbase + j] : 0.0;
+      if constexpr (MULTI) {
+        double *rm = wgs + WGS_SEAM;
+        __syncthreads();
+        rm[kk] = t;
+        __syncthreads();
+        for (int j = 0; j < S; j++) tsum += (j <= k) ? rm[j] : 0.0;
+      } else {
+        wave_lds_sync();
+        lds[L_RED][lane] = t;
+        wave_lds_sync();
+        for (int j = 0; j < S; j++) tsum += (j <= k) ? lds[L_RED][gbase + j] : 0.0;
+      }
       Xcold0 = Xinit[0] + Xinit[1] * tsum;
     }
     {
-      const Red4 r0 = group_reduce<0, 1, 1, 2>(lds + L_RED, lane, gbase, k, S, no_solution_lane ? 1.0 : 0.0, bnorm, qn, gapmin);
+      const Red4 r0 = reduce4<MULTI, 0, 1, 1, 2>(lds + L_RED, wgs, lane, wv, gbase, k, S, no_solution_lane ? 1.0 : 0.0, bnorm, qn, gapmin);
       bnorm = r0.b; qn = r0.c; gapmin = r0.d;
       no_solution = r0.a > 0.0;
     }
     infeasible_bounds = !(gapmin >= 0.0) || !(t > 0.0);
+    if constexpr (MULTI) {   // one decision for the whole workgroup (a segment without duration counts like an empty row)
+      const Red4 rt = reduce4<MULTI, 0, 1, 1, 1>(lds + L_RED, wgs, lane, wv, gbase, k, S, 0.0, (valid && !(t > 0.0)) ? 1.0 : 0.0, 0.0, 0.0);
+      infeasible_bounds = !(gapmin >= 0.0) || rt.b > 0.0;
+    }
 
     // multipliers of this lane in the warm-start arrays: [axis][row 0..35][b][k]
     lam_e = (size_t)axis * 36 * lam_row + (size_t)b * a.seg_stride + k;
@@ -616,6 +682,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     best_score = 1e300; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2];
     best_it = 0; iters = 0; best_res = 3e38f; res_it = 0; plain = false;
     done = !valid || infeasible_bounds || no_solution;
+    if constexpr (MULTI) done = (cand_live == 0) || infeasible_bounds || no_solution;   // lanes beyond S follow the problem
     unc_pass = !ELASTIC && !QUEUE && a.unc_start != 0 && !warm_started;
   };
   auto write_back = [&]() {
@@ -669,9 +736,9 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
           viol = fmax(viol, v); vcls[cls] = fmax(vcls[cls], v); vnorm = fmax(vnorm, v * inorm[cls]);
         END_ROWS
       }
-      const Red4 ro = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, obj, viol, vnorm, 0.0);
+      const Red4 ro = reduce4<MULTI, 0, 1, 1, 1>(lds + L_RED, wgs, lane, wv, gbase, k, S, obj, viol, vnorm, 0.0);
       [[maybe_unused]] Red4 rv = {0.0, 0.0, 0.0, 0.0};
-      if constexpr (ELASTIC) rv = group_reduce<1, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, vcls[0], vcls[1], vcls[2], vcls[3]);
+      if constexpr (ELASTIC) rv = reduce4<MULTI, 1, 1, 1, 1>(lds + L_RED, wgs, lane, wv, gbase, k, S, vcls[0], vcls[1], vcls[2], vcls[3]);
       if (valid && (!SPLIT || g == 0)) {
         // control points in the reference's order: s axis (6 S), then l axis (6 S); rows are 12*seg_stride apart
         double *dst = a.ctrl + (size_t)b * 12 * a.seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
@@ -713,8 +780,9 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   if constexpr (QUEUE) {
     if (first && lane_in_group) next_cand = atomicAdd(a.queue + axis, 1);
   } else {
-    long long cand = SPLIT ? (long long)pair : (long long)pair * gpw + gl;
+    long long cand = (SPLIT || MULTI) ? (long long)pair : (long long)pair * gpw + gl;
     const bool valid0 = lane_in_group && cand < ncand;
+    cand_live = cand < ncand ? 1 : 0;
     if (cand >= ncand) cand = ncand - 1;
     const int b0 = ORDERED ? a.order[cand0 + (int)cand] : (int)cand;
     begin_candidate(b0, valid0, load_record(b0));
@@ -812,7 +880,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     if (!(mu_part == mu_part) || !(rd_part == rd_part) || !(rp_part == rp_part) || !(dscale == dscale) ||
         !(fabs(rd_part) < 1e300) || !(fabs(mu_part) < 1e300))
       rp_part = 1e300;
-    const Red4 rr = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, mu_part, rd_part, rp_part, dscale);
+    const Red4 rr = reduce4<MULTI, 0, 1, 1, 1>(lds + L_RED, wgs, lane, wv, gbase, k, S, mu_part, rd_part, rp_part, dscale);
     const double mu = rr.a * inv_m;
     // KKT score: dual residual relative to (1+|q|) with a round-off floor, primal residual
     // relative to the bound scale, complementarity absolute.
@@ -1081,7 +1149,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       }
       // (a group takes the step as a whole or not at all: dX of a singular block system is not finite in every lane)
       {
-        const Red4 rf = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, 0.0,
+        const Red4 rf = reduce4<MULTI, 0, 1, 1, 1>(lds + L_RED, wgs, lane, wv, gbase, k, S, 0.0,
                                                  (fabs(dX[0]) < 1e300 && fabs(dX[1]) < 1e300 && fabs(dX[2]) < 1e300) ? 0.0 : 1.0, 0.0, 0.0);
         if (rf.b > 0.0 && unc_pass && !done) { X[0] = Xcold0; X[1] = Xinit[1]; X[2] = 0.0; }
       }
@@ -1111,7 +1179,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       S4 = (lds[L_XCH + 1][Lj[0]] + lds[L_XCH + 1][Lj[1]]) + lds[L_XCH + 1][Lj[2]];
       qmax = fmax(fmax(lds[L_XCH + 2][Lj[0]], lds[L_XCH + 2][Lj[1]]), lds[L_XCH + 2][Lj[2]]);
       qmin = fmin(fmin(lds[L_XCH + 3][Lj[0]], lds[L_XCH + 3][Lj[1]]), lds[L_XCH + 3][Lj[2]]);
-      const Red4 ra = group_reduce<0, 0, 1, 2>(lds + L_RED, lane, gbase, k, S, S1, S4, qmax, qmin);
+      const Red4 ra = reduce4<MULTI, 0, 0, 1, 2>(lds + L_RED, wgs, lane, wv, gbase, k, S, S1, S4, qmax, qmin);
       const double ap = 1.0 / fmax(-ra.d, 1.0), ad = 1.0 / fmax(1.0 + ra.c, 1.0);
       const double mua = ((1.0 - ad) * rr.a + (ap - ad - ap * ad) * ra.a - ap * ad * ra.b) * inv_m;
       const double sr = mua / mu;
@@ -1147,7 +1215,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       wave_lds_sync();
       pr = fmax(fmax(lds[L_XCH + 0][Lj[0]], lds[L_XCH + 0][Lj[1]]), lds[L_XCH + 0][Lj[2]]);
       dr = fmax(fmax(lds[L_XCH + 1][Lj[0]], lds[L_XCH + 1][Lj[1]]), lds[L_XCH + 1][Lj[2]]);
-      const Red4 rb = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, 0.0, pr, dr, 0.0);
+      const Red4 rb = reduce4<MULTI, 0, 1, 1, 1>(lds + L_RED, wgs, lane, wv, gbase, k, S, 0.0, pr, dr, 0.0);
       const double m_ = fmax(rb.b, rb.c);
       const double tau = (m_ * a.tau_thr <= 1.0 && eit - it0 < a.tau_iters) ? a.tau : fmin(a.tau, 0.995);
       const double alpha = fmin(1.0, tau / fmax(m_, tau));
@@ -1178,7 +1246,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         S1 += al + au;
         S4 += al * ql + au * qu;
       END_ROWS
-      const Red4 ra = group_reduce<0, 0, 1, 2>(lds + L_RED, lane, gbase, k, S, S1, S4, qmax, qmin);
+      const Red4 ra = reduce4<MULTI, 0, 0, 1, 2>(lds + L_RED, wgs, lane, wv, gbase, k, S, S1, S4, qmax, qmin);
       const double ap = 1.0 / fmax(-ra.d, 1.0), ad = 1.0 / fmax(1.0 + ra.c, 1.0);
       const double mua = ((1.0 - ad) * rr.a + (ap - ad - ap * ad) * ra.a - ap * ad * ra.b) * inv_m;
       const double sr = mua / mu;
@@ -1226,7 +1294,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         pr = fmax(pr, fmax(-dsl * isl, -dsu * isu));
         dr = fmax(dr, fmax(-dll * rcp_fast(ll), -dlu * rcp_fast(lu)));
       END_ROWS
-      const Red4 ra = group_reduce<0, 1, 1, 1>(lds + L_RED, lane, gbase, k, S, 0.0, pr, dr, 0.0);
+      const Red4 ra = reduce4<MULTI, 0, 1, 1, 1>(lds + L_RED, wgs, lane, wv, gbase, k, S, 0.0, pr, dr, 0.0);
       // m = largest ratio -ds/s, -dlambda/lambda: the boundary is 1/m away.  A long step may go almost all the way
       // (fewer iterations); a blocked one keeps 0.5 % distance, or the iterates lose centrality and crawl.
       const double m_ = fmax(ra.b, ra.c);
@@ -1286,6 +1354,14 @@ __global__ __launch_bounds__(64) void ipm_solve_queue_kernel(const KernelArgs a,
 __global__ __launch_bounds__(64) void ipm_solve_split_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[21][64];
   ipm_solve_body<false, false, false, false, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
+}
+// More than 64 segments (up to 256): one axis problem per workgroup of ceil(S / 64) wavefronts (MULTI above).
+// Workgroup w: axis w & 1 of candidate w >> 1.
+__global__ __launch_bounds__(256) void ipm_solve_long_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  __shared__ double lds[4][lds_rows<false>()][64];
+  __shared__ double wgs[WGS_SEAM + 4 * WGS_LANES];
+  const int wv = (int)threadIdx.x >> 6;
+  ipm_solve_body<false, false, false, false, false, true>(a, mqm, lds[wv], (int)blockIdx.x, (int)threadIdx.x & 63, wgs, wv);
 }
 // Rescue pass (btrapz_options.elastic): the stalled axis problems, listed per axis, with elastic rows.
 __global__ __launch_bounds__(64) void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm) {

@@ -197,7 +197,8 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   if (!select_segments(variant, in.delta, lists, in.s_ref, in.l_ref, seg)) return FAIL;
   const int S = (int)seg.size();
   const double t_corr = tm ? now_us() : 0.0;
-  if (S < 1 || S > BTRAPZ_MAX_SEGMENTS) { fprintf(stderr, "btrapz: %d segments not supported (1..%d)\n", S, BTRAPZ_MAX_SEGMENTS); return FAIL; }
+  if (S < 1 || S > BTRAPZ_MAX_SEGMENTS_LONG) { fprintf(stderr, "btrapz: %d segments not supported (1..%d)\n", S, BTRAPZ_MAX_SEGMENTS_LONG); return FAIL; }
+  const bool long_form = S > BTRAPZ_MAX_SEGMENTS;   // solved through the batched entry point, one workgroup per axis
   for (const Segment &c : seg) if (!(c.t > 0)) return FAIL;
 
   // batch record, B = 1 (layout: include/btrapz_hip.h)
@@ -283,6 +284,9 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   btrapz_options opt1;
   btrapz_options_init(&opt1);
   if (const char *mi = getenv("BTRAPZ_MAX_ITER")) opt1.max_iter = atoi(mi);   // (experiments: cost per iteration)
+  if (long_form) {
+    h_status[0] = BTRAPZ_MAX_ITER_REACHED;   // (nothing solved yet: the block below does it, without the rescue rows)
+  } else
   if (btrapz_launch_single(ctx, &sh, &opt1, S, d_in, d_out, max_points, warm_on ? 1 : 0, me->stream) != BTRAPZ_OK ||
       hipStreamSynchronize(me->stream) != hipSuccess) {
     fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
@@ -290,18 +294,20 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
     return FAIL;
   }
   const double t_done = tm ? now_us() : 0.0;
+  if (!long_form) {
   h_cost = h_out[0];
   memcpy(h_status, &h_out[1], 8);
   memcpy(&h_np, &h_out[2], 4);
+  }
   t_last.iters = h_status[1]; t_last.status = h_status[0];
   if (tm) fprintf(stderr, "btrapz: timing [us]: corridor stage %.1f, record + table %.1f, launch to results %.1f (%d iterations)\n",
                   t_corr - t_begin, t_launch - t_corr, t_done - t_launch, h_status[1]);
   if (h_status[0] != BTRAPZ_SOLVED && h_status[0] != BTRAPZ_SOLVED_INACCURATE) btrapz_single_forget(ctx);
-  if (h_status[0] == BTRAPZ_MAX_ITER_REACHED && el.on) {
+  if (long_form || (h_status[0] == BTRAPZ_MAX_ITER_REACHED && el.on)) {
     // Second attempt (no solution to converge to: a marginally infeasible corridor): the rescue pass of
     // btrapz_options.elastic, the counterpart of the reference accepting OSQP's status 2.  Rare, so it simply goes
     // through the batched entry points on a device copy of the inputs.
-    if (verbose()) fprintf(stderr, "btrapz: S=%d stalled after %d iterations, rescue pass\n", S, h_status[1]);
+    if (verbose() && !long_form) fprintf(stderr, "btrapz: S=%d stalled after %d iterations, rescue pass\n", S, h_status[1]);
     const size_t n_dev = n_in + n_out + 1 + 4;   // (+ the four class violations behind the results)
     if (n_dev * 8 > me->scratch_bytes) {
       if (me->scratch) (void)hipFree(me->scratch);
@@ -318,21 +324,21 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
     if (hipMemcpyAsync(s_in, h_in, (n_in + 1) * 8, hipMemcpyHostToDevice, me->stream) != hipSuccess) return FAIL;
     btrapz_options opt;
     btrapz_options_init(&opt);
-    opt.elastic = 1; opt.elastic_tol = el.tol;
+    opt.elastic = long_form ? 0 : 1; opt.elastic_tol = el.tol;
     double *s_viol = s_out + n_out;
     double h_viol[4] = {0.0, 0.0, 0.0, 0.0};
     if (btrapz_solve_batch_device(ctx, &sh, &opt, 1, S, s_in, s_init, s_init + 6, s_init + 8, s_out + 3, s_out, s_status,
                                   s_status + 1, me->stream) != BTRAPZ_OK ||
         btrapz_sample_device(ctx, 1, S, in.delta, s_in, s_init, s_out + 3, 1, s_sel, max_points, s_out + 3 + 12 * S, s_np,
                              me->stream) != BTRAPZ_OK ||
-        btrapz_rescue_violations_device(ctx, 1, s_viol, me->stream) != BTRAPZ_OK) {
+        (!long_form && btrapz_rescue_violations_device(ctx, 1, s_viol, me->stream) != BTRAPZ_OK)) {
       fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
       t_last.status = BTRAPZ_EHIP;
       btrapz_single_forget(ctx);
       return FAIL;
     }
     if (hipMemcpyAsync(h_out, s_out, n_out * 8, hipMemcpyDeviceToHost, me->stream) != hipSuccess ||
-        hipMemcpyAsync(h_viol, s_viol, 4 * 8, hipMemcpyDeviceToHost, me->stream) != hipSuccess ||
+        (!long_form && hipMemcpyAsync(h_viol, s_viol, 4 * 8, hipMemcpyDeviceToHost, me->stream) != hipSuccess) ||
         hipStreamSynchronize(me->stream) != hipSuccess) { t_last.status = BTRAPZ_EHIP; btrapz_single_forget(ctx); return FAIL; }
     h_cost = h_out[0];
     memcpy(h_status, &h_out[1], 8);

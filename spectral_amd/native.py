@@ -353,7 +353,7 @@ def find_traj_mem(variant, params, kb, b=0, cap=None):
                     (C.c_double * 2)(*h["dds"]), (C.c_double * 2)(*h["ddds"]), (C.c_double * 2)(*h["ddl"]),
                     (C.c_double * 2)(*h["dddl"]), *[a.ctypes.data for a in arrs])
     cap = int(cap if cap is not None else 4 * kb.N + 16)
-    traj = np.zeros((7, cap)); ctrl = np.zeros(12 * 64)
+    traj = np.zeros((7, cap)); ctrl = np.zeros(12 * 256)
     n, S = C.c_int(0), C.c_int(0)
     cost = lib().btrapz_find_traj_mem(int(variant), C.byref(ti), C.byref(cp), cap, traj.ctypes.data, C.byref(n),
                                       ctrl.ctypes.data, C.byref(S))

@@ -28,7 +28,7 @@ def test_bad_arguments_are_reported_not_fatal():
                                                      p(db.dl_bounds), p(ctrl), p(o["cost"]), p(o["status"]), p(o["iters"]), None)
     assert lib.btrapz_solve_batch_device(*args(0, 10)) == EINVAL            # B < 1
     assert lib.btrapz_solve_batch_device(*args(8, 0)) == EINVAL             # S < 1
-    assert lib.btrapz_solve_batch_device(*args(8, 65)) == EINVAL            # S > 64
+    assert lib.btrapz_solve_batch_device(*args(8, 257)) == EINVAL           # S > 256 (65..256: the long form)
     assert b"invalid" in lib.btrapz_last_error(h)
     bad = list(args(8, 10)); bad[5] = None                                  # null seg
     assert lib.btrapz_solve_batch_device(*bad) == EINVAL
