@@ -1,7 +1,12 @@
 """find_traj (in-memory) against the oracle's restatement of the same call on many knot-level inputs: decision
 (trajectory or sentinel), control points vs x*, the sample-count check of solve_3d.cc:1407.
 
-    python tests/fuzz/find_traj_vs_oracle.py SEED CALLS [ELASTIC]     # needs a GPU; ~12 s per 600 calls
+    python tests/fuzz/find_traj_vs_oracle.py SEED CALLS [ELASTIC] [LIB] [PORT_EVERY]     # needs a GPU; ~12 s per 600 calls
+
+PORT_EVERY = k > 0: on every k-th call the oracle's OSQP PORT -- the reference's own algorithm at its own
+settings (eps 1e-5, 5000 iterations) -- decides as well, and its agreement with the product is tallied apart from the
+agreement with the oracle's exact / relaxed solve: the port's accept decision is what the reference's find_traj returns,
+the exact solve is what the QP says.
 
 Inputs, in turn: scenario_1 scenes of 2-24 segments (synth.scenario1_knots), jittered copies of the bundled corridor
 files, fuzz_knot_batch garbage (tests/helpers.py).  ELASTIC = 0 (default here): the plain solve against the oracle's
@@ -18,7 +23,9 @@ ELASTIC = sys.argv[3] if len(sys.argv) > 3 else "0"
 os.environ["BTRAPZ_ELASTIC"] = ELASTIC
 from oracle import oracle as O
 from spectral_amd import synth, knots, native
-if len(sys.argv) > 4: native.LIB_PATH = sys.argv[4]
+if len(sys.argv) > 4 and sys.argv[4] not in ("", "-"): native.LIB_PATH = sys.argv[4]
+PORT_EVERY = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+port = {"both": 0, "neither": 0, "product only, QP has an optimum": 0, "product only, rescued": 0, "port only": 0}
 GOLD = os.path.join(ROOT, 'tests', 'golden'); W = np.loadtxt(GOLD + '/inputs/weights.txt')
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
@@ -67,6 +74,26 @@ for it in range(count):
     except Exception as e:
         want_accept = False
     got_accept = cost != 100000000000.0
+    if PORT_EVERY and it % PORT_EVERY == 0:
+        try:
+            pc, pS, _, _, pinfo = O.find_traj(variant, path, None, O.params_from_weights(W))
+            port_accept = pc != O.FAIL_SENTINEL
+        except Exception:
+            port_accept = False
+        if port_accept and got_accept: port["both"] += 1
+        elif not port_accept and not got_accept: port["neither"] += 1
+        elif port_accept:
+            port["port only"] += 1
+            try:      # what the port accepted, and how far the least-violation answer is from the tolerance
+                _n, _cb = O.pipeline(variant, O.ParsedInput(path))
+                _qp = O.AssembledQp(variant, _cb, O.params_from_weights(W), O.ParsedInput(path))
+                _xe, _, _ie, _v = _qp.solve_elastic()
+                print("PORT-ONLY", it, mode, variant, "segments", _n, "port status/iters", (pinfo.status, pinfo.iter), "port iterate violates (pos, vel, acc, jerk)",
+                      [round(v, 4) for v in _qp.class_violations(_qp.solve()[0])], "least violation / |g| %.4f" % _v,
+                      "its classes", [round(v, 4) for v in _qp.class_violations(_xe)], "product status", native.find_traj_last_status()[0], flush=True)
+            except Exception as e:
+                print("PORT-ONLY", it, "details failed", repr(e)[:100])
+        else: port["product only, rescued" if native.find_traj_last_status()[1].any() else "product only, QP has an optimum"] += 1
     if skipped: continue
     if got_accept != want_accept:
         bad += 1; print("DECISION", it, mode, variant, "hip", got_accept, "oracle", want_accept, "N", kb.N, "obs", kb.num_obs, "segments", n, "oracle status/iters", (info.status, info.iter) if x is not None else None, "t", [round(c.t, 2) for c in cubes][:12] if n > 0 else None, flush=True)
@@ -80,4 +107,5 @@ for it in range(count):
     worst = max(worst, err)
     if not (ctrl.shape == x.shape and err <= tol_x):
         bad += 1; print("XSTAR", it, mode, variant, err)
+if PORT_EVERY: print("against the OSQP port (every %d-th call):" % PORT_EVERY, port)
 print("calls", count, "agree", agree, "accepted", acc, "rejected", rej, "mismatches", bad, "worst rel err %.2e" % worst, "seconds %.1f" % (time.time() - t0))
