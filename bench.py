@@ -32,6 +32,12 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (64 FMA lanes/clk/CU x 256 C
 # iteration: rows/residuals ~420, Newton matrix + projection ~520, two solves ~600,
 # own pivot step of the block LDL^T and sweeps ~160 (DESIGN.md "Flop model").
 FLOPS_PER_SEGMENT_ITER = 1700.0
+# What one solve call launches (btrapz_last_solve_form): kernel_ms in the line is the HIP-event time of the call, i.e.
+# of ALL of these kernels; the rocprofv3 averages of the named ones add up to it.
+SOLVE_FORMS = {0: "btrapz::ipm_solve_kernel", 1: "btrapz::ipm_solve_split_kernel", 2: "btrapz::ipm_solve_long_kernel",
+               3: "btrapz::ipm_solve_capped_kernel + btrapz::ipm_solve_resume_kernel (one solve = two launches: every candidate stops when "
+                  "left alone in its wavefront after 6 iterations, the second launch carries those on; + 6 bucketing launches of ~5 us)",
+               4: "btrapz::ipm_solve_queue_kernel"}
 
 
 def parse():
@@ -245,6 +251,7 @@ def main():
         rank_ms = [1e3 * float(t.item()) / a.steps for t in allt]
         elapsed = max(float(t.item()) for t in allt)
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    solve_form = solver.ctx.last_solve_form()
 
     status = o["status"].cpu().numpy(); iters = o["iters"].cpu().numpy()
     solved = float(np.mean((status == 1) | (status == 2)))
@@ -295,7 +302,7 @@ def main():
                          # HBM bytes per launch from the PMC passes (FETCH_SIZE doubled as the guide prescribes for wide
                          # coalesced reads + WRITE_SIZE) of THIS kernel build on THIS workload, else null
                          "traffic": hbm["bytes_per_launch"] if hbm else None, "traffic_source": hbm_src,
-                         "kernel": "btrapz::ipm_solve_kernel", "kernel_ms": kernel_ms, "kernel_source_hash": kernel_stamp(),
+                         "kernel": SOLVE_FORMS.get(solve_form, "btrapz::ipm_solve_kernel"), "kernel_ms": kernel_ms, "kernel_source_hash": kernel_stamp(),
                          "algorithmic_bytes_per_solve": batch.algorithmic_bytes(),
                          "note": "on-chip solve: the binding resource is FP64 VALU issue + dependent sweeps, not HBM "
                                  "(SURVEY 8d); see fp64_valu",

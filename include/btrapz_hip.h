@@ -214,6 +214,14 @@ typedef struct btrapz_options {
    * an iteration's work), i.e. the unconstrained optimum, then the usual slacks and multipliers.  The optimum does not
    * depend on it; the iteration count does (measured: DESIGN.md 3.9). */
   int start;
+  /* Uniform cold batches of many more candidates than the device holds at once: two launches instead of one.  In the
+   * first, a candidate that is the only one of its wavefront still iterating after cap_iter interior-point iterations
+   * (or still iterating four iterations later) hands its iterate over; the second launch carries those candidates on from
+   * exactly where they stopped, like with like and the far-from-converged first -- same iterates, same results bit for
+   * bit, but no wavefront runs at a third of its width for one slow candidate and no slow candidate starts last
+   * (-9 % on the scenario_1 bench batch).  0 -> automatic (6 for batches of 16..64 segments that fill
+   * the device at least eight times over); > 0 -> that many iterations, any uniform cold batch; -1 -> never. */
+  int cap_iter;
 } btrapz_options;
 /* Zeroes *opt (every field: "use the default") and sets struct_size.  Call it before filling the struct in. */
 void btrapz_options_init(btrapz_options *opt);
@@ -249,6 +257,11 @@ int btrapz_solve_batch_device(btrapz_ctx *ctx, const btrapz_shared *shared,
  * 60 (...): solve_3d.cc:823-888), the larger of the two axes.  A caller that must not leave the corridor by more than
  * its own margin tests viol[b][0].  Device pointer; stream order. */
 int btrapz_rescue_violations_device(btrapz_ctx *ctx, int B, double *viol, void *stream);
+
+/* Which form of the solve kernel the context's last batched solve ran (scheduling only; results do not depend on it):
+ * 0 packed (floor(64/S) candidates per wavefront), 1 split (btrapz_options.split), 2 long (65..256 segments),
+ * 3 capped first launch + resume launch (btrapz_options.cap_iter), 4 candidate queue (btrapz_options.queue); -1 none yet. */
+int btrapz_last_solve_form(const btrapz_ctx *ctx);
 
 /* Arg-min of cost over contiguous groups of `group` candidates (B % group == 0).
  * best_idx[g] = global candidate index (index_base + local), ties -> lowest index;

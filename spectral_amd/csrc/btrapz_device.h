@@ -52,6 +52,15 @@ struct KernelArgs {
   const double *lam0;       // [2][36][B][seg_stride] multipliers of an earlier solve
   double *lam_out;          // same layout, multipliers at the end of this solve
   double mu0, smin;         // lambda = lam0 + mu0 / s , s = max(gap, smin)
+  // capped first launch + resume launch (btrapz_options.cap_iter): see CAPPED / RESUME in btrapz_kernels.hip
+  int cap_iter;             // iterations after which a group of the capped launch may suspend (0: no cap) ...
+  int cap_alone;            // ... when at most this many groups of its wavefront are still iterating,
+  int cap_hi;               // and after which it suspends in any case
+  int susp_cap;             // slots of susp_state
+  double *susp_state;       // [susp_cap][SUSP_FIELDS][seg_stride]
+  int *susp_count;          // [1] slots handed out
+  int *susp_slot;           // [2B] slot of a suspended axis problem
+  int *susp_key;            // [2][B] convergence class of a suspended axis problem (key of the resume lists)
   int unc_start;            // btrapz_options.start: 1 = first one Newton step of the problem without its inequality rows
   int bucket_S;             // 0: the bucket id IS the segment count (ragged); else buckets are hint classes, S = bucket_S
   // rescue pass (btrapz_options.elastic): order = [2][B] per-axis lists, cand_prefix / wave_prefix = [2][198] tables
@@ -91,6 +100,9 @@ __global__ void ipm_solve_warm_ordered_kernel(const KernelArgs a, const double *
 __global__ void ipm_solve_queue_kernel(const KernelArgs a, const double *__restrict__ mqm);         // persistent, candidate queue
 __global__ void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm);       // rescue pass
 __global__ void ipm_solve_split_kernel(const KernelArgs a, const double *__restrict__ mqm);         // one candidate per wavefront, rows over 3 lanes
+__global__ void ipm_solve_capped_kernel(const KernelArgs a, const double *__restrict__ mqm);        // first launch of a capped solve
+__global__ void ipm_solve_resume_kernel(const KernelArgs a, const double *__restrict__ mqm);        // ... and the launch that carries the suspended problems on
+#define BTRAPZ_SUSPENDED (-7)   // internal: an axis problem the capped launch handed over (never leaves the library)
 __global__ void ipm_solve_long_kernel(const KernelArgs a, const double *__restrict__ mqm);          // 65..256 segments: one axis problem per workgroup
 __global__ void rescue_keys_kernel(int B, int S, const int *seg_count, const int *axis_status, int *keys, int all);
 __global__ void rescue_init_kernel(int B, int S, const int *seg_count, double *axis_obj, int *axis_status, int *axis_iters);

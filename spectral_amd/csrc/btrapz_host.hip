@@ -85,7 +85,11 @@ struct btrapz_ctx {
   // sets, read / written alternately), and the problem shape they belong to
   double *d_single_warm = nullptr; int single_S = 0, single_variant = -1, single_flip = 0;
   int *d_queue = nullptr;           // [2] candidate counters of the persistent launch (ipm_solve_queue_kernel)
+  // capped solve (btrapz_options.cap_iter): iterates of the suspended axis problems, their slots and list keys
+  double *d_susp_state = nullptr; size_t susp_state_doubles = 0;
+  int *d_susp_ints = nullptr; size_t susp_ints = 0;      // [1 count (+pad)] [2B slots] [2B keys]
   int resident_waves = 1024;        // wavefronts the device holds at one per SIMD
+  int last_form = -1;               // btrapz_last_solve_form
   int *d_istage = nullptr; size_t istage_cap = 0;
 };
 
@@ -130,7 +134,7 @@ BTRAPZ_EXPORT int btrapz_destroy(btrapz_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters); (void)hipFree(c->d_axis_viol);
   (void)hipFree(c->d_mqm); (void)hipFree(c->d_stage); (void)hipFree(c->d_istage); (void)hipFree(c->d_single);
-  (void)hipFree(c->d_queue); (void)hipFree(c->d_single_warm);
+  (void)hipFree(c->d_queue); (void)hipFree(c->d_single_warm); (void)hipFree(c->d_susp_state); (void)hipFree(c->d_susp_ints);
   (void)hipFree(c->d_order); (void)hipFree(c->d_meta); (void)hipFree(c->d_retry);
   (void)hipFree(c->d_rescue); (void)hipFree(c->d_rescue_meta); (void)hipFree(c->d_argmin_cost); (void)hipFree(c->d_argmin_idx);
   if (c->ws_free) (void)hipEventDestroy(c->ws_free);
@@ -139,6 +143,7 @@ BTRAPZ_EXPORT int btrapz_destroy(btrapz_ctx *c) {
 }
 
 BTRAPZ_EXPORT const char *btrapz_last_error(const btrapz_ctx *c) { return c ? c->err.c_str() : "null context"; }
+BTRAPZ_EXPORT int btrapz_last_solve_form(const btrapz_ctx *c) { return c ? c->last_form : -1; }
 
 static int ensure_axis_ws(btrapz_ctx *c, size_t nprob) {
   if (nprob <= c->axis_cap) return BTRAPZ_OK;
@@ -189,6 +194,7 @@ static void fill_parameters(KernelArgs &a, const btrapz_shared *sh, const btrapz
   a.elastic_delta = (opt && opt->elastic_delta > 0) ? opt->elastic_delta : BTRAPZ_DEFAULT_ELASTIC_DELTA;
   a.elastic_tol = (opt && opt->elastic_tol > 0) ? opt->elastic_tol : BTRAPZ_DEFAULT_ELASTIC_TOL;
   a.bucket_S = 0;
+  a.cap_iter = 0; a.cap_alone = 0; a.cap_hi = 0; a.susp_cap = 0; a.susp_state = nullptr; a.susp_count = nullptr; a.susp_slot = nullptr; a.susp_key = nullptr;
   static const int start_env = [] { const char *e = getenv("BTRAPZ_START"); return e ? atoi(e) : -1; }();
   a.unc_start = start_env >= 0 ? start_env : (opt ? opt->start : 0);
 }
@@ -370,16 +376,80 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     const int split_opt = split_env ? split_env : (opt ? opt->split : 0);
     const bool split_on = !a.order && !warm_kernel && S <= 21 &&
                           (split_opt > 0 || (split_opt == 0 && 2u * (unsigned)B <= (unsigned)c->resident_waves));
-    if (long_form) {
+    // Two launches for uniform cold batches much larger than the machine (btrapz_options.cap_iter / BTRAPZ_CAP): every
+    // group stops at cap_iter iterations, the unfinished ones are carried on by a second launch, like with like, the
+    // far-from-converged first (CAPPED / RESUME in btrapz_kernels.hip).  Same iterates, same results.
+    static const int cap_env = [] { const char *q = getenv("BTRAPZ_CAP"); return q ? atoi(q) : -1; }();
+    // Measured (tools/cap_bench.py, 65 536 candidates, one launch -> two): scenario_1 x 20 7.00 -> 6.39 ms, its cuboid
+    // variant 6.70 -> 6.35, generic x 20 5.21 -> 5.18, scenario_1 x 10 2.24 -> 2.46 (six groups per wavefront: what a
+    // lone straggler wastes is less than what the second launch costs).  Automatic (cap_iter = 0): 6 for uniform cold
+    // batches of 16 to 64 segments that fill the device at least eight times over; -1: never.
+    int cap_iter = cap_env >= 0 ? cap_env : (opt ? opt->cap_iter : 0);
+    if (cap_iter == 0 && S >= 16 && blocks >= 8u * (unsigned)c->resident_waves) cap_iter = 6;
+    const bool capped = cap_iter > 0 && !long_form && !split_on && !a.order && !warm_kernel && !queue_on && S <= BTRAPZ_MAX_SEGMENTS &&
+                        cap_iter < a.max_iter && elastic != 2;
+    if (capped) {
+      // slots for a quarter of the axis problems (BTRAPZ_SUSP_PERCENT: experiments); a group that finds none goes on
+      static const int susp_percent = [] { const char *q = getenv("BTRAPZ_SUSP_PERCENT"); return q ? atoi(q) : 25; }();
+      size_t slots = 2 * (size_t)B * (size_t)(susp_percent < 1 ? 1 : susp_percent > 100 ? 100 : susp_percent) / 100;
+      if (slots < 1024) slots = 1024;
+      const size_t need_state = slots * 74 * (size_t)S, need_ints = 4 + 4 * (size_t)B;
+      if (need_state > c->susp_state_doubles) {
+        (void)hipFree(c->d_susp_state); c->d_susp_state = nullptr; c->susp_state_doubles = 0;
+        HIPCHK(c, hipMalloc(&c->d_susp_state, sizeof(double) * need_state));
+        c->susp_state_doubles = need_state;
+      }
+      if (need_ints > c->susp_ints) {
+        (void)hipFree(c->d_susp_ints); c->d_susp_ints = nullptr; c->susp_ints = 0;
+        HIPCHK(c, hipMalloc(&c->d_susp_ints, sizeof(int) * need_ints));
+        c->susp_ints = need_ints;
+      }
+      if (2 * (size_t)B > c->rescue_cap) {
+        (void)hipFree(c->d_rescue); c->d_rescue = nullptr; c->rescue_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_rescue, sizeof(int) * 4 * (size_t)B));
+        c->rescue_cap = 2 * (size_t)B;
+      }
+      if (!c->d_rescue_meta) HIPCHK(c, hipMalloc(&c->d_rescue_meta, sizeof(int) * 2 * 198));
+      int *count = c->d_susp_ints, *slot_of = c->d_susp_ints + 4, *keys = slot_of + 2 * (size_t)B;
+      HIPCHK(c, hipMemsetAsync(count, 0, sizeof(int) * 4, stream));
+      HIPCHK(c, hipMemsetAsync(keys, 0, sizeof(int) * 2 * (size_t)B, stream));
+      HIPCHK(c, hipMemsetAsync(c->d_rescue_meta, 0, sizeof(int) * 2 * 198, stream));
+      KernelArgs p1 = a;
+      static const int cap_alone_env = [] { const char *q = getenv("BTRAPZ_CAP_ALONE"); return q ? atoi(q) : 1; }();
+      static const int cap_hi_env = [] { const char *q = getenv("BTRAPZ_CAP_HI"); return q ? atoi(q) : 4; }();
+      p1.cap_iter = cap_iter; p1.cap_alone = cap_alone_env; p1.cap_hi = cap_iter + cap_hi_env; p1.susp_cap = (int)slots; p1.susp_state = c->d_susp_state; p1.susp_count = count;
+      p1.susp_slot = slot_of; p1.susp_key = keys;
+      hipLaunchKernelGGL(ipm_solve_capped_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+      int *lists = c->d_rescue + 2 * (size_t)B;
+      const unsigned nb = (unsigned)((B + 255) / 256);
+      for (int ax = 0; ax < 2; ax++) {
+        int *meta = c->d_rescue_meta + ax * 198;
+        const int *k = keys + (size_t)ax * B;
+        hipLaunchKernelGGL(bucket_hist_kernel, dim3(nb), dim3(256), 0, stream, B, S, k, meta, -S);
+        hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(64), 0, stream, meta, -S);
+        hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nb), dim3(256), 0, stream, B, S, k, meta, lists + (size_t)ax * B,
+                           (double *)nullptr, (int *)nullptr, (int *)nullptr, -S);
+      }
+      KernelArgs p2 = p1;
+      p2.cap_iter = 0; p2.order = lists; p2.seg_count = nullptr; p2.cand_prefix = c->d_rescue_meta; p2.wave_prefix = c->d_rescue_meta + 66;
+      p2.bucket_S = S;
+      const unsigned rblocks = 2u * (unsigned)(slots / (size_t)(64 / S) + 65);
+      hipLaunchKernelGGL(ipm_solve_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
+      c->last_form = 3;
+    } else if (long_form) {
+      c->last_form = 2;
       hipLaunchKernelGGL(ipm_solve_long_kernel, dim3(2u * (unsigned)B), dim3(64u * (unsigned)((S + 63) / 64)), 0, stream, a,
                          (const double *)c->d_mqm);
     } else if (split_on) {
+      c->last_form = 1;
       hipLaunchKernelGGL(ipm_solve_split_kernel, dim3(2u * (unsigned)B), dim3(64), 0, stream, a, (const double *)c->d_mqm);
     } else if (queue_on && !a.order && !warm_kernel && blocks >= 3u * (unsigned)c->resident_waves) {
       HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int) * 2, stream));
+      c->last_form = 4;
       hipLaunchKernelGGL(ipm_solve_queue_kernel, dim3((unsigned)c->resident_waves & ~1u), dim3(64), 0, stream, a,
                          (const double *)c->d_mqm);
     } else {
+      c->last_form = 0;
       hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
     }
     HIPCHK(c, hipGetLastError());

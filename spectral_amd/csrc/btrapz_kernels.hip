@@ -285,12 +285,26 @@ __device__ __forceinline__ Red4 reduce4(double (*red)[64], double *wgs, int lane
 // termination decisions (lanes beyond S compute garbage nobody reads and write nothing), so all wavefronts leave the
 // loop together.  Correctness over speed: the reference has no limit on the segment count (std::vector,
 // solve_3d.cc:323-486), its bundled inputs have at most 14.
-template <bool WARM, bool ORDERED, bool ELASTIC = false, bool QUEUE = false, bool SPLIT = false, bool MULTI = false>
+// CAPPED / RESUME (uniform cold batches much larger than the machine; btrapz_options.cap_iter): two launches instead of
+// one.  A wavefront runs as long as its slowest group, and a launch as long as its last wavefront: on the scenario_1
+// batch the same candidates sorted by iteration count (hard ones first) take 5.67 ms instead of 7.02.  The order cannot
+// be known in advance (neither the cold start's nor the unconstrained optimum's violations predict the count), but it
+// can be produced: the CAPPED launch stops every group at cap_iter iterations -- a group that has not converged by then
+// SUSPENDS: it writes its iterate (joint states, slacks, multipliers, best iterate and the termination bookkeeping:
+// SUSP_FIELDS doubles per lane) to a slot of a.susp_state and reports BTRAPZ_SUSPENDED -- and the RESUME launch picks
+// the suspended axis problems up from per-axis lists, bucketed by how far from convergence they were (the machinery of
+// the rescue pass), restores the iterate and carries on: the same iterates, bit for bit, as the one-launch solve.
+enum { SUSP_FIELDS = 3 + 4 * 15 + 3 + 8 };
+template <bool WARM, bool ORDERED, bool ELASTIC = false, bool QUEUE = false, bool SPLIT = false, bool MULTI = false,
+          bool CAPPED = false, bool RESUME = false>
 __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double *__restrict__ mqm, double (*lds)[64],
                                                const int wave_id, const int lane, double *wgs = nullptr, const int wv = 0) {
   static_assert(!QUEUE || (!WARM && !ORDERED && !ELASTIC), "the queue serves uniform cold batches");
   static_assert(!SPLIT || (!ORDERED && !ELASTIC && !QUEUE), "the split form serves uniform batches");
   static_assert(!MULTI || (!WARM && !ORDERED && !ELASTIC && !QUEUE && !SPLIT), "the long form serves uniform cold batches");
+  static_assert(!(CAPPED || RESUME) || (!WARM && !ELASTIC && !QUEUE && !SPLIT && !MULTI && !(CAPPED && RESUME)), "capped / resume: packed cold form");
+  static_assert(!RESUME || ORDERED, "the resume pass reads its problems from per-axis lists");
+  constexpr bool PERAXIS = ELASTIC || RESUME;   // one candidate list and one set of bucket tables per axis
   // value of the previous / next segment's lane (0 beyond the ends of the wavefront -- or, long form, of the workgroup)
   auto from_prev = [&](double x) -> double {
     double r = dpp_prev(x);
@@ -323,7 +337,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   if constexpr (ORDERED) {
     // ragged batch: candidates are bucketed by segment count; find this wave's bucket (wave-uniform)
     // (rescue pass: one set of tables and one candidate list per axis, the stalled axis problems only)
-    const int *wave_prefix = a.wave_prefix + (ELASTIC ? axis * 198 : 0), *cand_prefix = a.cand_prefix + (ELASTIC ? axis * 198 : 0);
+    const int *wave_prefix = a.wave_prefix + (PERAXIS ? axis * 198 : 0), *cand_prefix = a.cand_prefix + (PERAXIS ? axis * 198 : 0);
     if (pair >= wave_prefix[65]) return;
     // slot s with wave_prefix[s] <= pair < wave_prefix[s + 1] (empty buckets repeat their prefix): binary search,
     // six dependent scalar loads instead of up to 63
@@ -333,7 +347,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       if (wave_prefix[mid] <= pair) s = mid; else hi = mid;
     }
     S = a.bucket_S ? a.bucket_S : 65 - s;   // slot s holds key 65 - s (longest first); hint mode: classes of a uniform batch
-    pair -= wave_prefix[s]; cand0 = cand_prefix[s] + (ELASTIC ? axis * a.B : 0); ncand = cand_prefix[s + 1] - cand_prefix[s];
+    pair -= wave_prefix[s]; cand0 = cand_prefix[s] + (PERAXIS ? axis * a.B : 0); ncand = cand_prefix[s + 1] - cand_prefix[s];
   } else {
     S = a.S;
   }
@@ -416,6 +430,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   // there.  The pass is the loop body up to the predictor's sweep; it is not counted as an iteration.
   [[maybe_unused]] bool unc_pass = false;
   bool done = true;
+  [[maybe_unused]] bool suspended = false;   // capped launch: the group has handed its iterate over to the resume launch
   [[maybe_unused]] int cand_live = 0;   // long form: the workgroup has a candidate
   // The group's own iteration count.  (Warm-start instantiations: when one group of the wavefront restarts cold the
   // others lose that pass of the loop; queue: the groups of a wavefront are at different iterations.  A candidate's
@@ -462,6 +477,28 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   auto cold_start = [&]() {
     X[0] = Xcold0; X[1] = Xinit[1]; X[2] = 0.0;
     init_slacks();
+  };
+
+  // ---- capped / resume: a group's iterate in a.susp_state, slot-major, field i of lane k at [slot][i][k] ----
+  [[maybe_unused]] auto state_io = [&](const bool store, const long long slot) {
+    double *base = a.susp_state + (size_t)slot * SUSP_FIELDS * a.seg_stride + k;
+    const size_t fs = a.seg_stride;
+    int f = 0;
+    auto io = [&](double &v) { if (store) base[(size_t)f * fs] = v; else v = base[(size_t)f * fs]; ++f; };
+    UNROLL for (int i = 0; i < 3; i++) io(X[i]);
+    UNROLL for (int i = 0; i < 3; i++) io(Xb[i]);
+    FOR_ROWS(r)
+      io(sl[SI(r)]); io(su[SI(r)]);
+      double l_ = LL(r), u_ = LU(r);
+      io(l_); io(u_);
+      if (!store) { LL(r) = l_; LU(r) = u_; }
+    END_ROWS
+    double g8[8] = {best_score, (double)best_it, (double)best_res, (double)res_it, plain ? 1.0 : 0.0, (double)eit, (double)it0, (double)iters};
+    UNROLL for (int i = 0; i < 8; i++) io(g8[i]);
+    if (!store) {
+      best_score = g8[0]; best_it = (int)g8[1]; best_res = (float)g8[2]; res_it = (int)g8[3]; plain = g8[4] != 0.0;
+      eit = (int)g8[5]; it0 = (int)g8[6]; iters = (int)g8[7];
+    }
   };
 
   // What a lane reads of its candidate: its segment's fields for the wavefront's axis and the candidate's per-axis
@@ -683,9 +720,17 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     best_it = 0; iters = 0; best_res = 3e38f; res_it = 0; plain = false;
     done = !valid || infeasible_bounds || no_solution;
     if constexpr (MULTI) done = (cand_live == 0) || infeasible_bounds || no_solution;   // lanes beyond S follow the problem
-    unc_pass = !ELASTIC && !QUEUE && a.unc_start != 0 && !warm_started;
+    if constexpr (RESUME) {   // carry on where the capped launch stopped
+      if (valid) state_io(false, a.susp_slot[2LL * b + axis]);
+    }
+    unc_pass = !ELASTIC && !QUEUE && !RESUME && a.unc_start != 0 && !warm_started;
   };
   auto write_back = [&]() {
+    if constexpr (CAPPED) {
+      if (suspended) {
+        if (valid && first) { a.axis_status[2LL * b + axis] = BTRAPZ_SUSPENDED; a.axis_iters[2LL * b + axis] = iters; a.axis_obj[2LL * b + axis] = 0.0; }
+      }
+    }
     // ---------------- write back: multipliers (warm start of a later solve), control points, objective/status ----
     if (WARM && SPLIT && a.lam_out && valid) {   // every lane of a segment writes its own five rows
       UNROLL for (int i = 0; i < 5; i++) {
@@ -739,7 +784,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       const Red4 ro = reduce4<MULTI, 0, 1, 1, 1>(lds + L_RED, wgs, lane, wv, gbase, k, S, obj, viol, vnorm, 0.0);
       [[maybe_unused]] Red4 rv = {0.0, 0.0, 0.0, 0.0};
       if constexpr (ELASTIC) rv = reduce4<MULTI, 1, 1, 1, 1>(lds + L_RED, wgs, lane, wv, gbase, k, S, vcls[0], vcls[1], vcls[2], vcls[3]);
-      if (valid && (!SPLIT || g == 0)) {
+      if (valid && (!SPLIT || g == 0) && !(CAPPED && suspended)) {
         // control points in the reference's order: s axis (6 S), then l axis (6 S); rows are 12*seg_stride apart
         double *dst = a.ctrl + (size_t)b * 12 * a.seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
         UNROLL for (int i = 0; i < 6; i++) dst[i] = c[i];
@@ -918,6 +963,33 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 #endif
       // the iteration budget: the iterate just evaluated was the last one (a step nobody evaluates is not taken)
       if (!done && !restart_now && eit + 1 >= a.max_iter) done = true;
+    }
+    if constexpr (CAPPED) {
+      // the cap: a group still iterating after cap_iter iterations hands its iterate over to the resume launch.  (The
+      // iterate has just been evaluated; the resume launch evaluates it again -- the bookkeeping above is idempotent.)
+      // Who hands over: a group that is the only one of its wavefront still iterating after cap_iter iterations (the
+      // wavefront would run at a third of its width for it), and any group still iterating cap_hi iterations in (a long
+      // runner belongs at the front of a launch, not wherever the batch order put it).
+      const int nact = __popcll(__ballot(first && lane_in_group && valid && !done));
+      const bool want = !done && !unc_pass && valid && ((eit >= a.cap_iter && nact <= a.cap_alone) || eit >= a.cap_hi);
+      if (__any(want)) {
+        UNIFORM_BLOCK;
+        wave_lds_sync();
+        if (want && first) lds[L_RED][lane] = (double)atomicAdd(a.susp_count, 1);
+        wave_lds_sync();
+        const long long slot = want ? (long long)lds[L_RED][gbase] : -1;
+        if (want && slot < (long long)a.susp_cap) {   // (no room: the group simply goes on)
+          state_io(true, slot);
+          if (first) {
+            // how far from convergence: the class the resume launch buckets by (far ones first, like with like)
+            const double sc = fmax(fmin(score, 1e3), 1e-12);
+            int cls = 1 + (int)(4.0 * (log10(sc) + 12.0));
+            a.susp_slot[2LL * b + axis] = (int)slot;
+            a.susp_key[(size_t)axis * a.B + b] = cls < 1 ? 1 : cls > 64 ? 64 : cls;
+          }
+          suspended = true; done = true;
+        }
+      }
     }
     if constexpr (!QUEUE) { if (__all(done)) break; }
     if (WARM && __any(restart_now)) {
@@ -1343,6 +1415,16 @@ __global__ __launch_bounds__(64) void ipm_solve_warm_kernel(const KernelArgs a, 
 __global__ __launch_bounds__(64) void ipm_solve_warm_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[lds_rows<false>()][64];
   ipm_solve_body<true, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
+}
+// Uniform cold batches much larger than the machine, two launches (CAPPED / RESUME above): every group stops at
+// cap_iter iterations; the unfinished ones are carried on by the resume launch, like with like, far ones first.
+__global__ __launch_bounds__(64) void ipm_solve_capped_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  __shared__ double lds[lds_rows<false>()][64];
+  ipm_solve_body<false, false, false, false, false, false, true, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
+}
+__global__ __launch_bounds__(64) void ipm_solve_resume_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  __shared__ double lds[lds_rows<false>()][64];
+  ipm_solve_body<false, true, false, false, false, false, false, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 // Uniform cold batches much larger than the machine: persistent wavefronts over a candidate queue (see QUEUE above).
 __global__ __launch_bounds__(64) void ipm_solve_queue_kernel(const KernelArgs a, const double *__restrict__ mqm) {

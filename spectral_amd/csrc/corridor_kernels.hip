@@ -493,13 +493,18 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
 // all have the same count (the usual case) serialises on one address -- 0.74 ms per kernel at B = 65 536.
 // fixed_S > 0: the keys are difficulty hints of a uniform batch (any int; clamped to a class 1..64) instead of counts.
 __device__ __forceinline__ int hint_class(int v) { return v < 1 ? 1 : (v > 64 ? 64 : v); }
+// fixed_S < 0: classes of a uniform batch of -fixed_S segments in which a key <= 0 means "not listed" (the resume pass of
+// a capped solve lists the suspended axis problems only)
+__device__ __forceinline__ int bucket_key(int v, int fixed_S) {
+  return fixed_S > 0 ? hint_class(v) : fixed_S < 0 ? (v < 1 ? 0 : hint_class(v)) : v;
+}
 __global__ void bucket_hist_kernel(int B, int seg_stride, const int *seg_count, int *meta, int fixed_S) {
   __shared__ int h[65];
   for (int j = threadIdx.x; j < 65; j += blockDim.x) h[j] = 0;
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) {
-    const int s = fixed_S ? hint_class(seg_count[i]) : seg_count[i];
+    const int s = bucket_key(seg_count[i], fixed_S);
     if (s >= 1 && s <= 64 && (fixed_S || s <= seg_stride)) atomicAdd(&h[65 - s], 1);   // slot 65 - key: see the prefix kernel
   }
   __syncthreads();
@@ -513,7 +518,7 @@ __global__ void bucket_prefix_kernel(int *meta, int fixed_S) {
   meta[0] = 0; meta[66] = 0;
   for (int j = 1; j <= 64; j++) {
     const int key = 65 - j;
-    const int cnt = meta[132 + j], gpw = 64 / (fixed_S ? fixed_S : key);
+    const int cnt = meta[132 + j], gpw = 64 / (fixed_S > 0 ? fixed_S : fixed_S < 0 ? -fixed_S : key);
     meta[j] = cand; meta[66 + j] = wave;
     cand += cnt; wave += (cnt + gpw - 1) / gpw;
     meta[132 + j] = 0;  // becomes the scatter cursor
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(int B, int seg_stri
   int s = 0, rank = 0;
   bool usable = false;
   if (i < B) {
-    s = fixed_S ? hint_class(seg_count[i]) : seg_count[i];
+    s = bucket_key(seg_count[i], fixed_S);
     usable = s >= 1 && s <= 64 && (fixed_S || s <= seg_stride);
     if (!usable && axis_status) {  // no usable corridor: the reference's find_traj fails here (empty selection / CHECK)
       axis_obj[2 * i] = 0.0; axis_obj[2 * i + 1] = 0.0;

@@ -44,13 +44,13 @@ class COptions(C.Structure):
     """btrapz_options; struct_size is what btrapz_options_init() sets (the library rejects other layouts)."""
     _fields_ = [("struct_size", C.c_int), ("max_iter", C.c_int), ("eps", C.c_double), ("step_fraction", C.c_double),
                 ("step_threshold", C.c_double), ("elastic", C.c_int), ("elastic_tol", C.c_double),
-                ("elastic_delta", C.c_double), ("queue", C.c_int), ("split", C.c_int), ("start", C.c_int)]
+                ("elastic_delta", C.c_double), ("queue", C.c_int), ("split", C.c_int), ("start", C.c_int), ("cap_iter", C.c_int)]
 
 
-def _options(max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, elastic_delta=0.0, queue=0, split=0, start=0):
+def _options(max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, elastic_delta=0.0, queue=0, split=0, start=0, cap_iter=0):
     return COptions(C.sizeof(COptions), int(max_iter), float(eps), float(os.environ.get("BTRAPZ_STEP_FRACTION", "0")),
                     float(os.environ.get("BTRAPZ_STEP_THRESHOLD", "0")), int(elastic), float(elastic_tol),
-                    float(elastic_delta), int(queue), int(split), int(start))
+                    float(elastic_delta), int(queue), int(split), int(start), int(cap_iter))
 
 
 class CWarm(C.Structure):
@@ -106,7 +106,8 @@ EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "bt
            "btrapz_corridor_batch_device", "btrapz_sample_ragged_device", "btrapz_solve_warm_device",
            "btrapz_eval_states_device", "btrapz_find_traj_mem", "btrapz_prism_bounds_device",
            "btrapz_find_traj_last_iterations", "btrapz_argmin_pairs_device", "btrapz_options_init",
-           "btrapz_rescue_violations_device", "btrapz_find_traj_last_status", "btrapz_debug_mqm_tables")
+           "btrapz_rescue_violations_device", "btrapz_find_traj_last_status", "btrapz_debug_mqm_tables",
+           "btrapz_last_solve_form")
 
 
 def build(verbose=False):
@@ -171,6 +172,7 @@ def lib():
         l.btrapz_find_traj_last_status.argtypes = [C.c_void_p]; l.btrapz_find_traj_last_status.restype = C.c_int
         l.btrapz_options_init.argtypes = [C.POINTER(COptions)]; l.btrapz_options_init.restype = None
         l.btrapz_rescue_violations_device.argtypes = [vp, C.c_int, dp, vp]
+        l.btrapz_last_solve_form.argtypes = [vp]; l.btrapz_last_solve_form.restype = C.c_int
         l.btrapz_debug_mqm_tables.argtypes = [vp, C.POINTER(CShared), dp, dp]
         l.btrapz_solve_batch_device.argtypes = [vp, C.POINTER(CShared), C.POINTER(COptions), C.c_int, C.c_int,
                                                 dp, dp, dp, dp, dp, dp, ip, ip, vp]
@@ -239,8 +241,8 @@ class Context:
 
     # ---- device-pointer path (torch tensors only carry the memory) --------------------------
     def solve_device(self, B, S, shared, seg, init, ref_end, dl_bounds, ctrl, cost, status, iters=None,
-                     stream=None, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, queue=0, split=0, start=0):
-        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol, queue=queue, split=split, start=start)
+                     stream=None, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, queue=0, split=0, start=0, cap_iter=0):
+        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol, queue=queue, split=split, start=start, cap_iter=cap_iter)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self._check(lib().btrapz_solve_batch_device(self._h, C.byref(sh), C.byref(opt), B, S, ptr(seg), ptr(init),
                                                     ptr(ref_end), ptr(dl_bounds), ptr(ctrl), ptr(cost),
@@ -268,6 +270,10 @@ class Context:
                                                    ptr(seg), ptr(seg_count), ptr(init), ptr(ref_end), ptr(dl_bounds),
                                                    ptr(ctrl), ptr(cost), ptr(status), ptr(iters),
                                                    C.c_void_p(stream or 0)), "btrapz_solve_warm_device")
+
+    def last_solve_form(self):
+        """btrapz_last_solve_form: 0 packed, 1 split, 2 long, 3 capped + resume, 4 queue."""
+        return int(lib().btrapz_last_solve_form(self._h))
 
     def rescue_violations_device(self, B, viol, stream=None):
         """btrapz_rescue_violations_device: viol [B][4] (position, velocity, acceleration, jerk rows) of the last solve

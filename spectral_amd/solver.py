@@ -40,7 +40,7 @@ class BatchSolver:
         return self._out[key]
 
     def solve(self, dbatch, shared, max_iter=0, eps=0.0, out=None, warm=None, keep_multipliers=False, elastic=0,
-              elastic_tol=0.0, queue=0, split=0, start=0):
+              elastic_tol=0.0, queue=0, split=0, start=0, cap_iter=0):
         """Launches the solve on torch's current stream; returns dict of device tensors.
 
         warm: dict with optional "x0" ([B,2,S,3] joint states, e.g. from eval_states) and "lam" ([2,36,B,S]
@@ -55,7 +55,7 @@ class BatchSolver:
             self.ctx.solve_device(dbatch.B, dbatch.S, shared, dbatch.seg, dbatch.init, dbatch.ref_end,
                                   dbatch.dl_bounds, o["ctrl"], o["cost"], o["status"], o["iters"], stream=stream,
                                   max_iter=max_iter, eps=eps, elastic=elastic, elastic_tol=elastic_tol, queue=queue,
-                                  split=split, start=start)
+                                  split=split, start=start, cap_iter=cap_iter)
             return o
         warm = warm or {}
         x0, lam0, hint = warm.get("x0"), warm.get("lam"), warm.get("hint")

@@ -109,3 +109,30 @@ def test_unconstrained_start_reaches_the_same_optimum(gen, S, variant, split):
     for i in range(4):
         if ok[i]:
             assert np.abs(b["ctrl"][i] - xs[i]).max() <= 1e-5 * np.abs(xs[i]).max()
+
+
+@pytest.mark.parametrize("gen,S,variant,cap", [("scenario1", 20, 0, 6), ("scenario1", 20, 1, 5), ("generic", 20, 0, 4), ("scenario1", 10, 0, 7),
+                                               ("generic", 33, 0, 3), ("scenario1", 20, 0, 1)])
+def test_capped_first_launch_and_resume_launch_give_the_one_launch_results_bit_for_bit(gen, S, variant, cap):
+    """btrapz_options.cap_iter: a first launch in which a candidate left alone in its wavefront after cap iterations (or
+    still iterating four iterations later) hands its iterate over, and a second launch that carries those candidates
+    on from exactly that iterate.  Scheduling only: control points, costs, statuses and iteration counts are the
+    one-launch solve's, bit for bit."""
+    import torch
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    B = 3000
+    batch, sh = (synth.make_scenario1_batch(B, S, variant) if gen == "scenario1" else synth.make_batch(B, S, config=3, variant=variant))
+    db = solver.upload(batch)
+    a = {k: v.cpu().numpy().copy() for k, v in solver.solve(db, sh, split=-1, cap_iter=-1).items()}
+    b = {k: v.cpu().numpy().copy() for k, v in solver.solve(db, sh, split=-1, cap_iter=cap).items()}
+    torch.cuda.synchronize()
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["cost"], b["cost"])
+    ok = a["status"] > 0
+    assert ok.any() and np.array_equal(a["ctrl"][ok], b["ctrl"][ok])
+    assert (a["iters"] + 1 > cap + 4).any()          # (some candidates did go through the second launch)
+    # with the rescue pass behind it, too
+    c = {k: v.cpu().numpy().copy() for k, v in solver.solve(db, sh, split=-1, cap_iter=cap, elastic=1).items()}
+    d = {k: v.cpu().numpy().copy() for k, v in solver.solve(db, sh, split=-1, cap_iter=-1, elastic=1).items()}
+    torch.cuda.synchronize()
+    assert np.array_equal(c["status"], d["status"]) and np.array_equal(c["cost"], d["cost"])

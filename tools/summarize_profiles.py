@@ -13,7 +13,8 @@ import os
 import shutil
 import sys
 
-KERNEL = "ipm_solve_kernel"
+KERNEL = "ipm_solve_"        # every kernel of a solve call: ipm_solve_kernel, or ipm_solve_capped_kernel + ipm_solve_resume_kernel
+PRIMARY = ("ipm_solve_kernel", "ipm_solve_capped_kernel", "ipm_solve_queue_kernel", "ipm_solve_split_kernel")   # one launch of these = one solve
 
 
 def counter_means(root, pattern="pmc_*", kernel=KERNEL):
@@ -26,18 +27,30 @@ def counter_means(root, pattern="pmc_*", kernel=KERNEL):
             newest[group] = path
     for path in newest.values():
         acc = {}
-        with open(path, newline="") as f:
-            for row in csv.DictReader(f):
+        solve_of = {}      # dispatch -> number of the solve call it belongs to (a primary kernel opens one)
+        nsolve = 0
+        rows = list(csv.DictReader(open(path, newline="")))
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        for row in rows:
                 if kernel not in row["Kernel_Name"]:
                     continue
-                acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
-                acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+                base = row["Kernel_Name"].split("(")[0].split("::")[-1]
+                primary = kernel != KERNEL or base in PRIMARY
+                if row["Dispatch_Id"] not in solve_of:
+                    if primary:
+                        nsolve += 1
+                    solve_of[row["Dispatch_Id"]] = max(nsolve, 1)
+                key = solve_of[row["Dispatch_Id"]]
+                acc.setdefault(row["Counter_Name"], {}).setdefault(key, 0.0)
+                acc[row["Counter_Name"]][key] += float(row["Counter_Value"])
                 # rocprofv3's register columns are NOT the compiler's VGPR / AGPR counts: on gfx950 it reports the unified
                 # allocation (VGPR + AGPR, rounded up to the granule of 8) divided by two under VGPR_Count and 0 under
                 # Accum_VGPR_Count (256 + 199 -> 456 / 2 = 228).  Kept under names that say so; the compiler's figures
                 # are added by compiler_resources() below.
-                res = dict(rocprof_VGPR_Count_field=row["VGPR_Count"], rocprof_Accum_VGPR_Count_field=row["Accum_VGPR_Count"],
-                           sgpr=row["SGPR_Count"], lds=row["LDS_Block_Size"], scratch=row["Scratch_Size"], grid=row["Grid_Size"])
+                if primary:
+                    res = dict(rocprof_VGPR_Count_field=row["VGPR_Count"], rocprof_Accum_VGPR_Count_field=row["Accum_VGPR_Count"],
+                               sgpr=row["SGPR_Count"], lds=row["LDS_Block_Size"], scratch=row["Scratch_Size"], grid=row["Grid_Size"],
+                               primary_kernel=base)
         for name, per in acc.items():
             vals = list(per.values())
             out[name] = dict(mean=sum(vals) / len(vals), min=min(vals), max=max(vals), launches=len(vals), **res)
@@ -113,8 +126,9 @@ def main():
     for k in ("FETCH_SIZE", "WRITE_SIZE"):
         if k in c:
             hbm[k] = dict(launches=c[k]["launches"], mean_KB=c[k]["mean"], min_KB=c[k]["min"], max_KB=c[k]["max"],
-                          **{r: c[k][r] for r in ("rocprof_VGPR_Count_field", "rocprof_Accum_VGPR_Count_field", "sgpr", "lds", "scratch", "grid")})
-    cres = compiler_resources(here)
+                          **{r: c[k][r] for r in ("rocprof_VGPR_Count_field", "rocprof_Accum_VGPR_Count_field", "sgpr", "lds", "scratch", "grid", "primary_kernel")})
+    primary = next(iter(c.values())).get("primary_kernel", "ipm_solve_kernel")
+    cres = compiler_resources(here, primary + "E")
     if len(hbm) == 2:
         hbm["compiler_resources"] = cres
         hbm["workload"] = wl
@@ -129,7 +143,7 @@ def main():
         hbm["fetch_factor"], hbm["write_factor"] = kf, kw
         hbm["bytes_per_launch"] = (kf * hbm["FETCH_SIZE"]["mean_KB"] + kw * hbm["WRITE_SIZE"]["mean_KB"]) * 1024.0
         hbm["note"] = ("FETCH_SIZE/WRITE_SIZE in KB, separate --pmc passes (TCC slot limit), means over the launches of "
-                       "btrapz::ipm_solve_kernel.  bytes_per_launch = fetch_factor x FETCH_SIZE + write_factor x WRITE_SIZE with the "
+                       "the solve call's kernels (btrapz::ipm_solve_*: one launch, or the capped launch + the resume launch).  bytes_per_launch = fetch_factor x FETCH_SIZE + write_factor x WRITE_SIZE with the "
                        "factors measured by tools/fetch_calib.hip on known byte counts in the kernel's access widths "
                        "(calibration); bytes_per_launch_raw is the uncorrected sum.")
         json.dump(hbm, open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
@@ -156,7 +170,7 @@ def main():
                             f64.get("SQ_INSTS_VALU_ADD_F64", 0) + f64.get("SQ_INSTS_VALU_TRANS_F64", 0))
             derived["fp64_flops_per_launch_all_lanes"] = flops
             derived["fp64_share_of_valu_instructions"] = sum(f64.values()) / sq["SQ_INSTS_VALU"]
-        json.dump(dict(kernel=KERNEL, workload=wl, kernel_source_hash=stamp, compiler_resources=cres, per_launch=sq, derived=derived,
+        json.dump(dict(kernel=primary + (" + ipm_solve_resume_kernel" if primary == "ipm_solve_capped_kernel" else ""), workload=wl, kernel_source_hash=stamp, compiler_resources=cres, per_launch=sq, derived=derived,
                        note="rocprofv3 --pmc passes (tools/collect_profiles.sh), means over the launches of one "
                             "bench.py --steps 3 --warmup 1 run; SQ cycle counters are in units of 4 clock cycles."),
                   open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)
