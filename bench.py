@@ -305,7 +305,10 @@ def main():
                          "kernel": SOLVE_FORMS.get(solve_form, "btrapz::ipm_solve_kernel"), "kernel_ms": kernel_ms, "kernel_source_hash": kernel_stamp(),
                          "algorithmic_bytes_per_solve": batch.algorithmic_bytes(),
                          "note": "on-chip solve: the binding resource is FP64 VALU issue + dependent sweeps, not HBM "
-                                 "(SURVEY 8d); see fp64_valu",
+                                 "(SURVEY 8d); see fp64_valu" + ("; traffic above the algorithmic bytes is the iterate of the candidates the "
+                                 "first launch hands to the second (74 doubles per segment, written once and read once, for the ~12 % of "
+                                 "the axis problems that are handed over) and their records read a second time: not re-reads of a "
+                                 "working set" if solve_form == 3 else ""),
                          "fp64_valu": {"achieved_tflops": flops / (kernel_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                                        "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                        "model": "%.0f useful flops per segment per iteration x %.2f mean iterations" %
