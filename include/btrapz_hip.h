@@ -332,6 +332,17 @@ typedef struct btrapz_road {
 int btrapz_prism_bounds_device(btrapz_ctx *ctx, int B, int P, int N, const btrapz_road *road, const double *prisms,
                                int O, double *s_bounds, double *l_bounds, int *n_strips, void *stream);
 
+/* Obstacle prisms -> corridors in ONE launch: btrapz_prism_bounds_device followed by btrapz_corridor_batch_device with
+ * num_obs = O, with the strips evaluated inside the corridor kernel where it reads them instead of written to memory
+ * and read back (2 x 32 O N bytes per scene less traffic, one launch less).  Same outputs, bit for bit
+ * (tests/test_gpu_prism_bounds.py).  Arguments as in the two calls it replaces; n_strips may be NULL.  Scenes with
+ * O * N > 1536 take the two launches internally, through a workspace of the context. */
+int btrapz_prism_corridor_batch_device(btrapz_ctx *ctx, int variant, int B, int P, int N, const btrapz_road *road,
+                                       const double *prisms, int O, double delta, const double *ds_bounds,
+                                       const double *dl_bounds_knots, const double *s_ref, const double *l_ref,
+                                       int seg_stride, double *seg, int *seg_count, double *ref_end,
+                                       double *dl_bounds, int *n_strips, void *stream);
+
 /* btrapz_sample_device for ragged batches (seg_count may be NULL: every candidate has seg_stride). */
 int btrapz_sample_ragged_device(btrapz_ctx *ctx, int B, int seg_stride, const int *seg_count,
                                 double delta, const double *seg, const double *init,

@@ -70,10 +70,20 @@ struct KernelArgs {
   double *x_out;            // warm-start instantiations: joint states of the returned iterate, layout of x0 (may be null)
 };
 
+struct PrismRoad {              // btrapz_road in the form the prism stage uses it (prism_core.h)
+  double rate;                  // knots per second (the reference hard-codes 10: `i/10`, `t0*10`)
+  double s_lo, s_hi, l_lo, l_hi, l_safe, w_safe;
+};
+
 struct CorridorArgs {
   int B, N, num_obs, variant, seg_stride;
   double delta;
-  const double *s_bounds, *l_bounds;   // [B][num_obs][N][2]
+  const double *s_bounds, *l_bounds;   // [B][num_obs][N][2]; unused by the fused prism + corridor kernels
+  // fused prism + corridor kernels (btrapz_prism_corridor_batch_device): the strips are evaluated from the prisms
+  const double *prisms;                // [B][P][8]
+  int P;
+  PrismRoad road;
+  int *n_strips;                       // [B]
   const double *ds_bounds, *dl_bounds; // [B][N][2]
   const double *s_ref, *l_ref;         // [B][N]
   double *seg;                         // [NUM_SEG_FIELDS][B][seg_stride]
@@ -88,6 +98,8 @@ struct CorridorArgs {
 
 __global__ void corridor_batch_kernel(const CorridorArgs a, int staged);
 __global__ void corridor_batch_short_kernel(const CorridorArgs a, int staged);   // N <= 128
+__global__ void prism_corridor_batch_kernel(const CorridorArgs a, int staged);   // prisms -> strips -> corridors in one launch
+__global__ void prism_corridor_batch_short_kernel(const CorridorArgs a, int staged);
 // fixed_S = 0: bucket by segment count (ragged batches); > 0: uniform batch of fixed_S segments, bucket by hint class
 __global__ void bucket_hist_kernel(int B, int seg_stride, const int *seg_count, int *meta, int fixed_S);
 __global__ void bucket_prefix_kernel(int *meta, int fixed_S);

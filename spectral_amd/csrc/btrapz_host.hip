@@ -10,6 +10,7 @@
 #include <string>
 
 #include "btrapz_device.h"
+#include "prism_core.h"
 
 using namespace btrapz;
 
@@ -71,6 +72,7 @@ struct btrapz_ctx {
   int *d_order = nullptr; size_t order_cap = 0;
   int *d_meta = nullptr;            // [198] histogram/cand_prefix, wave_prefix, cursors
   int *d_retry = nullptr; size_t retry_cap = 0;   // corridor stage: [0] count, [1..] candidates of the retry pass
+  void *d_strips = nullptr; size_t strip_cap = 0; // btrapz_prism_corridor_batch_device's two-launch path: the strips
   // rescue pass (btrapz_options.elastic): keys [2][B], per-axis candidate lists [2][B], bucket tables [2][198]
   // The workspaces above serve one launch sequence at a time.  Launches of one context issued on DIFFERENT streams are
   // ordered behind each other with this event (recorded after every sequence, waited for when the stream changes).
@@ -135,7 +137,7 @@ BTRAPZ_EXPORT int btrapz_destroy(btrapz_ctx *c) {
   (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters); (void)hipFree(c->d_axis_viol);
   (void)hipFree(c->d_mqm); (void)hipFree(c->d_stage); (void)hipFree(c->d_istage); (void)hipFree(c->d_single);
   (void)hipFree(c->d_queue); (void)hipFree(c->d_single_warm); (void)hipFree(c->d_susp_state); (void)hipFree(c->d_susp_ints);
-  (void)hipFree(c->d_order); (void)hipFree(c->d_meta); (void)hipFree(c->d_retry);
+  (void)hipFree(c->d_order); (void)hipFree(c->d_meta); (void)hipFree(c->d_retry); (void)hipFree(c->d_strips);
   (void)hipFree(c->d_rescue); (void)hipFree(c->d_rescue_meta); (void)hipFree(c->d_argmin_cost); (void)hipFree(c->d_argmin_idx);
   if (c->ws_free) (void)hipEventDestroy(c->ws_free);
   delete c;
@@ -556,6 +558,53 @@ BTRAPZ_EXPORT int btrapz_eval_states_device(btrapz_ctx *c, int B, int seg_stride
   return BTRAPZ_OK;
 }
 
+// The launches of the corridor stage: `a` holds the shapes and every pointer but the retry list.  prisms: the fused
+// prism + corridor kernels (the strips are evaluated from a.prisms instead of read from a.s_bounds / a.l_bounds).
+static int launch_corridor_stage(btrapz_ctx *c, CorridorArgs a, bool prisms, hipStream_t stream) {
+  const int B = a.B, N = a.N, num_obs = a.num_obs, seg_stride = a.seg_stride;
+  // Two passes (corridor_kernels.hip): lists sized for the usual case first -- LDS per workgroup is what limits the
+  // wavefronts per CU -- then the candidates that overflowed them, with the full capacities.
+  if ((size_t)B + 1 > c->retry_cap) {
+    (void)hipFree(c->d_retry); c->d_retry = nullptr; c->retry_cap = 0;
+    HIPCHK(c, hipMalloc(&c->d_retry, sizeof(int) * ((size_t)B + 1)));
+    c->retry_cap = (size_t)B + 1;
+  }
+  HIPCHK(c, hipMemsetAsync(c->d_retry, 0, sizeof(int), stream));
+  a.retry_count = c->d_retry; a.retry_list = c->d_retry + 1;
+  const int cap_o_big = 160 / num_obs, cap_sel_big = 64;        // MAX_ALL / O, MAX_SEL of corridor_kernels.hip
+  int cap_o_small = (N - 1) / 10 + 9, cap_sel_small = 2 * seg_stride < 16 ? 16 : 2 * seg_stride;
+  if (cap_o_small > cap_o_big) cap_o_small = cap_o_big;
+  if (cap_sel_small > cap_sel_big) cap_sel_small = cap_sel_big;
+  const size_t slope_bytes = sizeof(double) * 2 * (size_t)N * num_obs;
+  const int staged = slope_bytes <= 24 * 1024 ? 1 : 0;
+  if (prisms && !staged) { c->err = "internal: fused corridor stage without a staged slope table"; return BTRAPZ_EINVAL; }
+  auto lds_bytes = [&](int cap_o, int cap_sel) {
+    const size_t cap_all = (size_t)cap_o * num_obs;
+    return 104 * (cap_all > (size_t)cap_sel ? cap_all : (size_t)cap_sel) + (staged && slope_bytes > sizeof(double) * 4 * (size_t)N ? slope_bytes : sizeof(double) * 4 * (size_t)N) +
+           sizeof(int) * (cap_all + 64 + cap_sel) + sizeof(short) * (cap_all + cap_sel) + 16 +
+           (prisms ? prism_tab_bytes(a.P) + 8 : 0)
+#ifdef CABL_PAD   // occupancy experiments: scratch/build_variant.sh X -DCABL_PAD=bytes
+           + CABL_PAD
+#endif
+        ;
+  };
+  const bool two_pass = cap_o_small < cap_o_big || cap_sel_small < cap_sel_big;
+  a.pass = 0; a.cap_o = cap_o_small; a.cap_sel = cap_sel_small;
+  if (!two_pass) { a.retry_list = nullptr; a.retry_count = nullptr; }
+  // (horizons of at most 128 knots: the instantiation that holds half the prefetch registers)
+  auto kernel = prisms ? (N <= 128 ? prism_corridor_batch_short_kernel : prism_corridor_batch_kernel)
+                       : (N <= 128 ? corridor_batch_short_kernel : corridor_batch_kernel);
+  hipLaunchKernelGGL(kernel, dim3(B), dim3(64), lds_bytes(a.cap_o, a.cap_sel), stream, a, staged);
+  HIPCHK(c, hipGetLastError());
+  if (two_pass) {
+    a.pass = 1; a.cap_o = cap_o_big; a.cap_sel = cap_sel_big;
+    const unsigned blocks = B < 1024 ? (unsigned)B : 1024u;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds_bytes(a.cap_o, a.cap_sel), stream, a, staged);
+  }
+  HIPCHK(c, hipGetLastError());
+  return BTRAPZ_OK;
+}
+
 BTRAPZ_EXPORT int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B, int N, int num_obs, double delta,
                                             const double *s_bounds, const double *l_bounds, const double *ds_bounds,
                                             const double *dl_bounds_knots, const double *s_ref, const double *l_ref,
@@ -570,48 +619,56 @@ BTRAPZ_EXPORT int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B
   }
   HIPCHK(c, hipSetDevice(c->device));
   CorridorArgs a;
+  memset(&a, 0, sizeof a);
   a.B = B; a.N = N; a.num_obs = num_obs; a.variant = variant; a.seg_stride = seg_stride; a.delta = delta;
   a.s_bounds = s_bounds; a.l_bounds = l_bounds; a.ds_bounds = ds_bounds; a.dl_bounds = dl_bounds_knots;
   a.s_ref = s_ref; a.l_ref = l_ref; a.seg = seg; a.seg_count = seg_count; a.ref_end = ref_end; a.dl10 = dl_bounds;
-  // Two passes (corridor_kernels.hip): lists sized for the usual case first -- LDS per workgroup is what limits the
-  // wavefronts per CU -- then the candidates that overflowed them, with the full capacities.
-  if ((size_t)B + 1 > c->retry_cap) {
-    (void)hipFree(c->d_retry); c->d_retry = nullptr; c->retry_cap = 0;
-    HIPCHK(c, hipMalloc(&c->d_retry, sizeof(int) * ((size_t)B + 1)));
-    c->retry_cap = (size_t)B + 1;
+  return launch_corridor_stage(c, a, false, (hipStream_t)stream_);
+}
+
+// Obstacle prisms -> strips -> corridors: btrapz_prism_bounds_device + btrapz_corridor_batch_device (num_obs = O) with
+// the strips evaluated where the corridor stage reads them instead of written to memory and read back.  Scenes whose
+// slope table does not fit the kernel's LDS (O * N * 16 bytes > 24 KB) take the two launches through a workspace of
+// the context: the results are the same either way.
+BTRAPZ_EXPORT int btrapz_prism_corridor_batch_device(btrapz_ctx *c, int variant, int B, int P, int N, const btrapz_road *road,
+                                                  const double *prisms, int O, double delta, const double *ds_bounds,
+                                                  const double *dl_bounds_knots, const double *s_ref, const double *l_ref,
+                                                  int seg_stride, double *seg, int *seg_count, double *ref_end,
+                                                  double *dl_bounds, int *n_strips, void *stream_) {
+  if (!c) return BTRAPZ_EINVAL;
+  if (variant < 0 || variant > 1 || B < 1 || P < 1 || P > 16 || N < 3 || N > 512 || O < 1 || O > 64 || !(delta > 0) || !road ||
+      !(road->knots_per_second > 0) || !prisms || seg_stride < 1 || !ds_bounds || !dl_bounds_knots || !s_ref || !l_ref ||
+      !seg || !seg_count || !ref_end || !dl_bounds) {
+    c->err = "invalid argument";
+    return BTRAPZ_EINVAL;
   }
+  HIPCHK(c, hipSetDevice(c->device));
   hipStream_t stream = (hipStream_t)stream_;
-  HIPCHK(c, hipMemsetAsync(c->d_retry, 0, sizeof(int), stream));
-  a.retry_count = c->d_retry; a.retry_list = c->d_retry + 1;
-  const int cap_o_big = 160 / num_obs, cap_sel_big = 64;        // MAX_ALL / O, MAX_SEL of corridor_kernels.hip
-  int cap_o_small = (N - 1) / 10 + 9, cap_sel_small = 2 * seg_stride < 16 ? 16 : 2 * seg_stride;
-  if (cap_o_small > cap_o_big) cap_o_small = cap_o_big;
-  if (cap_sel_small > cap_sel_big) cap_sel_small = cap_sel_big;
-  const size_t slope_bytes = sizeof(double) * 2 * (size_t)N * num_obs;
-  const int staged = slope_bytes <= 24 * 1024 ? 1 : 0;
-  auto lds_bytes = [&](int cap_o, int cap_sel) {
-    const size_t cap_all = (size_t)cap_o * num_obs;
-    return 104 * (cap_all > (size_t)cap_sel ? cap_all : (size_t)cap_sel) + (staged && slope_bytes > sizeof(double) * 4 * (size_t)N ? slope_bytes : sizeof(double) * 4 * (size_t)N) +
-           sizeof(int) * (cap_all + 64 + cap_sel) + sizeof(short) * (cap_all + cap_sel) + 16
-#ifdef CABL_PAD   // occupancy experiments: scratch/build_variant.sh X -DCABL_PAD=bytes
-           + CABL_PAD
-#endif
-        ;
-  };
-  const bool two_pass = cap_o_small < cap_o_big || cap_sel_small < cap_sel_big;
-  a.pass = 0; a.cap_o = cap_o_small; a.cap_sel = cap_sel_small;
-  if (!two_pass) { a.retry_list = nullptr; a.retry_count = nullptr; }
-  // (horizons of at most 128 knots: the instantiation that holds half the prefetch registers)
-  auto kernel = N <= 128 ? corridor_batch_short_kernel : corridor_batch_kernel;
-  hipLaunchKernelGGL(kernel, dim3(B), dim3(64), lds_bytes(a.cap_o, a.cap_sel), stream, a, staged);
-  HIPCHK(c, hipGetLastError());
-  if (two_pass) {
-    a.pass = 1; a.cap_o = cap_o_big; a.cap_sel = cap_sel_big;
-    const unsigned blocks = B < 1024 ? (unsigned)B : 1024u;
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds_bytes(a.cap_o, a.cap_sel), stream, a, staged);
+  CorridorArgs a;
+  memset(&a, 0, sizeof a);
+  a.B = B; a.N = N; a.num_obs = O; a.variant = variant; a.seg_stride = seg_stride; a.delta = delta;
+  a.ds_bounds = ds_bounds; a.dl_bounds = dl_bounds_knots;
+  a.s_ref = s_ref; a.l_ref = l_ref; a.seg = seg; a.seg_count = seg_count; a.ref_end = ref_end; a.dl10 = dl_bounds;
+  if (sizeof(double) * 2 * (size_t)N * O <= 24 * 1024) {
+    a.prisms = prisms; a.P = P; a.road = prism_road(road); a.n_strips = n_strips;
+    return launch_corridor_stage(c, a, true, stream);
   }
-  HIPCHK(c, hipGetLastError());
-  return BTRAPZ_OK;
+  const size_t need = sizeof(double) * 4 * (size_t)B * O * N + sizeof(int) * (size_t)B;
+  if (need > c->strip_cap) {
+    (void)hipFree(c->d_strips); c->d_strips = nullptr; c->strip_cap = 0;
+    HIPCHK(c, hipMalloc(&c->d_strips, need));
+    c->strip_cap = need;
+  }
+  if (c->ws_used && stream != c->ws_stream) HIPCHK(c, hipStreamWaitEvent(stream, c->ws_free, 0));
+  double *sb = reinterpret_cast<double *>(c->d_strips), *lb = sb + 2 * (size_t)B * O * N;
+  int *ns = n_strips ? n_strips : reinterpret_cast<int *>(lb + 2 * (size_t)B * O * N);
+  const int rc = btrapz_prism_bounds_device(c, B, P, N, road, prisms, O, sb, lb, ns, stream_);
+  if (rc != BTRAPZ_OK) return rc;
+  a.s_bounds = sb; a.l_bounds = lb;
+  const int rc2 = launch_corridor_stage(c, a, false, stream);
+  c->ws_stream = stream; c->ws_used = true;
+  HIPCHK(c, hipEventRecord(c->ws_free, stream));
+  return rc2;
 }
 
 BTRAPZ_EXPORT int btrapz_argmin_device(btrapz_ctx *c, int B, int group, long long index_base, const double *cost,

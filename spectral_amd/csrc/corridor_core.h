@@ -71,8 +71,9 @@ struct SlopeTable {  // interleaved (down, up) pairs, entry i at p[2 i]
 
 // ---- CorridorGeneration + CorridorSplit for one obstacle.  Returns the number of segments written,
 // or -1 when `cap` is too small.
-template <class Slopes>
-BTRAPZ_HD int extract_segments_core(int variant, int N, double delta, BoundsView sb, BoundsView lb, Slopes sk, Seg *v, int cap) {
+// (SB, LB: anything with lo(i) / hi(i) -- BoundsView, or the strips of the fused prism + corridor kernel)
+template <class SB, class LB, class Slopes>
+BTRAPZ_HD int extract_segments_core(int variant, int N, double delta, SB sb, LB lb, Slopes sk, Seg *v, int cap) {
   if (cap < 1 || N < 3) return -1;
   int n = 0;
   {

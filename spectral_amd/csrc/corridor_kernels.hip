@@ -18,6 +18,7 @@
 
 #include "btrapz_device.h"
 #include "corridor_core.h"
+#include "prism_core.h"
 
 namespace btrapz {
 
@@ -31,22 +32,24 @@ enum { MAX_ALL = 160, MAX_SEL = 64 };   // capacities of the retry pass (see btr
 //              storage: s_ref[N] | l_ref[N] | ds_bounds[N][2]) |
 //              int hits[O * cap_o] | int ocount[64] | int key[cap_sel] | short slot_of[O * cap_o] | short pick[cap_sel]
 // RB: blocks of 64 knots of the reference and the ds bounds held in registers across the extraction (2 serve N <= 128).
-template <int RB>
+// PRISMS: the per-knot bounds are not read but evaluated from the scene's obstacle prisms (prism_core.h), whose tables
+// sit behind pick[] -- the fused form of prism_bounds_kernel + this kernel, same segments bit for bit.
+template <int RB, bool PRISMS>
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw);
 
 #ifndef CABL_WAVES
 #define CABL_WAVES 4
 #endif
-template <int RB>
+template <int RB, bool PRISMS = false>
 __device__ __forceinline__ void corridor_batch_body(const CorridorArgs &a, int staged) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   if (a.pass == 0) {
-    corridor_candidate<RB>(a, staged, (int)blockIdx.x, lds_raw);
+    corridor_candidate<RB, PRISMS>(a, staged, (int)blockIdx.x, lds_raw);
   } else {  // retry pass: the candidates the first pass could not hold
     const int n = *a.retry_count;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
       // (the candidate's number is the same in every lane: say so, or every address derived from it costs vector registers)
-      corridor_candidate<RB>(a, staged, __builtin_amdgcn_readfirstlane(a.retry_list[i]), lds_raw);
+      corridor_candidate<RB, PRISMS>(a, staged, __builtin_amdgcn_readfirstlane(a.retry_list[i]), lds_raw);
       __syncthreads();
     }
   }
@@ -58,6 +61,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 8))) void corridor_batch_short_kernel(const CorridorArgs a, int staged) {
   corridor_batch_body<2>(a, staged);
 }
+// prisms -> strips -> corridors in one launch (btrapz_prism_corridor_batch_device)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 8))) void prism_corridor_batch_kernel(const CorridorArgs a, int staged) {
+  corridor_batch_body<4, true>(a, staged);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 8))) void prism_corridor_batch_short_kernel(const CorridorArgs a, int staged) {
+  corridor_batch_body<2, true>(a, staged);
+}
+
+// Where the per-knot bounds of obstacle corridor o come from: memory ([num_obs][N][2] of the candidate) or the prisms.
+struct MemoryBounds {
+  const double *gs, *gl;
+  int N;
+  __device__ __forceinline__ double2 s2(int o, int i) const { const double *p = gs + ((size_t)o * N + i) * 2; return make_double2(p[0], p[1]); }
+  __device__ __forceinline__ double2 l2(int o, int i) const { const double *p = gl + ((size_t)o * N + i) * 2; return make_double2(p[0], p[1]); }
+};
+struct PrismBounds {
+  PrismTab t;
+  PrismRoad r;
+  __device__ __forceinline__ double2 s2(int o, int i) const { return prism_pair_s(t, r, o, i); }
+  __device__ __forceinline__ double2 l2(int o, int /*i*/) const { return prism_pair_l(t, o); }
+};
+struct PrismViewS { const PrismBounds *p; int o; __device__ double lo(int i) const { return p->s2(o, i).x; } __device__ double hi(int i) const { return p->s2(o, i).y; } };
+struct PrismViewL { const PrismBounds *p; int o; __device__ double lo(int i) const { return p->l2(o, i).x; } __device__ double hi(int i) const { return p->l2(o, i).y; } };
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {  // l: the same in every lane
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
@@ -122,8 +148,8 @@ __device__ __forceinline__ bool find_breaks_wave(const CorridorArgs &a, int lane
 }
 // after_slopes(): called by every lane once the slope table has been read for the last time (the caller stores the
 // prefetched reference over it there: held in registers any longer, the allocator spills the prefetch to scratch)
-template <class F>
-__device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int lane, const double *gs, const double *gl,
+template <class Src, class F>
+__device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int lane, const Src &src,
                                                     const double *slopes, Seg *all, int cap_o, int *ocount, const int *brk,
                                                     short *first, int my_nb, F &&after_slopes) {
   const int N = a.N, O = a.num_obs;
@@ -144,16 +170,17 @@ __device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int l
   after_slopes();
   if (mo >= 0) {
     const int beg = brk[mo * cap_o + mk];
-    const BoundsView sb{gs + (size_t)mo * N * 2}, lb{gl + (size_t)mo * N * 2};
+    const double2 sb = src.s2(mo, beg), lb = src.l2(mo, beg);
     s.beg_t = beg;
     s.end_t = mk + 1 < mn ? brk[mo * cap_o + mk + 1] : N - 1;
-    s.down_skew = slope.x; s.down_bias = sb.lo(beg);
-    s.upp_skew = slope.y; s.upp_bias = sb.hi(beg);
-    s.beg_l = lb.lo(beg); s.end_l = lb.hi(beg);
+    s.down_skew = slope.x; s.down_bias = sb.x;
+    s.upp_skew = slope.y; s.upp_bias = sb.y;
+    s.beg_l = lb.x; s.end_l = lb.y;
     if (a.variant == 0) {  // forward difference for the first segment, backward for the later ones (solve_3d.cc:338-341,358-367)
       const int i1 = beg == 0 ? 1 : beg, i0 = i1 - 1;
+      const double2 l1 = src.l2(mo, i1), l0 = src.l2(mo, i0);
       s.l_down_bias = s.beg_l; s.l_upp_bias = s.end_l;
-      s.l_down_skew = (lb.lo(i1) - lb.lo(i0)) / a.delta; s.l_upp_skew = (lb.hi(i1) - lb.hi(i0)) / a.delta;
+      s.l_down_skew = (l1.x - l0.x) / a.delta; s.l_upp_skew = (l1.y - l0.y) / a.delta;
     }
     s.t = (s.end_t - s.beg_t) * a.delta;
     double t = s.t;
@@ -190,7 +217,12 @@ __device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int l
   }
 }
 
-template <int RB>
+__device__ __forceinline__ double from_lane_below(double v) {   // lane l gets lane l - 1's value (lane 0: 0)
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false),    // wave_shr:1
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false));
+}
+
+template <int RB, bool PRISMS>
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw) {
   const int lane = threadIdx.x;
   const int N = a.N, O = a.num_obs;
@@ -199,7 +231,9 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   Seg *sel = all;                                        // the selected, ordered corridor: written (from registers)
                                                          // when all[] has been read for the last time, over it
   // (16-byte aligned: the slopes are written as double2)
-  double *dyn = reinterpret_cast<double *>((reinterpret_cast<size_t>(all + (cap_all > cap_sel ? cap_all : cap_sel)) + 15) & ~(size_t)15);
+  // (as an offset from lds_raw: a pointer that went through an integer is a generic pointer to the compiler, and every
+  //  access through it a flat_ instruction -- all lists behind the segments were reached that way until round 3)
+  double *dyn = reinterpret_cast<double *>(lds_raw + ((sizeof(Seg) * (size_t)(cap_all > cap_sel ? cap_all : cap_sel) + 15) & ~(size_t)15));
   // the slope table lives until the segments are built; the reference and the ds bounds (needed from the selection
   // on) are loaded meanwhile and stored over it
   double *slopes = dyn;
@@ -211,30 +245,53 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   int *key = ocount + 64;                                // beg_t of the survivors of the de-dup, for the rank sort
   short *slot_of = reinterpret_cast<short *>(key + cap_sel);  // flattened segment index -> slot in all[]
   short *pick = slot_of + cap_all;                       // slots of the selected segments, in selection order
+  PrismBounds prism;
+  if constexpr (PRISMS) {                                // the scene's tables: edges of the strips, faces of the cars
+    const size_t used = reinterpret_cast<unsigned char *>(pick + cap_sel) - lds_raw;
+    prism.t = prism_tab_at(lds_raw + ((used + 7) & ~(size_t)7), a.P);
+    prism.r = a.road;
+    const int strips = prism_tables(prism.t, prism.r, a.prisms + (size_t)b * a.P * 8, lane);
+    if (lane == 0 && a.n_strips) a.n_strips[b] = strips <= O ? strips : -1;
+  }
 
   // The streaming phase.  A wavefront that waits for each load before it issues the next one pays a memory round
   // trip per 64 knots: the loads are issued in blocks of four per array (indices clamped instead of predicated, so
   // that they stay in one basic block).
   // The extraction compares slopes: all lanes compute them (two divisions per knot) from coalesced 16-byte loads and
   // leave them in LDS; the bounds themselves are read again only where a segment starts.
-  const double *gs = a.s_bounds + (size_t)b * O * N * 2, *gl = a.l_bounds + (size_t)b * O * N * 2;
+  const double *gs = PRISMS ? nullptr : a.s_bounds + (size_t)b * O * N * 2, *gl = PRISMS ? nullptr : a.l_bounds + (size_t)b * O * N * 2;
+  const MemoryBounds memory{gs, gl, N};
   const int n2 = O * N;  // (lower, upper) pairs
+  // idx / N for idx < O * N <= 64 * 512 as a multiplication: exact while idx * N < 2^32 (an integer division costs ~25
+  // instructions, and there is one per pair)
+  const unsigned n_magic = 0xFFFFFFFFu / (unsigned)N + 1u;
+  auto obstacle_of = [&](int idx) { return (int)__umulhi((unsigned)idx, n_magic); };
   const double2 *gs2 = reinterpret_cast<const double2 *>(gs);
   double2 *sk2 = reinterpret_cast<double2 *>(slopes);
   double cur_lo[4], cur_hi[4], prv_lo[4], prv_hi[4];
+  double2 below = make_double2(0.0, 0.0);   // PRISMS: the pair in front of lane 0's (the previous block's last)
   auto load_pairs = [&](int base) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int i = base + u * 64 + lane, ic = i < n2 ? i : n2 - 1;
-      const double2 c2 = gs2[ic], p2 = gs2[ic > 0 ? ic - 1 : 0];
-      cur_lo[u] = c2.x; cur_hi[u] = c2.y; prv_lo[u] = p2.x; prv_hi[u] = p2.y;
+      if constexpr (PRISMS) {   // every pair is evaluated once; its predecessor comes from the lane below
+        const int j = obstacle_of(ic);
+        const double2 c2 = prism.s2(j, ic - j * N);
+        double2 p2 = make_double2(from_lane_below(c2.x), from_lane_below(c2.y));
+        if (lane == 0) p2 = below;
+        below = make_double2(readlane_f64(c2.x, 63), readlane_f64(c2.y, 63));
+        cur_lo[u] = c2.x; cur_hi[u] = c2.y; prv_lo[u] = p2.x; prv_hi[u] = p2.y;
+      } else {
+        const double2 c2 = gs2[ic], p2 = gs2[ic > 0 ? ic - 1 : 0];
+        cur_lo[u] = c2.x; cur_hi[u] = c2.y; prv_lo[u] = p2.x; prv_hi[u] = p2.y;
+      }
     }
   };
   auto store_slopes = [&](int base) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int i = base + u * 64 + lane;
-      if (i < n2 && i % N > 0)  // (b(i) - b(i-1)) / delta: the expression of SlopesOnTheFly
+      if (i < n2 && i - obstacle_of(i) * N > 0)  // (b(i) - b(i-1)) / delta: the expression of SlopesOnTheFly
         sk2[i] = make_double2((cur_lo[u] - prv_lo[u]) / a.delta, (cur_hi[u] - prv_hi[u]) / a.delta);
     }
   };
@@ -280,19 +337,26 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   const bool wide = staged && find_breaks_wave(a, lane, slopes, cap_o, hits, my_nb);
   load_refs(0);
   if (wide) {
-    build_segments_wave(a, lane, gs, gl, slopes, all, cap_o, ocount, hits, slot_of, my_nb, [&]() {
+    auto after_slopes = [&]() {
       __syncthreads();                                     // every lane has its slopes: the table may be overwritten
       store_refs(0);
-    });
+    };
+    if constexpr (PRISMS) build_segments_wave(a, lane, prism, slopes, all, cap_o, ocount, hits, slot_of, my_nb, after_slopes);
+    else build_segments_wave(a, lane, memory, slopes, all, cap_o, ocount, hits, slot_of, my_nb, after_slopes);
     refs_stored = true;
   } else {
     __syncthreads();
     if (lane < O) {  // the serial statement: lane o owns obstacle o
-      const BoundsView sb{gs + (size_t)lane * N * 2}, lb{gl + (size_t)lane * N * 2};
-      if (staged)
-        ocount[lane] = extract_segments_core(a.variant, N, a.delta, sb, lb, SlopeTable{slopes + (size_t)lane * N * 2}, all + lane * cap_o, cap_o);
-      else
-        ocount[lane] = extract_segments_core(a.variant, N, a.delta, sb, lb, SlopesOnTheFly{sb, a.delta}, all + lane * cap_o, cap_o);
+      if constexpr (PRISMS) {   // (always staged: the host takes the two-kernel path when the slope table does not fit)
+        ocount[lane] = extract_segments_core(a.variant, N, a.delta, PrismViewS{&prism, lane}, PrismViewL{&prism, lane},
+                                             SlopeTable{slopes + (size_t)lane * N * 2}, all + lane * cap_o, cap_o);
+      } else {
+        const BoundsView sb{gs + (size_t)lane * N * 2}, lb{gl + (size_t)lane * N * 2};
+        if (staged)
+          ocount[lane] = extract_segments_core(a.variant, N, a.delta, sb, lb, SlopeTable{slopes + (size_t)lane * N * 2}, all + lane * cap_o, cap_o);
+        else
+          ocount[lane] = extract_segments_core(a.variant, N, a.delta, sb, lb, SlopesOnTheFly{sb, a.delta}, all + lane * cap_o, cap_o);
+      }
     }
   }
 #endif

@@ -105,6 +105,7 @@ EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "bt
            "btrapz_sample_device", "btrapz_solve_batch_host", "btrapz_solve_ragged_device",
            "btrapz_corridor_batch_device", "btrapz_sample_ragged_device", "btrapz_solve_warm_device",
            "btrapz_eval_states_device", "btrapz_find_traj_mem", "btrapz_prism_bounds_device",
+           "btrapz_prism_corridor_batch_device",
            "btrapz_find_traj_last_iterations", "btrapz_argmin_pairs_device", "btrapz_options_init",
            "btrapz_rescue_violations_device", "btrapz_find_traj_last_status", "btrapz_debug_mqm_tables",
            "btrapz_last_solve_form")
@@ -192,6 +193,8 @@ def lib():
                                                C.c_int, dp, ip, dp, dp, dp, dp, dp, ip, ip, vp]
         l.btrapz_eval_states_device.argtypes = [vp, C.c_int, C.c_int, ip, dp, dp, C.c_int, dp, dp, vp]
         l.btrapz_prism_bounds_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(CRoad), dp, C.c_int, dp, dp, ip, vp]
+        l.btrapz_prism_corridor_batch_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(CRoad), dp, C.c_int,
+                                                         C.c_double, dp, dp, dp, dp, C.c_int, dp, ip, dp, dp, ip, vp]
         _lib = l
     return _lib
 
@@ -307,6 +310,15 @@ class Context:
         self._check(lib().btrapz_prism_bounds_device(self._h, B, P, N, C.byref(road), ptr(prisms), O, ptr(s_bounds),
                                                      ptr(l_bounds), ptr(n_strips), C.c_void_p(stream or 0)),
                     "btrapz_prism_bounds_device")
+
+    def prism_corridor_batch_device(self, variant, B, P, N, road, prisms, O, delta, ds_bounds, dl_bounds_knots, s_ref, l_ref,
+                                    seg_stride, seg, seg_count, ref_end, dl_bounds, n_strips=None, stream=None):
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self._check(lib().btrapz_prism_corridor_batch_device(self._h, int(variant), B, P, N, C.byref(road), ptr(prisms), O,
+                                                             float(delta), ptr(ds_bounds), ptr(dl_bounds_knots), ptr(s_ref),
+                                                             ptr(l_ref), seg_stride, ptr(seg), ptr(seg_count), ptr(ref_end),
+                                                             ptr(dl_bounds), ptr(n_strips), C.c_void_p(stream or 0)),
+                    "btrapz_prism_corridor_batch_device")
 
     def sample_ragged_device(self, B, seg_stride, seg_count, delta, seg, init, ctrl, sel, max_points, out, npoints,
                              stream=None):

@@ -138,6 +138,29 @@ class BatchSolver:
         rec["_inputs"] = ins
         return rec
 
+    def prism_corridor_batch(self, variant, prisms, N, O, delta, ds_bounds, dl_bounds, s_ref, l_ref, init, seg_stride=16,
+                             road=None):
+        """prism_bounds + corridor_batch_tensors in one launch (btrapz_prism_corridor_batch_device): the strips are
+        evaluated inside the corridor kernel instead of written to memory.  Same record, plus rec["n_strips"]."""
+        from .native import CRoad
+        d = self.device
+        c = lambda t: t.to(d, dtype=torch.float64).contiguous()
+        prisms = c(prisms)
+        B, P = prisms.shape[0], prisms.shape[1]
+        ins = [prisms, c(ds_bounds), c(dl_bounds), c(s_ref), c(l_ref)]
+        rec = dict(B=B, seg_stride=seg_stride,
+                   seg=torch.zeros((L.NUM_SEG_FIELDS, B, seg_stride), dtype=torch.float64, device=d),
+                   seg_count=torch.zeros(B, dtype=torch.int32, device=d), init=c(init),
+                   ref_end=torch.zeros((B, 2), dtype=torch.float64, device=d),
+                   dl_bounds=torch.zeros((B, 10), dtype=torch.float64, device=d),
+                   n_strips=torch.empty(B, dtype=torch.int32, device=d))
+        stream = torch.cuda.current_stream(d).cuda_stream
+        self.ctx.prism_corridor_batch_device(variant, B, P, N, road or CRoad.reference(), prisms, O, delta, *ins[1:],
+                                             seg_stride, rec["seg"], rec["seg_count"], rec["ref_end"], rec["dl_bounds"],
+                                             rec["n_strips"], stream=stream)
+        rec["_inputs"] = ins
+        return rec
+
     def solve_ragged(self, rec, shared, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0):
         """Solve a ragged batch record (from corridor_batch); outputs stay on the device."""
         d = self.device

@@ -128,3 +128,43 @@ def test_prisms_to_arg_min_end_to_end():
             assert np.abs(ctrl[b, :12 * nseg] - xs).max() <= 1e-5 * np.abs(xs).max()
             checked += 1
     assert checked >= 3
+
+
+def _knot_inputs(B, N, seed):
+    rng = np.random.default_rng(seed)
+    tt = np.arange(N) * 0.1
+    s_ref = (rng.uniform(4.0, 7.0, (B, 1)) * tt[None, :]) + rng.uniform(0, 2, (B, 1))
+    l_ref = np.clip(1.2 + rng.uniform(0.02, 0.12, (B, 1)) * (np.arange(N)[None, :] - rng.integers(5, 30, (B, 1))), 1.2, 4.5)
+    init = np.zeros((B, 6)); init[:, 1] = 6.0; init[:, 3] = 1.2
+    dsb = np.tile(np.array([0.0, 20.0]), (B, N, 1)); dlb = np.tile(np.array([-3.0, 3.0]), (B, N, 1))
+    return s_ref, l_ref, init, dsb, dlb
+
+
+@pytest.mark.parametrize("variant,Pm,N,Omax,seg_stride", [(0, 4, 71, 9, 24), (1, 4, 71, 5, 24), (0, 2, 121, 5, 32), (0, 16, 71, 33, 24),
+                                                           (0, 3, 201, 7, 40), (0, 6, 31, 13, 16)])
+def test_fused_prism_corridor_stage_equals_the_two_launches_bit_for_bit(variant, Pm, N, Omax, seg_stride):
+    """btrapz_prism_corridor_batch_device (strips evaluated inside the corridor kernel) against
+    btrapz_prism_bounds_device + btrapz_corridor_batch_device: every field of the batch record, the segment counts, the
+    strip counts -- including scenes with more strips than O holds, scenes whose lists overflow the first pass, and
+    (O * N > 1536) the shapes the fused entry point routes through its own two launches."""
+    import torch
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    scenes = random_scenes(300, 11 + N + Pm, max_cars=Pm) + random_scenes(300, 12 + N, max_cars=min(Pm, 4), nice=True)
+    if Pm <= 4 and N == 71:
+        scenes += [sc["cars"][:Pm] for sc in G["scenes"]]
+    B = len(scenes)
+    pr = torch.from_numpy(pack(scenes, Pm))
+    s_ref, l_ref, init, dsb, dlb = _knot_inputs(B, N, 3)
+    t = torch.from_numpy
+    sb, lb, n = solver.prism_bounds(pr, N, Omax)
+    two = solver.corridor_batch_tensors(variant, N, 0.1, sb, lb, t(dsb), t(dlb), t(s_ref), t(l_ref), t(init), seg_stride=seg_stride)
+    one = solver.prism_corridor_batch(variant, pr, N, Omax, 0.1, t(dsb), t(dlb), t(s_ref), t(l_ref), t(init), seg_stride=seg_stride)
+    torch.cuda.synchronize()
+    assert torch.equal(one["n_strips"], n)
+    cnt = two["seg_count"].cpu().numpy()
+    assert torch.equal(one["seg_count"], two["seg_count"]), (cnt != one["seg_count"].cpu().numpy()).sum()
+    assert Omax > 13 or (cnt > 0).mean() > 0.3      # (33 strips leave 4 list slots per strip: every scene overflows, in both)
+    a, b = one["seg"].cpu().numpy(), two["seg"].cpu().numpy()
+    assert a.tobytes() == b.tobytes(), np.argwhere(~((a == b) | (np.isnan(a) & np.isnan(b))))[:5]
+    assert torch.equal(one["ref_end"], two["ref_end"]) and torch.equal(one["dl_bounds"], two["dl_bounds"])

@@ -97,6 +97,24 @@ def main(argv=None):
         e0.record(); corridors(); e1.record(); out = solver.solve_ragged(rec, sh); e2.record()
         torch.cuda.synchronize()
         tc.append(e0.elapsed_time(e1)); ts.append(e1.elapsed_time(e2))
+    fused_ms = None
+    if a.prisms:   # the same stage in one launch: strips evaluated inside the corridor kernel (btrapz_prism_corridor_batch_device)
+        from spectral_amd.native import CRoad
+        rec2 = {k: (torch.zeros_like(v) if torch.is_tensor(v) else v) for k, v in rec.items()}
+        ns2 = torch.empty(B, dtype=torch.int32, device=d)
+
+        def fused():
+            solver.ctx.prism_corridor_batch_device(a.variant, B, 2, kb.N, CRoad.reference(), d_pr, kb.num_obs, kb.delta, *ins[2:], st,
+                                                   rec2["seg"], rec2["seg_count"], rec2["ref_end"], rec2["dl_bounds"], ns2, stream=stream)
+        for _ in range(2):
+            fused()
+        torch.cuda.synchronize()
+        tf = []
+        for _ in range(a.reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fused(); e1.record(); torch.cuda.synchronize(); tf.append(e0.elapsed_time(e1))
+        fused_ms = float(np.median(tf))
+        same = bool(torch.equal(rec2["seg_count"], rec["seg_count"]) and rec2["seg"].cpu().numpy().tobytes() == rec["seg"].cpu().numpy().tobytes())
     cnt = rec["seg_count"].cpu().numpy(); status = out["status"].cpu().numpy()
     mean_cnt = float(cnt[cnt > 0].mean()) if (cnt > 0).any() else 0.0
     in_bytes = sum(t.numel() * 8 for t in ins)
@@ -110,6 +128,9 @@ def main(argv=None):
                                    "unit": "GB/s", "frac": pb / (prism_ms * 1e-3) / 1e9 / 8000.0}
         extra["prism_ms"] = prism_ms
         extra["end_to_end_scenes_per_s"] = B / (prism_ms + float(np.median(tc)) + float(np.median(ts))) * 1e3
+        extra["fused_prism_corridor_ms"] = fused_ms
+        extra["fused_equals_two_launches"] = same
+        extra["end_to_end_scenes_per_s_fused"] = B / (fused_ms + float(np.median(ts))) * 1e3
     result = {**extra,
         "workload": "%s (N = %d knots, %d obstacles), %s constraints" %
                     (label, kb.N, kb.num_obs, "trapezoid" if a.variant == 0 else "cuboid"),
