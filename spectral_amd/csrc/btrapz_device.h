@@ -98,8 +98,12 @@ struct CorridorArgs {
 
 __global__ void corridor_batch_kernel(const CorridorArgs a, int staged);
 __global__ void corridor_batch_short_kernel(const CorridorArgs a, int staged);   // N <= 128
+__global__ void corridor_first_kernel(const CorridorArgs a, int staged);         // first pass of a two-pass launch: no serial statement
+__global__ void corridor_first_short_kernel(const CorridorArgs a, int staged);
 __global__ void prism_corridor_batch_kernel(const CorridorArgs a, int staged);   // prisms -> strips -> corridors in one launch
 __global__ void prism_corridor_batch_short_kernel(const CorridorArgs a, int staged);
+__global__ void prism_corridor_first_kernel(const CorridorArgs a, int staged);
+__global__ void prism_corridor_first_short_kernel(const CorridorArgs a, int staged);
 // fixed_S = 0: bucket by segment count (ragged batches); > 0: uniform batch of fixed_S segments, bucket by hint class
 __global__ void bucket_hist_kernel(int B, int seg_stride, const int *seg_count, int *meta, int fixed_S);
 __global__ void bucket_prefix_kernel(int *meta, int fixed_S);

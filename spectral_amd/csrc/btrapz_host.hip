@@ -572,7 +572,14 @@ static int launch_corridor_stage(btrapz_ctx *c, CorridorArgs a, bool prisms, hip
   HIPCHK(c, hipMemsetAsync(c->d_retry, 0, sizeof(int), stream));
   a.retry_count = c->d_retry; a.retry_list = c->d_retry + 1;
   const int cap_o_big = 160 / num_obs, cap_sel_big = 64;        // MAX_ALL / O, MAX_SEL of corridor_kernels.hip
-  int cap_o_small = (N - 1) / 10 + 9, cap_sel_small = 2 * seg_stride < 16 ? 16 : 2 * seg_stride;
+  // first-pass lists: one slot per second of horizon (CorridorSplit's pieces) plus a few for the slope breaks.  Every
+  // slot is 104 bytes of LDS per obstacle and LDS bounds the wavefronts per CU; a candidate with more breaks only takes
+  // the retry pass.  Measured on 65 536 candidates (+9 was round 2's margin): N = 71, 3 obstacles 0.305 -> 0.272 ms with
+  // +3 and five wavefronts per SIMD; N = 201, 2 obstacles 0.686 -> 0.637 with +5 (0.663 with +3: more retries).
+#ifndef CABL_CAPO_EXTRA
+#define CABL_CAPO_EXTRA (N <= 128 ? 3 : 5)
+#endif
+  int cap_o_small = (N - 1) / 10 + CABL_CAPO_EXTRA, cap_sel_small = 2 * seg_stride < 16 ? 16 : 2 * seg_stride;
   if (cap_o_small > cap_o_big) cap_o_small = cap_o_big;
   if (cap_sel_small > cap_sel_big) cap_sel_small = cap_sel_big;
   const size_t slope_bytes = sizeof(double) * 2 * (size_t)N * num_obs;
@@ -591,10 +598,14 @@ static int launch_corridor_stage(btrapz_ctx *c, CorridorArgs a, bool prisms, hip
   const bool two_pass = cap_o_small < cap_o_big || cap_sel_small < cap_sel_big;
   a.pass = 0; a.cap_o = cap_o_small; a.cap_sel = cap_sel_small;
   if (!two_pass) { a.retry_list = nullptr; a.retry_count = nullptr; }
-  // (horizons of at most 128 knots: the instantiation that holds half the prefetch registers)
+  // (horizons of at most 128 knots: the instantiation that holds half the prefetch registers; the first pass of two
+  //  runs without the serial statement of the extraction -- a candidate that needs it takes the retry pass)
   auto kernel = prisms ? (N <= 128 ? prism_corridor_batch_short_kernel : prism_corridor_batch_kernel)
                        : (N <= 128 ? corridor_batch_short_kernel : corridor_batch_kernel);
-  hipLaunchKernelGGL(kernel, dim3(B), dim3(64), lds_bytes(a.cap_o, a.cap_sel), stream, a, staged);
+  auto first = !(two_pass && staged) ? kernel
+               : prisms ? (N <= 128 ? prism_corridor_first_short_kernel : prism_corridor_first_kernel)
+                        : (N <= 128 ? corridor_first_short_kernel : corridor_first_kernel);
+  hipLaunchKernelGGL(first, dim3(B), dim3(64), lds_bytes(a.cap_o, a.cap_sel), stream, a, staged);
   HIPCHK(c, hipGetLastError());
   if (two_pass) {
     a.pass = 1; a.cap_o = cap_o_big; a.cap_sel = cap_sel_big;

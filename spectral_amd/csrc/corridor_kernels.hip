@@ -34,40 +34,53 @@ enum { MAX_ALL = 160, MAX_SEL = 64 };   // capacities of the retry pass (see btr
 // RB: blocks of 64 knots of the reference and the ds bounds held in registers across the extraction (2 serve N <= 128).
 // PRISMS: the per-knot bounds are not read but evaluated from the scene's obstacle prisms (prism_core.h), whose tables
 // sit behind pick[] -- the fused form of prism_bounds_kernel + this kernel, same segments bit for bit.
-template <int RB, bool PRISMS>
+// SERIAL: the instantiation carries the serial statement of the extraction for the shapes the wave-wide code does not
+// take.  The first pass of a two-pass launch runs without it (a candidate that needs it goes to the retry list): the
+// statement is a quarter of the kernel's code and its registers are what the hot path then does not spill.
+template <int RB, bool PRISMS, bool SERIAL>
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw);
 
+// Registers per wavefront against wavefronts per SIMD (round 3, with the segment lists sized by the host to match:
+// btrapz_host.hip, launch_corridor_stage): the kernel issues ~1 900 vector and ~1 400 scalar instructions per candidate
+// and keeps the vector unit 68 % busy at four wavefronts per SIMD (profiles/r03_corridor_pmc_before.json) -- it runs on issue
+// slots and dependent latency, so a fifth wavefront pays (0.305 -> 0.272 ms at N = 71, 65 536 candidates) although the
+// 102 registers it leaves spill a little more; a sixth does not (0.271), eight cost (0.290).  The instantiation for
+// long horizons holds twice the prefetch registers and is fastest at four (N = 201: 0.64 / 0.64 / 0.70 / 0.78 ms at
+// 4 / 5 / 6 / 8).
 #ifndef CABL_WAVES
 #define CABL_WAVES 4
 #endif
-template <int RB, bool PRISMS = false>
+#ifndef CABL_WAVES_SHORT
+#define CABL_WAVES_SHORT 5
+#endif
+template <int RB, bool PRISMS, bool SERIAL>
 __device__ __forceinline__ void corridor_batch_body(const CorridorArgs &a, int staged) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  if (a.pass == 0) {
-    corridor_candidate<RB, PRISMS>(a, staged, (int)blockIdx.x, lds_raw);
+  if (!SERIAL || a.pass == 0) {
+    corridor_candidate<RB, PRISMS, SERIAL>(a, staged, (int)blockIdx.x, lds_raw);
   } else {  // retry pass: the candidates the first pass could not hold
     const int n = *a.retry_count;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
       // (the candidate's number is the same in every lane: say so, or every address derived from it costs vector registers)
-      corridor_candidate<RB, PRISMS>(a, staged, __builtin_amdgcn_readfirstlane(a.retry_list[i]), lds_raw);
+      corridor_candidate<RB, PRISMS, SERIAL>(a, staged, __builtin_amdgcn_readfirstlane(a.retry_list[i]), lds_raw);
       __syncthreads();
     }
   }
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 8))) void corridor_batch_kernel(const CorridorArgs a, int staged) {
-  corridor_batch_body<4>(a, staged);
-}
-// horizons of at most 128 knots (the bundled scenes have 71-121): half the prefetch registers
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 8))) void corridor_batch_short_kernel(const CorridorArgs a, int staged) {
-  corridor_batch_body<2>(a, staged);
-}
-// prisms -> strips -> corridors in one launch (btrapz_prism_corridor_batch_device)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 8))) void prism_corridor_batch_kernel(const CorridorArgs a, int staged) {
-  corridor_batch_body<4, true>(a, staged);
-}
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CABL_WAVES, 8))) void prism_corridor_batch_short_kernel(const CorridorArgs a, int staged) {
-  corridor_batch_body<2, true>(a, staged);
-}
+#define CORRIDOR_KERNEL(name, waves, RB, PRISMS, SERIAL)                                                                   \
+  __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves, 8))) void name(const CorridorArgs a, int staged) { \
+    corridor_batch_body<RB, PRISMS, SERIAL>(a, staged);                                                                       \
+  }
+// (short: horizons of at most 128 knots -- the bundled scenes have 71-121 --, half the prefetch registers; prism_: the
+//  fused form, btrapz_prism_corridor_batch_device; first_: first pass of a two-pass launch, without the serial statement)
+CORRIDOR_KERNEL(corridor_batch_kernel, CABL_WAVES, 4, false, true)
+CORRIDOR_KERNEL(corridor_batch_short_kernel, CABL_WAVES_SHORT, 2, false, true)
+CORRIDOR_KERNEL(corridor_first_kernel, CABL_WAVES, 4, false, false)
+CORRIDOR_KERNEL(corridor_first_short_kernel, CABL_WAVES_SHORT, 2, false, false)
+CORRIDOR_KERNEL(prism_corridor_batch_kernel, CABL_WAVES, 4, true, true)
+CORRIDOR_KERNEL(prism_corridor_batch_short_kernel, CABL_WAVES_SHORT, 2, true, true)
+CORRIDOR_KERNEL(prism_corridor_first_kernel, CABL_WAVES, 4, true, false)
+CORRIDOR_KERNEL(prism_corridor_first_short_kernel, CABL_WAVES_SHORT, 2, true, false)
 
 // Where the per-knot bounds of obstacle corridor o come from: memory ([num_obs][N][2] of the candidate) or the prisms.
 struct MemoryBounds {
@@ -222,7 +235,7 @@ __device__ __forceinline__ double from_lane_below(double v) {   // lane l gets l
                           __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false));
 }
 
-template <int RB, bool PRISMS>
+template <int RB, bool PRISMS, bool SERIAL>
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw) {
   const int lane = threadIdx.x;
   const int N = a.N, O = a.num_obs;
@@ -344,6 +357,9 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     if constexpr (PRISMS) build_segments_wave(a, lane, prism, slopes, all, cap_o, ocount, hits, slot_of, my_nb, after_slopes);
     else build_segments_wave(a, lane, memory, slopes, all, cap_o, ocount, hits, slot_of, my_nb, after_slopes);
     refs_stored = true;
+  } else if constexpr (!SERIAL) {   // not a shape for the wave-wide code: the retry pass has the serial statement
+    if (lane == 0) a.retry_list[atomicAdd(a.retry_count, 1)] = b;
+    return;
   } else {
     __syncthreads();
     if (lane < O) {  // the serial statement: lane o owns obstacle o

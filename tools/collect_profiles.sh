@@ -82,6 +82,17 @@ if [ "$QUICK" != "quick" ]; then
     python3 "$ROOT/tools/find_traj_loop.py"
   unset BTRAPZ_SPLIT
   step split_bench "$OUT/split_bench.json" python3 "$ROOT/tools/split_bench.py"
+  step cap_bench "$OUT/cap_bench.json" python3 "$ROOT/tools/cap_bench.py"
+  # counters of the corridor kernel (tools/summarize_corridor_pmc.py -> profiles/<tag>_corridor_pmc.json)
+  i=0
+  for group in \
+    "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+    "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
+    "SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64" ; do
+    i=$((i + 1))
+    # shellcheck disable=SC2086
+    step "corridor_pmc$i" "$OUT/corridor_pmc$i.json" rocprofv3 --pmc $group --output-format csv -d "$OUT/corridor_pmc$i" -- python3 "$ROOT/tools/pipeline_bench.py" --reps 2
+  done
   step mpc_2rank "$OUT/mpc_warm_2rank_gloo.json" python3 "$ROOT/tools/mpc_bench.py" --gpus 2 --backend gloo --share-device
 fi
 # keep only the CSVs (the merge-back limit is 64 MiB)
