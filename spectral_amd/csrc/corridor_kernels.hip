@@ -40,18 +40,18 @@ enum { MAX_ALL = 160, MAX_SEL = 64 };   // capacities of the retry pass (see btr
 template <int RB, bool PRISMS, bool SERIAL>
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw);
 
-// Registers per wavefront against wavefronts per SIMD (round 3, with the segment lists sized by the host to match:
-// btrapz_host.hip, launch_corridor_stage): the kernel issues ~1 900 vector and ~1 400 scalar instructions per candidate
-// and keeps the vector unit 68 % busy at four wavefronts per SIMD (profiles/r03_corridor_pmc_before.json) -- it runs on issue
-// slots and dependent latency, so a fifth wavefront pays (0.305 -> 0.272 ms at N = 71, 65 536 candidates) although the
-// 102 registers it leaves spill a little more; a sixth does not (0.271), eight cost (0.290).  The instantiation for
-// long horizons holds twice the prefetch registers and is fastest at four (N = 201: 0.64 / 0.64 / 0.70 / 0.78 ms at
-// 4 / 5 / 6 / 8).
+// Registers against wavefronts per SIMD.  The kernel issues ~1 900 vector and ~1 400 scalar instructions per candidate
+// and kept the vector unit 68 % busy at four wavefronts per SIMD (profiles/r03_corridor_pmc_before.json): it runs on
+// issue slots and dependent latency, so more resident wavefronts pay as long as they do not spill.  The first-pass
+// instantiations (no serial statement) need 52-60 registers: LDS alone bounds them, and the host sizes the lists for
+// that (btrapz_host.hip, launch_corridor_stage).  The instantiations with the serial statement -- retry pass, and the
+// only pass for shapes without a staged slope table -- are held to four wavefronts per SIMD (128 registers; measured
+// with the serial statement in the hot path: five 0.272 ms against 0.305 at N = 71, but 132-176 B of scratch).
 #ifndef CABL_WAVES
 #define CABL_WAVES 4
 #endif
 #ifndef CABL_WAVES_SHORT
-#define CABL_WAVES_SHORT 5
+#define CABL_WAVES_SHORT 4
 #endif
 template <int RB, bool PRISMS, bool SERIAL>
 __device__ __forceinline__ void corridor_batch_body(const CorridorArgs &a, int staged) {

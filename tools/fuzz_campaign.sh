@@ -1,0 +1,20 @@
+#!/bin/bash
+# The fuzz drivers of tests/fuzz against the oracle, at scale, on the GPU box (through gpurun from the repo root):
+#   gpurun --timeout 1200 -- 'bash tools/fuzz_campaign.sh r03'
+# Logs under gpurun_out/fuzz_<tag>/; the last lines of every log are the tallies DESIGN.md section 5 quotes.
+TAG=${1:-r03}
+CALLS=${2:-1500}
+OUT=gpurun_out/fuzz_$TAG
+mkdir -p "$OUT"
+# find_traj (in-memory) against the oracle: plain solve, then the product's default (rescue pass on) with the OSQP
+# port's decision tallied on every 10th call; four processes at a time (at most 6 may hold the GPU)
+for e in 0 1; do
+  for s in 1 2 3 4; do
+    timeout -k 10 900 python tests/fuzz/find_traj_vs_oracle.py $((300 + 10 * e + s)) "$CALLS" $e - $((e * 10)) > "$OUT/find_traj_e${e}_s$s.log" 2>&1 &
+  done
+  wait
+  echo "find_traj elastic=$e done"; tail -n 2 "$OUT"/find_traj_e${e}_s*.log
+done
+timeout -k 10 600 python tests/fuzz/prisms_vs_restatement.py 5 3000 > "$OUT/prisms.log" 2>&1; tail -n 2 "$OUT/prisms.log"
+timeout -k 10 900 python tests/fuzz/warm_start_vs_oracle.py 4096 > "$OUT/warm_start.log" 2>&1; tail -n 3 "$OUT/warm_start.log"
+timeout -k 10 1200 python tests/fuzz/bench_batches_vs_oracle.py 65536 16 > "$OUT/bench_batches.log" 2>&1; tail -n 6 "$OUT/bench_batches.log"
