@@ -1697,7 +1697,8 @@ __global__ void sample_kernel(int B, int seg_stride, const int *seg_count, doubl
 // launches.  The inputs (a.seg, a.init, ..., mqm) and out may be host memory mapped into the device -- inputs are read
 // once, results written once -- so the call needs no copy either; what the kernel reads back (control points, per-axis
 // records) lives in device memory (a.ctrl, a.axis_*).  out: [0] cost, [1] status and iterations (two ints), [2]
-// sample count (int), [3 .. 3 + 12 S) control points, then traj [6][max_points].
+// sample count (int) and the completion word (int: set to 1, system scope, when everything else is in place),
+// [3 .. 3 + 12 S) control points, then traj [6][max_points].
 template <bool WARM, bool SPLIT = false>
 __device__ __forceinline__ void single_candidate_body(const KernelArgs &a, const double *__restrict__ mqm, double delta,
                                                       int max_points, double *out) {
@@ -1725,6 +1726,11 @@ __device__ __forceinline__ void single_candidate_body(const KernelArgs &a, const
     ri[0] = st; ri[1] = a.axis_iters[0] > a.axis_iters[1] ? a.axis_iters[0] : a.axis_iters[1];
     reinterpret_cast<int *>(res + 2)[0] = np;
   }
+  // "results complete", for a host that polls the mapped block instead of waiting for the end-of-kernel signal: every
+  // thread's result stores are released to the system before one thread sets the word
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<int *>(res + 2) + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ __launch_bounds__(128) void single_candidate_kernel(const KernelArgs a, const double *__restrict__ mqm,
                                                                double delta, int max_points, double *out) {

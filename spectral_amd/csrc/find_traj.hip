@@ -90,6 +90,23 @@ bool verbose() { const char *v = getenv("BTRAPZ_VERBOSE"); return v && *v && *v 
 // BTRAPZ_VERBOSE=2: where a call's time goes (host stages and the launch), on stderr
 bool timing() { const char *v = getenv("BTRAPZ_VERBOSE"); return v && *v == '2'; }
 double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// The single launch writes its results through the mapping and sets a completion word last (system-scope release):
+// polling that word sees the results a few microseconds before hipStreamSynchronize returns (end-of-kernel cache
+// release, completion signal, the runtime's wake-up).  The poll gives up after 2 ms -- a solve of 256 segments and 200
+// iterations takes longer, a faulted kernel never answers -- and the stream wait takes over.  BTRAPZ_SPIN=0: wait only.
+bool wait_for_results(const double *h_out, hipStream_t stream) {
+  static const bool spin = [] { const char *v = getenv("BTRAPZ_SPIN"); return !(v && *v == '0'); }();
+  if (spin) {
+    const volatile int *done = reinterpret_cast<const volatile int *>(h_out + 2) + 1;
+    const double t0 = now_us();
+    for (int i = 0; !*done; ++i) {
+      __builtin_ia32_pause();
+      if ((i & 255) == 255 && now_us() - t0 > 2000.0) break;
+    }
+    if (*done) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return true; }
+  }
+  return hipStreamSynchronize(stream) == hipSuccess;
+}
 
 // BTRAPZ_ELASTIC=0 turns the rescue pass of find_traj off (strict mode: a QP without a solution is a failure);
 // BTRAPZ_ELASTIC_TOL overrides btrapz_options.elastic_tol (largest accepted row violation / |g|, default 0.01).
@@ -270,6 +287,7 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   std::copy(h_ref_end.begin(), h_ref_end.end(), p_init + 6);
   std::copy(h_dl.begin(), h_dl.end(), p_init + 8);
   btrapz_mqm_table_host(&sh, p_init + 18);
+  reinterpret_cast<volatile int *>(h_out + 2)[1] = 0;   // the kernel's completion word (wait_for_results)
   int h_status[2] = {0, 0}, h_np = 0;
   double h_cost = 0.0;
   const ElasticEnv el = elastic_env();
@@ -288,7 +306,7 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
     h_status[0] = BTRAPZ_MAX_ITER_REACHED;   // (nothing solved yet: the block below does it, without the rescue rows)
   } else
   if (btrapz_launch_single(ctx, &sh, &opt1, S, d_in, d_out, max_points, warm_on ? 1 : 0, me->stream) != BTRAPZ_OK ||
-      hipStreamSynchronize(me->stream) != hipSuccess) {
+      !wait_for_results(h_out, me->stream)) {
     fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
     btrapz_single_forget(ctx);   // (whatever the failed launch left is no start for the next call)
     return FAIL;

@@ -359,25 +359,42 @@ def find_traj_last_status():
     return int(st), np.array(v[:])
 
 
+class TrajCall:
+    """btrapz_find_traj_mem() on candidate b of a spectral_amd.knots.KnotBatch, prepared once and callable many times
+    (a replanning loop, a latency measurement): the input struct and the output buffers are built here, a call is the
+    C function and two slices.  The arrays of `kb` are referenced, not copied, when they are contiguous float64."""
+
+    def __init__(self, variant, params, kb, b=0, cap=None):
+        self.variant = int(variant)
+        self.cp = params if isinstance(params, CParams) else CParams(*params)
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self._arrs = [f(kb.s_bounds[b]), f(kb.l_bounds[b]), f(kb.ds_bounds[b]), f(kb.dl_bounds[b]), f(kb.s_ref[b]), f(kb.l_ref[b])]
+        h = kb.header
+        self.ti = CTrajInput(int(kb.N), int(kb.num_obs), float(kb.delta), (C.c_double * 3)(*kb.init[b, :3]),
+                             (C.c_double * 3)(*kb.init[b, 3:]), float(h["ds_ref"]), float(h["dl_ref"]),
+                             (C.c_double * 2)(*h["dds"]), (C.c_double * 2)(*h["ddds"]), (C.c_double * 2)(*h["ddl"]),
+                             (C.c_double * 2)(*h["dddl"]), *[a.ctypes.data for a in self._arrs])
+        self.cap = int(cap if cap is not None else 4 * kb.N + 16)
+        self.traj = np.zeros((7, self.cap)); self.ctrl = np.zeros(12 * 256)
+        self.n, self.S = C.c_int(0), C.c_int(0)
+        self._fn = lib().btrapz_find_traj_mem
+        self._args = (self.variant, C.byref(self.ti), C.byref(self.cp), self.cap, self.traj.ctypes.data, C.byref(self.n),
+                      self.ctrl.ctypes.data, C.byref(self.S))
+
+    def __call__(self, copy=True):
+        """(cost, traj [7][n] rows t s l ds dl dds ddl, ctrl [12 S]); cost == 1e11 on failure (traj, ctrl None).
+        copy=False returns views of the call's own buffers (overwritten by the next call)."""
+        cost = self._fn(*self._args)
+        if cost == 100000000000.0:
+            return cost, None, None
+        traj, ctrl = self.traj[:, :min(self.n.value, self.cap)], self.ctrl[:12 * self.S.value]
+        return (cost, traj.copy(), ctrl.copy()) if copy else (cost, traj, ctrl)
+
+
 def find_traj_mem(variant, params, kb, b=0, cap=None):
     """btrapz_find_traj_mem(): find_traj on candidate b of a spectral_amd.knots.KnotBatch (arrays in, arrays out).
     Returns (cost, traj [7][n] rows t s l ds dl dds ddl, ctrl [12 S]); cost == 1e11 on failure (traj, ctrl None)."""
-    cp = params if isinstance(params, CParams) else CParams(*params)
-    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
-    arrs = [f(kb.s_bounds[b]), f(kb.l_bounds[b]), f(kb.ds_bounds[b]), f(kb.dl_bounds[b]), f(kb.s_ref[b]), f(kb.l_ref[b])]
-    h = kb.header
-    ti = CTrajInput(int(kb.N), int(kb.num_obs), float(kb.delta), (C.c_double * 3)(*kb.init[b, :3]),
-                    (C.c_double * 3)(*kb.init[b, 3:]), float(h["ds_ref"]), float(h["dl_ref"]),
-                    (C.c_double * 2)(*h["dds"]), (C.c_double * 2)(*h["ddds"]), (C.c_double * 2)(*h["ddl"]),
-                    (C.c_double * 2)(*h["dddl"]), *[a.ctypes.data for a in arrs])
-    cap = int(cap if cap is not None else 4 * kb.N + 16)
-    traj = np.zeros((7, cap)); ctrl = np.zeros(12 * 256)
-    n, S = C.c_int(0), C.c_int(0)
-    cost = lib().btrapz_find_traj_mem(int(variant), C.byref(ti), C.byref(cp), cap, traj.ctypes.data, C.byref(n),
-                                      ctrl.ctypes.data, C.byref(S))
-    if cost == 100000000000.0:
-        return cost, None, None
-    return cost, traj[:, :min(n.value, cap)].copy(), ctrl[:12 * S.value].copy()
+    return TrajCall(variant, params, kb, b, cap)()
 
 
 def corridor_from_file(variant, input_path, cap=256):

