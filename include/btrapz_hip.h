@@ -396,6 +396,12 @@ int btrapz_eval_states_device(btrapz_ctx *ctx, int B, int seg_stride, const int 
 /* Test hook: the batch-invariant M' pQp_d M table (solve_3d.cc:87-143) from the library's host builder (find_traj's
  * single launch) and from its device builder (the batched entry points): [2][4][21] doubles each, host pointers. */
 int btrapz_debug_mqm_tables(btrapz_ctx *ctx, const btrapz_shared *shared, double *host_table, double *device_table);
+/* Test / analysis hook: iterations [B][2] and status [B][2] (s axis, l axis) of the axis problems of the context's last
+ * batched solve of B candidates, into host arrays; synchronises the device. */
+int btrapz_debug_axis_records(btrapz_ctx *ctx, int B, int *iters, int *status);
+/* ... and the keys [2][B] (axis-major) the resume launch of the context's last capped solve of B candidates was bucketed
+ * by: 0 where the axis problem was not handed over. */
+int btrapz_debug_resume_keys(btrapz_ctx *ctx, int B, int *keys);
 
 /* Host-pointer convenience wrapper: H2D, solve, D2H, synchronous. */
 int btrapz_solve_batch_host(btrapz_ctx *ctx, const btrapz_shared *shared,

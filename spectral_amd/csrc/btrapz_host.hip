@@ -245,6 +245,25 @@ BTRAPZ_EXPORT int btrapz_debug_mqm_tables(btrapz_ctx *c, const btrapz_shared *sh
   return BTRAPZ_OK;
 }
 
+// Test / analysis hook: iterations and status of the 2 B axis problems of the context's last batched solve
+// ([b][axis], host arrays; synchronises the device).  tools/resume_model.py reads them.
+BTRAPZ_EXPORT int btrapz_debug_axis_records(btrapz_ctx *c, int B, int *iters, int *status) {
+  if (!c || B < 1 || (size_t)2 * B > c->axis_cap || !iters || !status) return BTRAPZ_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(iters, c->d_axis_iters, sizeof(int) * 2 * B, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(status, c->d_axis_status, sizeof(int) * 2 * B, hipMemcpyDeviceToHost));
+  return BTRAPZ_OK;
+}
+// ... and the keys [2][B] the last capped solve's resume launch was bucketed by (0: the axis problem was not handed over)
+BTRAPZ_EXPORT int btrapz_debug_resume_keys(btrapz_ctx *c, int B, int *keys) {
+  if (!c || B < 1 || !keys || c->susp_ints < 4 + 4 * (size_t)B) return BTRAPZ_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(keys, c->d_susp_ints + 4 + 2 * (size_t)B, sizeof(int) * 2 * B, hipMemcpyDeviceToHost));
+  return BTRAPZ_OK;
+}
+
 int btrapz_launch_single(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_options *opt, int S, const double *in,
                          double *out, int max_points, int warm, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;

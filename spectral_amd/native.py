@@ -108,6 +108,7 @@ EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "bt
            "btrapz_prism_corridor_batch_device",
            "btrapz_find_traj_last_iterations", "btrapz_argmin_pairs_device", "btrapz_options_init",
            "btrapz_rescue_violations_device", "btrapz_find_traj_last_status", "btrapz_debug_mqm_tables",
+           "btrapz_debug_axis_records", "btrapz_debug_resume_keys",
            "btrapz_last_solve_form")
 
 
@@ -283,6 +284,20 @@ class Context:
         with elastic != 0."""
         self._check(lib().btrapz_rescue_violations_device(self._h, int(B), C.c_void_p(viol.data_ptr()),
                                                           C.c_void_p(stream or 0)), "btrapz_rescue_violations_device")
+
+    def debug_axis_records(self, B):
+        """(iters [B, 2], status [B, 2]) of the axis problems of the last batched solve."""
+        it = np.zeros((B, 2), dtype=np.int32); st = np.zeros((B, 2), dtype=np.int32)
+        lib().btrapz_debug_axis_records.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self._check(lib().btrapz_debug_axis_records(self._h, B, it.ctypes.data, st.ctypes.data), "btrapz_debug_axis_records")
+        return it, st
+
+    def debug_resume_keys(self, B):
+        """keys [2, B] of the last capped solve's resume launch (0: not handed over)."""
+        k = np.zeros((2, B), dtype=np.int32)
+        lib().btrapz_debug_resume_keys.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._check(lib().btrapz_debug_resume_keys(self._h, B, k.ctypes.data), "btrapz_debug_resume_keys")
+        return k
 
     def debug_mqm_tables(self, shared):
         sh = CShared.from_shared(shared)
