@@ -131,6 +131,13 @@ def test_capped_first_launch_and_resume_launch_give_the_one_launch_results_bit_f
     ok = a["status"] > 0
     assert ok.any() and np.array_equal(a["ctrl"][ok], b["ctrl"][ok])
     assert (a["iters"] + 1 > cap + 4).any()          # (some candidates did go through the second launch)
+    # the per-axis records behind the candidates' (debug hooks): a candidate's count is its slower axis's, and only
+    # axis problems that were still iterating at the hand-over point carry a key of the resume lists
+    it_ax, st_ax = solver.ctx.debug_axis_records(B)
+    keys = solver.ctx.debug_resume_keys(B)
+    assert np.array_equal(it_ax.max(axis=1)[ok], b["iters"][ok]) and ((st_ax > 0).all(axis=1) == ok).all()
+    assert (keys >= 0).all() and (keys <= 64).all() and (keys > 0).sum() > 0
+    assert (it_ax.T[keys > 0] + 1 > cap).all()      # (not every long runner has one: the hand-over slots are bounded)
     # with the rescue pass behind it, too
     c = {k: v.cpu().numpy().copy() for k, v in solver.solve(db, sh, split=-1, cap_iter=cap, elastic=1).items()}
     d = {k: v.cpu().numpy().copy() for k, v in solver.solve(db, sh, split=-1, cap_iter=-1, elastic=1).items()}
