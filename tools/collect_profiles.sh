@@ -8,11 +8,11 @@
 # failed or empty run.
 set -u
 TAG=${1:-r02}
-QUICK=${2:-}                      # "quick": bench + trace + counters only
+QUICK=${2:-}                      # "quick": bench + trace + counters only; "rest": everything else (two calls fit gpurun's limit)
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
-rm -f "$OUT/failed.txt"
+[ "$QUICK" = "rest" ] || rm -f "$OUT/failed.txt"
 export TMPDIR=/tmp
 BENCH="$ROOT/bench.py"
 cd /tmp
@@ -27,6 +27,7 @@ step() {   # step <name> <stdout file> <command...>: run, keep stderr, record fa
 python3 -c "import sys; sys.path.insert(0, '$ROOT'); from spectral_amd import native; print(native.kernel_source_hash())" \
   > "$OUT/kernel_source_hash.txt" 2> "$OUT/hash.err" || echo "FAILED: kernel_source_hash" >> "$OUT/failed.txt"
 
+if [ "$QUICK" != "rest" ]; then
 step bench "$OUT/bench.json" python3 "$BENCH"
 
 step trace "$OUT/bench_under_rocprof.json" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
@@ -53,6 +54,7 @@ if /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/fetch_calib "$ROOT/tool
 else
   echo "FAILED: build of tools/fetch_calib.hip" >> "$OUT/failed.txt"
 fi
+fi   # not "rest"
 
 if [ "$QUICK" != "quick" ]; then
   # the other tools: BASELINE config 5 (receding horizon), knots -> control points, the other configs through bench.py
