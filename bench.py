@@ -175,6 +175,12 @@ def main():
     from spectral_amd.dist import global_argmin_with_winner, shard_bounds
     from spectral_amd.solver import BatchSolver
 
+    # This program's stdout carries ONE JSON line.  Libraries below write there too (gloo announces its connections on
+    # the C-level stdout, a profiler or the runtime may): descriptor 1 points at stderr from here on and the line goes
+    # to the descriptor saved now.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -427,11 +433,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(batch, shared, a.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        line_out.write(json.dumps(out) + "\n"); line_out.flush()     # the line is out before anything below can go wrong
+    if world > 1:
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:                 # (a rank that lost step with the others must not take the line with it)
+            sys.stderr.write("bench.py: rank %d: %r at shutdown\n" % (rank, e))
 
 
 if __name__ == "__main__":

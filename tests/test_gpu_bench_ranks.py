@@ -20,7 +20,8 @@ def run(*args):
                        capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout                      # rank 0 prints ONE JSON line
+    assert len(lines) == 1, p.stdout                      # rank 0 prints ONE JSON line ...
+    assert p.stdout.strip() == lines[0], p.stdout         # ... and nothing else reaches stdout (gloo's chatter goes to stderr)
     return json.loads(lines[0])
 
 
@@ -81,7 +82,7 @@ def run_mpc(*args):
                         "--check", "0", *args], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout
+    assert len(lines) == 1 and p.stdout.strip() == lines[0], p.stdout
     return json.loads(lines[0])
 
 

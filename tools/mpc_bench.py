@@ -95,10 +95,15 @@ def main(argv=None):
     if world_n > 1:
         torch.cuda.set_device(local_rank)
         if not dist.is_initialized():        # (bench.py calls this tool with its process group up)
-            if a.backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            else:
-                dist.init_process_group(a.backend)
+            sys.stdout.flush()
+            saved_fd = os.dup(1); os.dup2(2, 1)     # (gloo announces its connections on the C-level stdout)
+            try:
+                if a.backend == "nccl":
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                else:
+                    dist.init_process_group(a.backend)
+            finally:
+                os.dup2(saved_fd, 1); os.close(saved_fd)
             own_pg = True
     S, G_all, C = a.segments, a.agents, a.cand
     horizon_pieces = S + int(np.ceil(a.steps * a.dt)) + 2
@@ -218,9 +223,17 @@ def main(argv=None):
     }
     if world_n > 1:
         # after the last step: the ranks' figures side by side (gloo side group: python objects, not on the data path)
-        side = dist.new_group(backend="gloo")
-        allr = [None] * world_n
-        dist.all_gather_object(allr, result, group=side)
+        import datetime
+        # (gloo announces its connections on the C-level stdout: this program's stdout carries ONE JSON line, so the
+        #  descriptor points at stderr while the group is set up and used)
+        sys.stdout.flush()
+        saved_fd = os.dup(1); os.dup2(2, 1)
+        try:
+            side = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=180))   # (a rank that failed must not hang the others)
+            allr = [None] * world_n
+            dist.all_gather_object(allr, result, group=side)
+        finally:
+            os.dup2(saved_fd, 1); os.close(saved_fd)
         if rank == 0:
             result = dict(allr[0])
             result["achieved_hz"] = min(r["achieved_hz"] for r in allr)          # a fleet replans as fast as its slowest shard
@@ -232,7 +245,7 @@ def main(argv=None):
             result["solved_fraction_min"] = min(r["solved_fraction_min"] for r in allr)
             result["last_winners"] = [w for r in allr for w in r["last_winners"]]
             result["dumped_winners"] = sum(r["dumped_winners"] for r in allr)
-        dist.barrier()
+        dist.barrier(group=side)
         if own_pg:
             dist.destroy_process_group()
     if rank != 0:
