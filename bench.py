@@ -412,6 +412,17 @@ def main():
                 t1 = time.perf_counter(); cst, _, ctl = call1(); lat_f.append(time.perf_counter() - t1)
             out["p50_find_traj_mem_ms"] = float(np.percentile(np.array(lat_f[5:]) * 1e3, 50))
             out["find_traj_mem_segments"] = None if ctl is None else int(len(ctl) // 12)
+            # ... and exactly as the reference's harness calls it: corridor text file in, trajectory text file out
+            # (trp_wrapper.py:45-66 -> find_traj(Params*)); the files live in a temporary directory
+            import ctypes as _C, tempfile as _tf
+            with _tf.TemporaryDirectory() as tdir:
+                fin, fout = os.path.join(tdir, "corridor.txt"), os.path.join(tdir, "traj.txt")
+                _knots_mod = __import__("spectral_amd.knots", fromlist=["write_corridor_file"])
+                _knots_mod.write_corridor_file(fin, kb1)
+                lat_t = []
+                for i in range(max(30, a.latency_reps // 2)):
+                    t1 = time.perf_counter(); native.lib().btrapz_find_traj(a.variant, fin.encode(), fout.encode(), _C.byref(prm)); lat_t.append(time.perf_counter() - t1)
+                out["p50_find_traj_file_ms"] = float(np.percentile(np.array(lat_t[5:]) * 1e3, 50))
             # ... and the replanning loop it sits in: consecutive calls on nearly the same scene, each starting from
             # the state the previous call of this thread left on the device (BTRAPZ_WARM=1; opt-in
             # because the last digits of a result then depend on the call history)

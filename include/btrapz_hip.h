@@ -398,6 +398,10 @@ int btrapz_eval_states_device(btrapz_ctx *ctx, int B, int seg_stride, const int 
 int btrapz_debug_mqm_tables(btrapz_ctx *ctx, const btrapz_shared *shared, double *host_table, double *device_table);
 /* Test / analysis hook: iterations [B][2] and status [B][2] (s axis, l axis) of the axis problems of the context's last
  * batched solve of B candidates, into host arrays; synchronises the device. */
+/* Test hooks (host only): the scanner of corridor files and the "%.3f" writer of trajectory files -- fast paths around
+ * strtod / printf that must give the same value / the same text (tests/test_text_io.py).  out336: 336 bytes. */
+double btrapz_debug_parse_double(const char *text, int *consumed);
+int btrapz_debug_format_fixed(double v, char *out336);
 int btrapz_debug_axis_records(btrapz_ctx *ctx, int B, int *iters, int *status);
 /* ... and the keys [2][B] (axis-major) the resume launch of the context's last capped solve of B candidates was bucketed
  * by: 0 where the axis problem was not handed over. */

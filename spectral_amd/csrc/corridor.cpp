@@ -13,6 +13,83 @@ namespace btrapz {
 // The reference reads with `ifs >> v` and never checks the stream: after the first failed
 // extraction every later one is a no-op that leaves its target untouched
 // (src/c_road_s1_2.txt has a short last row and relies on this).  TokenReader mirrors it.
+// strtod for the numbers corridor files hold.  Plain decimals ([+-]digits[.digits][e[+-]digits]) of at most 15
+// significant digits and a decimal exponent within +-22 are converted exactly as strtod does it, by ONE correctly
+// rounded operation on two exactly representable values (Clinger's fast path); everything else -- longer digit
+// strings, inf / nan / hex, no number at all -- goes to strtod itself.  Three times faster on the ~3 000 tokens of a
+// 20-second scene (the scan was a third of a file-based find_traj call).
+double parse_double(const char *p, const char **end) {
+  static const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  const char *q = p;
+  while (*q == ' ' || *q == '\n' || *q == '\t' || *q == '\r' || *q == '\f' || *q == '\v') ++q;
+  const char *tok = q;
+  bool neg = false;
+  if (*q == '+' || *q == '-') { neg = *q == '-'; ++q; }
+  unsigned long long mant = 0;
+  int digits = 0, scale = 0;
+  bool any = false, slow = false;
+  while (*q >= '0' && *q <= '9') {
+    any = true;
+    if (mant || *q != '0') { if (++digits > 15) slow = true; else mant = mant * 10 + (unsigned)(*q - '0'); }
+    ++q;
+  }
+  if (*q == '.') {
+    ++q;
+    while (*q >= '0' && *q <= '9') {
+      any = true;
+      if (mant || *q != '0') { if (++digits > 15) slow = true; else mant = mant * 10 + (unsigned)(*q - '0'); }
+      --scale; ++q;
+    }
+  }
+  if (any && !slow && (*q == 'e' || *q == 'E')) {
+    const char *r = q + 1;
+    bool eneg = false;
+    if (*r == '+' || *r == '-') { eneg = *r == '-'; ++r; }
+    if (*r >= '0' && *r <= '9') {
+      int ex = 0;
+      while (*r >= '0' && *r <= '9') { if (ex < 10000) ex = ex * 10 + (*r - '0'); ++r; }
+      scale += eneg ? -ex : ex;
+      q = r;
+    }
+  }
+  if (!any || slow || scale < -22 || scale > 22 || *q == 'x' || *q == 'X' || *q == 'p' || *q == 'P') {
+    char *e = nullptr;
+    const double v = strtod(p, &e);
+    *end = e;
+    return v;
+  }
+  (void)tok;
+  double v = (double)mant;                       // exact: below 1e15
+  v = scale < 0 ? v / P10[-scale] : v * P10[scale];
+  *end = q;
+  return neg ? -v : v;
+}
+
+// printf("%.3f") for the numbers a trajectory file holds: v * 1000 is rounded once, to within 1e-4 of the true
+// product, and unless its fraction is within 1e-3 of a tie (the residual is below 1e-4 for |v| < 1e9) the nearest integer is the correctly
+// rounded decimal -- what printf computes from the exact binary expansion.  Near a tie, for |v| >= 1e9 and for inf / nan, snprintf decides.  Returns the length.
+int format_3(char *out, double v) {
+  const double a = fabs(v);
+  if (!(a < 1e9)) return snprintf(out, FORMAT_3_MAX, "%.3f", v);
+  const double y = a * 1000.0;                   // a * 1000 = y + e exactly, |e| <= ulp(y) / 2
+  const double r = floor(y), frac = y - r;       // exact: y < 2^53
+  if (fabs(frac - 0.5) < 1e-3) return snprintf(out, FORMAT_3_MAX, "%.3f", v);
+  unsigned long long R = (unsigned long long)r + (frac > 0.5 ? 1u : 0u);
+  char tmp[24];
+  int n = 0;
+  const unsigned f3 = (unsigned)(R % 1000u);
+  unsigned long long ip = R / 1000u;
+  do { tmp[n++] = (char)('0' + ip % 10u); ip /= 10u; } while (ip);
+  char *o = out;
+  if (signbit(v)) *o++ = '-';
+  while (n) *o++ = tmp[--n];
+  *o++ = '.';
+  *o++ = (char)('0' + f3 / 100u); *o++ = (char)('0' + f3 / 10u % 10u); *o++ = (char)('0' + f3 % 10u);
+  *o = 0;
+  return (int)(o - out);
+}
+
 namespace {
 // The whole file is read at once and scanned with strtod / strtol (the stream extraction it replaces spent 0.1 ms on
 // the ~1000 tokens of a corridor file -- as long as the solve).
@@ -31,8 +108,8 @@ class TokenReader {
   bool open() const { return open_; }
   void get(double &v) {
     if (failed_) return;
-    char *end = nullptr;
-    const double t = strtod(p_, &end);
+    const char *end = nullptr;
+    const double t = parse_double(p_, &end);
     if (end == p_) failed_ = true; else { v = t; p_ = end; }
   }
   void get(int &v) {

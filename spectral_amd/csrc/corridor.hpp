@@ -43,6 +43,11 @@ struct TrajInput {  // grammar of src/trp_wrapper.cpp:39-144
 };
 
 bool read_traj_input(const std::string &path, TrajInput &in);
+// strtod / printf("%.3f") with fast paths for the numbers corridor and trajectory files hold (corridor.cpp); same
+// values, same text (tests/test_text_io.py)
+double parse_double(const char *p, const char **end);
+enum { FORMAT_3_MAX = 336 };         // "-" + 309 digits + ".000" + NUL of the largest double
+int format_3(char *out, double v);   // out: FORMAT_3_MAX bytes
 
 // CorridorGeneration + CorridorSplit for one obstacle's bounds.
 std::vector<Segment> extract_segments(int variant, int N, double delta, const Bounds &sb, const Bounds &lb);

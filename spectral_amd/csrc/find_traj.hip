@@ -410,11 +410,10 @@ BTRAPZ_EXPORT double btrapz_find_traj(int variant, const char *input_path, const
   if (FILE *f = fopen(out_path.c_str(), "w")) {
     std::string text;
     text.reserve((size_t)max_points * 64);
-    char line[256];
+    char num[FORMAT_3_MAX + 1];
     for (int i = 0; i < max_points; i++) {
-      const int n = snprintf(line, sizeof(line), "%.3f %.3f %.3f %.3f %.3f %.3f %.3f\n", i * in.delta, s[i], l[i], ds[i], dl[i],
-                             dds[i], ddl[i]);
-      if (n > 0) text.append(line, (size_t)n < sizeof(line) ? (size_t)n : sizeof(line) - 1);
+      const double row[7] = {i * in.delta, s[i], l[i], ds[i], dl[i], dds[i], ddl[i]};
+      for (int c = 0; c < 7; c++) { int n = format_3(num, row[c]); num[n++] = c < 6 ? ' ' : '\n'; text.append(num, (size_t)n); }
     }
     fwrite(text.data(), 1, text.size(), f);
     fclose(f);
@@ -423,6 +422,15 @@ BTRAPZ_EXPORT double btrapz_find_traj(int variant, const char *input_path, const
   }
   return cost;
 }
+
+// Test hooks (no device needed): the text scanner and writer of the file-based find_traj against strtod / printf
+BTRAPZ_EXPORT double btrapz_debug_parse_double(const char *text, int *consumed) {
+  const char *end = text;
+  const double v = parse_double(text, &end);
+  if (consumed) *consumed = (int)(end - text);
+  return v;
+}
+BTRAPZ_EXPORT int btrapz_debug_format_fixed(double v, char *out336) { return format_3(out336, v); }
 
 BTRAPZ_EXPORT int btrapz_find_traj_last_iterations(void) { return t_last.iters; }
 

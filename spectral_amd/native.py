@@ -108,7 +108,7 @@ EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "bt
            "btrapz_prism_corridor_batch_device",
            "btrapz_find_traj_last_iterations", "btrapz_argmin_pairs_device", "btrapz_options_init",
            "btrapz_rescue_violations_device", "btrapz_find_traj_last_status", "btrapz_debug_mqm_tables",
-           "btrapz_debug_axis_records", "btrapz_debug_resume_keys",
+           "btrapz_debug_axis_records", "btrapz_debug_resume_keys", "btrapz_debug_parse_double", "btrapz_debug_format_fixed",
            "btrapz_last_solve_form")
 
 
