@@ -253,6 +253,23 @@ class Context:
                                                     ptr(status), ptr(iters), C.c_void_p(stream or 0)),
                     "btrapz_solve_batch_device")
 
+    def prepared_solve(self, B, S, shared, seg, init, ref_end, dl_bounds, ctrl, cost, status, iters=None, stream=None,
+                       **options):
+        """btrapz_solve_batch_device with its argument structs built ONCE: returns a function of no arguments that
+        makes the call (a replanning loop or a latency measurement pays the C call, not the marshalling).  The tensors
+        and `stream` must stay alive and unchanged in place; options as in solve_device."""
+        sh = CShared.from_shared(shared); opt = _options(options.pop("max_iter", 0), options.pop("eps", 0.0), options.pop("elastic", 0),
+                                                         options.pop("elastic_tol", 0.0), **options)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        fn, check = lib().btrapz_solve_batch_device, self._check
+        args = (self._h, C.byref(sh), C.byref(opt), B, S, ptr(seg), ptr(init), ptr(ref_end), ptr(dl_bounds), ptr(ctrl), ptr(cost),
+                ptr(status), ptr(iters), C.c_void_p(stream or 0))
+        keep = (sh, opt, seg, init, ref_end, dl_bounds, ctrl, cost, status, iters)
+
+        def call(_keep=keep):
+            check(fn(*args), "btrapz_solve_batch_device")
+        return call
+
     def solve_ragged_device(self, B, seg_stride, shared, seg, seg_count, init, ref_end, dl_bounds, ctrl, cost,
                             status, iters=None, stream=None, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0):
         sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol)

@@ -78,6 +78,15 @@ class BatchSolver:
                                    elastic_tol=elastic_tol)
         return o
 
+    def prepare(self, dbatch, shared, out=None, **options):
+        """solve(dbatch, shared, **options) prepared once: returns (call, out) where call() launches the solve on the
+        stream that is current NOW and `out` is the dict of device tensors it fills (cold solves only)."""
+        o = out if out is not None else self._buffers(dbatch.B, dbatch.S)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        call = self.ctx.prepared_solve(dbatch.B, dbatch.S, shared, dbatch.seg, dbatch.init, dbatch.ref_end, dbatch.dl_bounds,
+                                       o["ctrl"], o["cost"], o["status"], o["iters"], stream=stream, **options)
+        return call, o
+
     def eval_states(self, dbatch, ctrl, times):
         """(p, v, a) of every candidate's solved trajectory at times[b][j] (seconds from the start of its
         horizon) -> [B, 2, n_times, 3]; the x0 of a warm start."""

@@ -206,3 +206,21 @@ def test_find_traj_threads_hand_their_device_state_on(tmp_path):
     t = threading.Thread(target=lambda: out.append((native.lib().btrapz_find_traj_last_iterations(), native.find_traj_last_status()[0])))
     t.start(); t.join()
     assert out == [(-1, 0)]
+
+
+def test_prepared_solve_is_the_solve():
+    """BatchSolver.prepare: the same call with its argument structs built once."""
+    import torch
+    from spectral_amd import synth
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    batch, sh = synth.make_scenario1_batch(48, 20, 0)
+    db = solver.upload(batch)
+    a = {k: v.clone() for k, v in solver.solve(db, sh, split=-1).items()}
+    call, o = solver.prepare(db, sh, split=-1)
+    for v in o.values():
+        v.zero_()
+    call(); call()
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], o[k]), k
