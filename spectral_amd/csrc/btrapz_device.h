@@ -117,6 +117,7 @@ __global__ void ipm_solve_queue_kernel(const KernelArgs a, const double *__restr
 __global__ void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm);       // rescue pass
 __global__ void ipm_solve_split_kernel(const KernelArgs a, const double *__restrict__ mqm);         // one candidate per wavefront, rows over 3 lanes
 __global__ void ipm_solve_capped_kernel(const KernelArgs a, const double *__restrict__ mqm);        // first launch of a capped solve
+__global__ void ipm_solve_capped_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);  // ... of a ragged batch
 __global__ void ipm_solve_resume_kernel(const KernelArgs a, const double *__restrict__ mqm);        // ... and the launch that carries the suspended problems on
 #define BTRAPZ_SUSPENDED (-7)   // internal: an axis problem the capped launch handed over (never leaves the library)
 __global__ void ipm_solve_long_kernel(const KernelArgs a, const double *__restrict__ mqm);          // 65..256 segments: one axis problem per workgroup

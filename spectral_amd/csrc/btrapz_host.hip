@@ -187,7 +187,8 @@ static void fill_parameters(KernelArgs &a, const btrapz_shared *sh, const btrapz
   a.tau = (opt && opt->step_fraction > 0 && opt->step_fraction < 1) ? opt->step_fraction : BTRAPZ_DEFAULT_STEP_FRACTION;
   a.tau_iters = BTRAPZ_AGGRESSIVE_ITERATIONS;
   a.stall_start = BTRAPZ_STALL_START; a.stall_len = BTRAPZ_STALL_LENGTH;
-  a.stall_factor = BTRAPZ_STALL_FACTOR;
+  static const float stall_factor_env = [] { const char *v = getenv("BTRAPZ_STALL_FACTOR"); return v ? (float)atof(v) : 0.0f; }();   // (experiments)
+  a.stall_factor = stall_factor_env > 0.0f ? stall_factor_env : BTRAPZ_STALL_FACTOR;
   a.diverge_factor = BTRAPZ_DIVERGE_FACTOR;
   a.tau_thr = (opt && opt->step_threshold > 0) ? opt->step_threshold : BTRAPZ_DEFAULT_STEP_THRESHOLD;
   a.x0 = warm ? warm->x0 : nullptr; a.lam0 = warm ? warm->lam0 : nullptr; a.lam_out = warm ? warm->lam_out : nullptr;
@@ -405,9 +406,16 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     // variant 6.70 -> 6.35, generic x 20 5.21 -> 5.18, scenario_1 x 10 2.24 -> 2.46 (six groups per wavefront: what a
     // lone straggler wastes is less than what the second launch costs).  Automatic (cap_iter = 0): 6 for uniform cold
     // batches of 16 to 64 segments that fill the device at least eight times over; -1: never.
-    int cap_iter = cap_env >= 0 ? cap_env : (opt ? opt->cap_iter : 0);
-    if (cap_iter == 0 && S >= 16 && blocks >= 8u * (unsigned)c->resident_waves) cap_iter = 6;
-    const bool capped = cap_iter > 0 && !long_form && !split_on && !a.order && !warm_kernel && !queue_on && S <= BTRAPZ_MAX_SEGMENTS &&
+    // Ragged batches (round 3, late): the same two launches on request (cap_iter > 0), the resume lists bucketed by
+    // segment count instead of by convergence class.  Not automatic: measured on 65 536 candidates, knots -> control
+    // points (tools/pipeline_bench.py, one launch -> cap 8): jittered c_road_s1_3.txt, 8 segments, a quarter of the
+    // candidates infeasible (16-19 iterations against 9-12) 3.20 -> 2.90 ms; scenario_1 at knot level, 18-24 segments
+    // 9.56 -> 9.79; two-car scenes, 7-9 segments, all feasible 3.21 -> 3.54 -- it pays where iteration counts spread
+    // widely, which the library does not know.
+    int cap_iter = cap_env > 0 ? cap_env : cap_env == 0 ? -1 : (opt ? opt->cap_iter : 0);   // BTRAPZ_CAP=0: never
+    const bool ragged = seg_count != nullptr;
+    if (cap_iter == 0 && !ragged && S >= 16 && blocks >= 8u * (unsigned)c->resident_waves) cap_iter = 6;
+    const bool capped = cap_iter > 0 && !long_form && !split_on && (!a.order || ragged) && !warm_kernel && !queue_on && S <= BTRAPZ_MAX_SEGMENTS &&
                         cap_iter < a.max_iter && elastic != 2;
     if (capped) {
       // slots for a quarter of the axis problems (BTRAPZ_SUSP_PERCENT: experiments); a group that finds none goes on
@@ -440,21 +448,24 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       static const int cap_hi_env = [] { const char *q = getenv("BTRAPZ_CAP_HI"); return q ? atoi(q) : 4; }();
       p1.cap_iter = cap_iter; p1.cap_alone = cap_alone_env; p1.cap_hi = cap_iter + cap_hi_env; p1.susp_cap = (int)slots; p1.susp_state = c->d_susp_state; p1.susp_count = count;
       p1.susp_slot = slot_of; p1.susp_key = keys;
-      hipLaunchKernelGGL(ipm_solve_capped_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+      if (ragged) hipLaunchKernelGGL(ipm_solve_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+      else hipLaunchKernelGGL(ipm_solve_capped_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
       int *lists = c->d_rescue + 2 * (size_t)B;
       const unsigned nb = (unsigned)((B + 255) / 256);
+      const int list_S = ragged ? 0 : -S;   // ragged: keys are segment counts; uniform: convergence classes, 0 = not listed
       for (int ax = 0; ax < 2; ax++) {
         int *meta = c->d_rescue_meta + ax * 198;
         const int *k = keys + (size_t)ax * B;
-        hipLaunchKernelGGL(bucket_hist_kernel, dim3(nb), dim3(256), 0, stream, B, S, k, meta, -S);
-        hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(64), 0, stream, meta, -S);
+        hipLaunchKernelGGL(bucket_hist_kernel, dim3(nb), dim3(256), 0, stream, B, S, k, meta, list_S);
+        hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(64), 0, stream, meta, list_S);
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nb), dim3(256), 0, stream, B, S, k, meta, lists + (size_t)ax * B,
-                           (double *)nullptr, (int *)nullptr, (int *)nullptr, -S);
+                           (double *)nullptr, (int *)nullptr, (int *)nullptr, list_S);
       }
       KernelArgs p2 = p1;
       p2.cap_iter = 0; p2.order = lists; p2.seg_count = nullptr; p2.cand_prefix = c->d_rescue_meta; p2.wave_prefix = c->d_rescue_meta + 66;
-      p2.bucket_S = S;
-      const unsigned rblocks = 2u * (unsigned)(slots / (size_t)(64 / S) + 65);
+      p2.bucket_S = ragged ? 0 : S;
+      // (ragged: no candidate has more than min(S, 64) segments, so no wavefront holds fewer groups than that allows)
+      const unsigned rblocks = 2u * (unsigned)(slots / (size_t)(64 / (S < 64 ? S : 64)) + 65);
       hipLaunchKernelGGL(ipm_solve_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
       c->last_form = 3;
     } else if (long_form) {

@@ -616,8 +616,13 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     bnorm = 0.0; qn = 0.0;
     static_for<18>([&](auto r_c) {          // (all rows of the reference: a row with l > u is reported as such)
       constexpr int r = decltype(r_c)::value;
-      gapmin = fmin(gapmin, UP0(r) - LO0(r));
-      bnorm = fmax(bnorm, fmax(fabs(LO0(r)), fabs(UP0(r))));
+      // ... by more than 1e-12 (the oracle's tolerance, oracle/btrapz_oracle.c ipm_core): a lower line that reaches the
+      // upper bound exactly at a control point (0.4 + 0.5 * 0.6 against 0.7) gives l = 0.7000000000000004 >
+      // u = 0.7000000000000001, an equality in all but the last bit (round-3 fuzz campaign: 1 call in 32 000 was refused
+      // for it)
+      const double rb = fmax(fabs(LO0(r)), fabs(UP0(r)));
+      gapmin = fmin(gapmin, (UP0(r) - LO0(r)) + 1e-12);
+      bnorm = fmax(bnorm, rb);
     });
     // Rows that no iterate can change: segment 0's first position / velocity / acceleration row state the given
     // initial state (c0, c1, c2 of segment 0 follow from it alone), and a joint whose two sides leave no common value.
@@ -792,7 +797,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
           int st;
           if (infeasible_bounds) st = BTRAPZ_PRIMAL_INFEASIBLE;
           else if (best_score < 1e-7) st = BTRAPZ_SOLVED;
-          else if (best_score < 1e-5) st = BTRAPZ_SOLVED_INACCURATE;
+          else if (best_score < 1e-5 || (res_it < 0 && best_score < 1e-4)) st = BTRAPZ_SOLVED_INACCURATE;   // res_it < 0: ended at the dual floor
           else st = BTRAPZ_MAX_ITER_REACHED;
           if constexpr (ELASTIC) {
             // converged on the relaxed problem: feasible after all (rows kept to 1e-7) -> as solved; least violation
@@ -932,6 +937,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     const double rd_eff = fmax(rr.b - 2e-13 * rr.d, 0.0);
     const double res = fmax(rd_eff / (1.0 + qn), rr.c / (1.0 + bnorm));
     const double score = fmax(res, mu);
+    const bool feasible_and_complementary = fmax(mu, rr.c / (1.0 + bnorm)) < 1e-7;   // (only the dual residual is left: see the dual floor below)
+#ifdef BTRAPZ_TRACE   // debugging aid: one line per iteration and axis problem (tools: build with -DBTRAPZ_TRACE)
+    if (first && lane_in_group && valid && !done && gl == 0) printf("trace axis %d b %d eit %d score %.3e res %.3e (dual %.3e primal %.3e) mu %.3e best %.3e@%d res_it %d | rd %.3e dscale %.3e qn %.3e bnorm %.3e\n", axis, b, eit, score, res, rd_eff / (1.0 + qn), rr.c / (1.0 + bnorm), mu, best_score, best_it, res_it, rr.b, rr.d, qn, bnorm);
+#endif
     bool restart_now = false;
     if (!done && !unc_pass) {
       iters = eit;
@@ -951,7 +960,13 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // into a failure nor cost more than a bounded number of iterations.
       const bool stalled = (eit - it0 >= a.stall_start && eit - best_it >= a.stall_len && eit - res_it >= a.stall_len) ||
                            (!ELASTIC && mu > (double)a.diverge_factor * best_score) || !(score < 1e299);
-      if (score < eps || (best_score < 1e-5 && eit - best_it >= 3)) done = true;
+      // (the dual floor: feasible to 1e-7 and complementary to 1e-7, the dual residual alone stuck between 1e-5 and
+      //  1e-4 for three iterations -- the accuracy of the block elimination on a badly scaled corridor (a 0.1 s segment
+      //  among 1 s ones), not of the iterate's position: "solved inaccurate", instead of iterating on until the slacks
+      //  underflow.  Found by the round-3 fuzz campaign: 1 call in 16 000.)
+      const bool at_floor = best_score < (feasible_and_complementary ? 1e-4 : 1e-5) && eit - best_it >= 3;
+      if (at_floor && feasible_and_complementary) res_it = -1;   // (the mark write_back reads: the stall bookkeeping is over)
+      if (score < eps || at_floor) done = true;
       else if (WARM && !restarted && (stalled || (eit - it0 >= 12 && best_score > 1e-4) || eit - it0 >= 24)) restart_now = true;
       else if (stalled) {
         // stalled with residuals at round-off level: only the complementarity is stuck (the two-cycle described at the
@@ -985,7 +1000,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
             const double sc = fmax(fmin(score, 1e3), 1e-12);
             int cls = 1 + (int)(4.0 * (log10(sc) + 12.0));
             a.susp_slot[2LL * b + axis] = (int)slot;
-            a.susp_key[(size_t)axis * a.B + b] = cls < 1 ? 1 : cls > 64 ? 64 : cls;
+            // (ragged batches: the resume lists are bucketed by segment count, as the batch itself is)
+            a.susp_key[(size_t)axis * a.B + b] = (ORDERED && !a.bucket_S) ? S : (cls < 1 ? 1 : cls > 64 ? 64 : cls);
           }
           suspended = true; done = true;
         }
@@ -1421,6 +1437,11 @@ __global__ __launch_bounds__(64) void ipm_solve_warm_ordered_kernel(const Kernel
 __global__ __launch_bounds__(64) void ipm_solve_capped_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[lds_rows<false>()][64];
   ipm_solve_body<false, false, false, false, false, false, true, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
+}
+// ... the first launch of a ragged batch (candidates bucketed by segment count, as in ipm_solve_ordered_kernel)
+__global__ __launch_bounds__(64) void ipm_solve_capped_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  __shared__ double lds[lds_rows<false>()][64];
+  ipm_solve_body<false, true, false, false, false, false, true, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 __global__ __launch_bounds__(64) void ipm_solve_resume_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[lds_rows<false>()][64];

@@ -271,8 +271,8 @@ class Context:
         return call
 
     def solve_ragged_device(self, B, seg_stride, shared, seg, seg_count, init, ref_end, dl_bounds, ctrl, cost,
-                            status, iters=None, stream=None, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0):
-        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol)
+                            status, iters=None, stream=None, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, cap_iter=0):
+        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol, cap_iter=cap_iter)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self._check(lib().btrapz_solve_ragged_device(self._h, C.byref(sh), C.byref(opt), B, seg_stride, ptr(seg),
                                                      ptr(seg_count), ptr(init), ptr(ref_end), ptr(dl_bounds),

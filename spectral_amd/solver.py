@@ -170,8 +170,9 @@ class BatchSolver:
         rec["_inputs"] = ins
         return rec
 
-    def solve_ragged(self, rec, shared, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0):
-        """Solve a ragged batch record (from corridor_batch); outputs stay on the device."""
+    def solve_ragged(self, rec, shared, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, cap_iter=0):
+        """Solve a ragged batch record (from corridor_batch); outputs stay on the device.  cap_iter:
+        btrapz_options.cap_iter (0 automatic, -1 one launch, n two launches with hand-over after n iterations)."""
         d = self.device
         B, st = rec["B"], rec["seg_stride"]
         o = dict(ctrl=torch.zeros((B, 12 * st), dtype=torch.float64, device=d),
@@ -180,7 +181,7 @@ class BatchSolver:
         stream = torch.cuda.current_stream(d).cuda_stream
         self.ctx.solve_ragged_device(B, st, shared, rec["seg"], rec["seg_count"], rec["init"], rec["ref_end"],
                                      rec["dl_bounds"], o["ctrl"], o["cost"], o["status"], o["iters"], stream=stream,
-                                     max_iter=max_iter, eps=eps, elastic=elastic, elastic_tol=elastic_tol)
+                                     max_iter=max_iter, eps=eps, elastic=elastic, elastic_tol=elastic_tol, cap_iter=cap_iter)
         return o
 
     def argmin(self, cost, group=None, index_base=0):

@@ -32,7 +32,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 rng = np.random.default_rng(seed0)
 files = ["c1", "c2", "c3", "c4", "c6", "c7", "c7_7", "c_road_s1", "c_road_s1_3"]
 tmp = tempfile.mkdtemp()
-agree = acc = rej = bad = 0
+agree = acc = rej = bad = inaccurate = loose = 0
 worst = 0.0
 t0 = time.time()
 for it in range(count):
@@ -105,7 +105,10 @@ for it in range(count):
     acc += 1
     err = np.abs(ctrl - x).max() / max(1e-300, np.abs(x).max())
     worst = max(worst, err)
+    if native.find_traj_last_status()[0] == 2:   # "solved inaccurate" (KKT score between 1e-7 and 1e-5, or the dual floor of a badly scaled corridor): the north-star's bar, and a tally
+        inaccurate += 1; loose += err > tol_x; tol_x = max(tol_x, 1e-4)
     if not (ctrl.shape == x.shape and err <= tol_x):
         bad += 1; print("XSTAR", it, mode, variant, err)
 if PORT_EVERY: print("against the OSQP port (every %d-th call):" % PORT_EVERY, port)
-print("calls", count, "agree", agree, "accepted", acc, "rejected", rej, "mismatches", bad, "worst rel err %.2e" % worst, "seconds %.1f" % (time.time() - t0))
+print("calls", count, "agree", agree, "accepted", acc, "rejected", rej, "mismatches", bad, "worst rel err %.2e" % worst, "seconds %.1f" % (time.time() - t0),
+      "| status 2 (solved inaccurate):", inaccurate, "of the accepted, beyond 1e-5 (within 1e-4):", loose)

@@ -266,3 +266,29 @@ def test_hip_path_reproduces_the_lateral_columns_of_saved_scenario1_files(ref, n
     got = traj.T                                             # rows t s l ds dl dds ddl -> columns
     assert np.abs(got[:, [2, 4, 6]] - want[:, [2, 4, 6]]).max() <= PRINT
     assert np.abs(got[:, [1, 3, 5]] - want[:, [1, 3, 5]]).max() <= 0.021
+
+
+@pytest.mark.parametrize("case,variant,tol", [("s704_it3149_v1", 1, 1e-4), ("s733_it3842_v0", 0, 1e-5)])
+def test_inputs_the_round3_fuzz_campaign_found(case, variant, tol):
+    """Two inputs of 32 000 fuzzed calls on which the product refused a corridor the oracle solves (tests/fuzz/cases/):
+    a 0.1 s segment among 1 s ones, where the dual residual stops at 2e-5 -- the accuracy of the block elimination --
+    while the iterate is feasible and complementary to 1e-13 (now "solved inaccurate", control points within 1e-4); and
+    a lower line that reaches the upper bound exactly at a control point, l = 0.7000000000000004 > u = 0.7000000000000001
+    (now the equality it is).  Both forms of the single-candidate kernel."""
+    from spectral_amd import knots
+    w = np.loadtxt(os.path.join(GOLD, "inputs", "weights.txt"))
+    path = os.path.join(os.path.dirname(__file__), "fuzz", "cases", case + ".txt")
+    inp = O.ParsedInput(path)
+    n, cubes = O.pipeline(variant, inp)
+    x, _, info = O.AssembledQp(variant, cubes, O.params_from_weights(w), inp).solve_exact()
+    assert info.status == 1
+    params = native.CParams(*[float(v) for v in w], 3)
+    for split in ("1", "0"):
+        os.environ["BTRAPZ_SPLIT"] = split
+        try:
+            cost, traj, ctrl = native.find_traj_mem(variant, params, knots.parse_corridor_file(path))
+        finally:
+            del os.environ["BTRAPZ_SPLIT"]
+        assert cost < 1e10 and len(ctrl) == 12 * n, (case, split)
+        assert native.find_traj_last_status()[0] in (1, 2), (case, split, native.find_traj_last_status())
+        assert np.abs(ctrl - x).max() <= tol * np.abs(x).max(), (case, split, np.abs(ctrl - x).max() / np.abs(x).max())

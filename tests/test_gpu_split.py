@@ -143,3 +143,36 @@ def test_capped_first_launch_and_resume_launch_give_the_one_launch_results_bit_f
     d = {k: v.cpu().numpy().copy() for k, v in solver.solve(db, sh, split=-1, cap_iter=-1, elastic=1).items()}
     torch.cuda.synchronize()
     assert np.array_equal(c["status"], d["status"]) and np.array_equal(c["cost"], d["cost"])
+
+
+@pytest.mark.parametrize("cap", [4, 8])
+def test_ragged_batches_in_two_launches_give_the_one_launch_results_bit_for_bit(cap):
+    """btrapz_options.cap_iter on a ragged batch (knots -> corridors -> QP): the first launch hands over, the resume
+    lists are bucketed by segment count; control points, costs, statuses, iteration counts are the one-launch solve's."""
+    import os
+    import torch
+    from spectral_amd import knots
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    gold = os.path.join(os.path.dirname(__file__), "golden", "inputs")
+    W = np.loadtxt(os.path.join(gold, "weights.txt"))
+    parts = [knots.jittered(knots.parse_corridor_file(os.path.join(gold, n + ".txt")), 1500, seed=3 + i) for i, n in enumerate(("c_road_s1_3", "c1", "c2"))]
+    listed = 0
+    for kb in parts + [synth.scenario1_knots(1200, 20)]:
+        sh = synth.shared_params(0, weights=W)
+        sh.ds_ref, sh.dl_ref = kb.header["ds_ref"], kb.header["dl_ref"]
+        sh.dds, sh.ddds, sh.ddl, sh.dddl = kb.header["dds"], kb.header["ddds"], kb.header["ddl"], kb.header["dddl"]
+        rec = solver.corridor_batch(kb, 0, seg_stride=32)
+        a = {k: v.cpu().numpy().copy() for k, v in solver.solve_ragged(rec, sh, cap_iter=-1).items()}
+        assert solver.ctx.last_solve_form() == 0
+        b = {k: v.cpu().numpy().copy() for k, v in solver.solve_ragged(rec, sh, cap_iter=cap).items()}
+        assert solver.ctx.last_solve_form() == 3
+        torch.cuda.synchronize()
+        assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["cost"], b["cost"])
+        ok = a["status"] > 0
+        assert ok.any() and np.array_equal(a["ctrl"][ok], b["ctrl"][ok])
+        keys = solver.ctx.debug_resume_keys(kb.B)
+        cnt = rec["seg_count"].cpu().numpy()
+        assert (keys[keys > 0] == np.stack([cnt, cnt])[keys > 0]).all()   # listed by segment count
+        listed += int((keys > 0).sum())
+    assert listed > 0                                                     # (some problems did go through the second launch)

@@ -4,13 +4,14 @@
 # Logs under gpurun_out/fuzz_<tag>/; the last lines of every log are the tallies DESIGN.md section 5 quotes.
 TAG=${1:-r03}
 CALLS=${2:-1500}
+SEED=${3:-300}
 OUT=gpurun_out/fuzz_$TAG
 mkdir -p "$OUT"
 # find_traj (in-memory) against the oracle: plain solve, then the product's default (rescue pass on) with the OSQP
 # port's decision tallied on every 10th call; four processes at a time (at most 6 may hold the GPU)
 for e in 0 1; do
   for s in 1 2 3 4; do
-    timeout -k 10 900 python tests/fuzz/find_traj_vs_oracle.py $((300 + 10 * e + s)) "$CALLS" $e - $((e * 10)) > "$OUT/find_traj_e${e}_s$s.log" 2>&1 &
+    timeout -k 10 900 python tests/fuzz/find_traj_vs_oracle.py $((SEED + 10 * e + s)) "$CALLS" $e - $((e * 10)) > "$OUT/find_traj_e${e}_s$s.log" 2>&1 &
   done
   wait
   echo "find_traj elastic=$e done"; tail -n 2 "$OUT"/find_traj_e${e}_s*.log
