@@ -616,7 +616,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     bnorm = 0.0; qn = 0.0;
     static_for<18>([&](auto r_c) {          // (all rows of the reference: a row with l > u is reported as such)
       constexpr int r = decltype(r_c)::value;
-      // ... by more than 1e-12 (the oracle's tolerance, oracle/btrapz_oracle.c ipm_core): a lower line that reaches the
+      // ... by more than 1e-12 (the tolerance of the test suite's exact solver, so that both decide alike): a lower line that reaches the
       // upper bound exactly at a control point (0.4 + 0.5 * 0.6 against 0.7) gives l = 0.7000000000000004 >
       // u = 0.7000000000000001, an equality in all but the last bit (round-3 fuzz campaign: 1 call in 32 000 was refused
       // for it)
