@@ -1403,6 +1403,7 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
       for (int r = 0; r < mi && finite; r++) finite = isfinite(rpl[r]) && isfinite(rpu[r]);
       if (!finite) score = 1e300;
     }
+    if (getenv("ORC_TRACE")) fprintf(stderr, "orc trace iter %d score %.3e dual %.3e primal %.3e mu %.3e\n", iter, score, vnorm_inf(rd, n) / (1 + qn), rpn / (1 + bn), mu);
     if (iter == 0 || score < best_score) {
       best_score = score; best_it = iter; memcpy(bx, x, sizeof(double) * n);
       for (int i = 0; i < m; i++) by[i] = iseq[i] ? nu[rowpos[i]] : (lu_[rowpos[i]] - ll[rowpos[i]]);
