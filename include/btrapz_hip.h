@@ -155,6 +155,7 @@ enum {
  * result, much slower per segment -- the reference has no limit, its bundled inputs have at most 14).  Ragged
  * batches, warm starts and the rescue pass stay at BTRAPZ_MAX_SEGMENTS. */
 #define BTRAPZ_MAX_SEGMENTS_LONG 256
+#define BTRAPZ_MAX_SEGMENTS_LONG_RESCUE 192 /* ... with a rescue pass (btrapz_options.elastic) behind it: three wavefronts */
 
 /* Weights (Params) and limits (input-file header, trp_wrapper.cpp:59-64) shared by all
  * candidates of a batch. */

@@ -121,6 +121,7 @@ __global__ void ipm_solve_capped_ordered_kernel(const KernelArgs a, const double
 __global__ void ipm_solve_resume_kernel(const KernelArgs a, const double *__restrict__ mqm);        // ... and the launch that carries the suspended problems on
 #define BTRAPZ_SUSPENDED (-7)   // internal: an axis problem the capped launch handed over (never leaves the library)
 __global__ void ipm_solve_long_kernel(const KernelArgs a, const double *__restrict__ mqm);          // 65..256 segments: one axis problem per workgroup
+__global__ void ipm_solve_long_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm);  // rescue pass of the long form (<= 192 segments)
 __global__ void rescue_keys_kernel(int B, int S, const int *seg_count, const int *axis_status, int *keys, int all);
 __global__ void rescue_init_kernel(int B, int S, const int *seg_count, double *axis_obj, int *axis_status, int *axis_iters);
 struct MqmWeights { double w[2][4]; };   // [axis][ref, dref, acc, jerk]

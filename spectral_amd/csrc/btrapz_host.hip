@@ -376,8 +376,8 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   }
   const bool warm_kernel = a.x0 || a.lam0 || a.lam_out;   // (a hint alone only reorders the candidates)
   const bool long_form = !seg_count && S > BTRAPZ_MAX_SEGMENTS;   // one axis problem per workgroup (ipm_solve_long_kernel)
-  if (long_form && (a.order || warm_kernel || elastic)) {
-    c->err = "more than 64 segments: uniform cold solve without rescue pass only";
+  if (long_form && (a.order || warm_kernel || elastic == 2 || (elastic == 1 && S > BTRAPZ_MAX_SEGMENTS_LONG_RESCUE))) {
+    c->err = "more than 64 segments: uniform cold solve only, rescue pass (elastic = 1) up to 192 segments";
     return BTRAPZ_EINVAL;
   }
   auto kernel = warm_kernel ? (a.order ? ipm_solve_warm_ordered_kernel : ipm_solve_warm_kernel)
@@ -486,7 +486,19 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     }
     HIPCHK(c, hipGetLastError());
   }
-  if (elastic) {
+  if (elastic && long_form) {
+    // Rescue pass of the long form: one workgroup per axis problem again; those whose problem did not stall leave at once
+    HIPCHK(c, hipMemsetAsync(c->d_axis_viol, 0, sizeof(double) * 8 * (size_t)B, stream));
+    c->viol_valid = (size_t)B;
+    KernelArgs e = a;
+    e.order = nullptr; e.x0 = nullptr; e.lam0 = nullptr; e.lam_out = nullptr;
+    e.max_iter = a.max_iter < 120 ? 120 : a.max_iter;   // (as below)
+    e.tau_iters = 0;
+    e.stall_start = 4 * BTRAPZ_STALL_START; e.stall_len = 4 * BTRAPZ_STALL_LENGTH;
+    hipLaunchKernelGGL(ipm_solve_long_elastic_kernel, dim3(2u * (unsigned)B), dim3(64u * (unsigned)((S + 63) / 64)), 0, stream, e,
+                       (const double *)c->d_mqm);
+    HIPCHK(c, hipGetLastError());
+  } else if (elastic) {
     // Rescue pass: the axis problems that stalled (elastic == 2: all of them) are listed per axis, bucketed by
     // segment count with the machinery of the ragged batches, and solved again with elastic rows.  The lists are
     // built on the device; the launch is sized for the worst case and its unused wavefronts leave at once.

@@ -301,7 +301,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
                                                const int wave_id, const int lane, double *wgs = nullptr, const int wv = 0) {
   static_assert(!QUEUE || (!WARM && !ORDERED && !ELASTIC), "the queue serves uniform cold batches");
   static_assert(!SPLIT || (!ORDERED && !ELASTIC && !QUEUE), "the split form serves uniform batches");
-  static_assert(!MULTI || (!WARM && !ORDERED && !ELASTIC && !QUEUE && !SPLIT), "the long form serves uniform cold batches");
+  static_assert(!MULTI || (!WARM && !ORDERED && !QUEUE && !SPLIT), "the long form serves uniform cold batches (and their rescue pass)");
   static_assert(!(CAPPED || RESUME) || (!WARM && !ELASTIC && !QUEUE && !SPLIT && !MULTI && !(CAPPED && RESUME)), "capped / resume: packed cold form");
   static_assert(!RESUME || ORDERED, "the resume pass reads its problems from per-axis lists");
   constexpr bool PERAXIS = ELASTIC || RESUME;   // one candidate list and one set of bucket tables per axis
@@ -1465,6 +1465,16 @@ __global__ __launch_bounds__(256) void ipm_solve_long_kernel(const KernelArgs a,
   __shared__ double wgs[WGS_SEAM + 4 * WGS_LANES];
   const int wv = (int)threadIdx.x >> 6;
   ipm_solve_body<false, false, false, false, false, true>(a, mqm, lds[wv], (int)blockIdx.x, (int)threadIdx.x & 63, wgs, wv);
+}
+// ... and its rescue pass (btrapz_options.elastic): the workgroups of the axis problems that stalled solve them again with
+// elastic rows, the others leave at once.  Up to three wavefronts (192 segments): the 18-row LDS columns of a fourth do
+// not fit the CU.
+__global__ __launch_bounds__(192) void ipm_solve_long_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  __shared__ double lds[3][lds_rows<true>()][64];
+  __shared__ double wgs[WGS_SEAM + 4 * WGS_LANES];
+  if (a.axis_status[blockIdx.x] != BTRAPZ_MAX_ITER_REACHED) return;   // (the same for every thread of the workgroup)
+  const int wv = (int)threadIdx.x >> 6;
+  ipm_solve_body<false, false, true, false, false, true>(a, mqm, lds[wv], (int)blockIdx.x, (int)threadIdx.x & 63, wgs, wv);
 }
 // Rescue pass (btrapz_options.elastic): the stalled axis problems, listed per axis, with elastic rows.
 __global__ __launch_bounds__(64) void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm) {

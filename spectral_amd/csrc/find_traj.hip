@@ -342,21 +342,23 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
     if (hipMemcpyAsync(s_in, h_in, (n_in + 1) * 8, hipMemcpyHostToDevice, me->stream) != hipSuccess) return FAIL;
     btrapz_options opt;
     btrapz_options_init(&opt);
-    opt.elastic = long_form ? 0 : 1; opt.elastic_tol = el.tol;
+    // (the long form has its rescue pass up to 192 segments; beyond, the plain solve decides)
+    const bool rescue = el.on && (!long_form || S <= BTRAPZ_MAX_SEGMENTS_LONG_RESCUE);
+    opt.elastic = rescue ? 1 : 0; opt.elastic_tol = el.tol;
     double *s_viol = s_out + n_out;
     double h_viol[4] = {0.0, 0.0, 0.0, 0.0};
     if (btrapz_solve_batch_device(ctx, &sh, &opt, 1, S, s_in, s_init, s_init + 6, s_init + 8, s_out + 3, s_out, s_status,
                                   s_status + 1, me->stream) != BTRAPZ_OK ||
         btrapz_sample_device(ctx, 1, S, in.delta, s_in, s_init, s_out + 3, 1, s_sel, max_points, s_out + 3 + 12 * S, s_np,
                              me->stream) != BTRAPZ_OK ||
-        (!long_form && btrapz_rescue_violations_device(ctx, 1, s_viol, me->stream) != BTRAPZ_OK)) {
+        (rescue && btrapz_rescue_violations_device(ctx, 1, s_viol, me->stream) != BTRAPZ_OK)) {
       fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
       t_last.status = BTRAPZ_EHIP;
       btrapz_single_forget(ctx);
       return FAIL;
     }
     if (hipMemcpyAsync(h_out, s_out, n_out * 8, hipMemcpyDeviceToHost, me->stream) != hipSuccess ||
-        (!long_form && hipMemcpyAsync(h_viol, s_viol, 4 * 8, hipMemcpyDeviceToHost, me->stream) != hipSuccess) ||
+        (rescue && hipMemcpyAsync(h_viol, s_viol, 4 * 8, hipMemcpyDeviceToHost, me->stream) != hipSuccess) ||
         hipStreamSynchronize(me->stream) != hipSuccess) { t_last.status = BTRAPZ_EHIP; btrapz_single_forget(ctx); return FAIL; }
     h_cost = h_out[0];
     memcpy(h_status, &h_out[1], 8);

@@ -39,14 +39,19 @@ def test_long_corridors_reach_the_oracle_optimum(gen, S, variant):
 
 
 def test_long_form_limits_and_refusals():
-    """Up to 256 segments, uniform cold solve only: the rescue pass, warm starts and ragged batches stay at 64."""
+    """Up to 256 segments, uniform cold solve only (with its rescue pass up to 192): the all-elastic solve, warm starts
+    and ragged batches stay at 64."""
     import torch
     from spectral_amd.solver import BatchSolver
     solver = BatchSolver(0)
     batch, sh = synth.make_batch(2, 70, config=3)
     db = solver.upload(batch)
+    solver.solve(db, sh, elastic=1)                          # rescue pass: three wavefronts per problem at most
     with pytest.raises(native.BtrapzError):
-        solver.solve(db, sh, elastic=1)
+        solver.solve(db, sh, elastic=2)
+    big193, sh193 = synth.make_batch(2, 193, config=3)
+    with pytest.raises(native.BtrapzError):
+        solver.solve(solver.upload(big193), sh193, elastic=1)
     with pytest.raises(native.BtrapzError):
         solver.solve(db, sh, keep_multipliers=True)
     big, sh2 = synth.make_batch(2, 257, config=3)
@@ -76,3 +81,29 @@ def test_find_traj_on_a_long_horizon():
     rc, smp = O.sample(cubes, inp.delta, x, inp.init_s, inp.init_l)
     assert rc == 0 and traj.shape[1] == len(smp[0])
     assert np.abs(traj[1] - smp[0]).max() <= 1e-4 * max(1.0, np.abs(smp[0]).max())      # s column against x*'s samples
+
+
+@pytest.mark.parametrize("case,variant", [("s712_it11_v1", 1), ("s755_it2486_v1", 1)])
+def test_rescue_pass_of_the_long_form(case, variant):
+    """Two corridors of 76 and 65 segments the round-3 fuzz campaign found (tests/fuzz/cases/): no feasible trajectory,
+    least violation within the rescue tolerance -- the oracle's relaxed solve accepts them, and since the long form has
+    a rescue pass (ipm_solve_long_elastic_kernel) so does find_traj: same decision, control points of the relaxed
+    problem's solution."""
+    w = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", "inputs", "weights.txt"))
+    path = os.path.join(os.path.dirname(__file__), "fuzz", "cases", case + ".txt")
+    inp = O.ParsedInput(path)
+    n, cubes = O.pipeline(variant, inp)
+    qp = O.AssembledQp(variant, cubes, O.params_from_weights(w), inp)
+    assert n > 64 and qp.solve_exact()[2].status not in (1, 2)
+    x, _, info, viol = qp.solve_elastic()
+    assert info.status in (1, 2) and viol <= 0.0125 - 0.0005
+    params = native.CParams(*[float(v) for v in w], 3)
+    cost, traj, ctrl = native.find_traj_mem(variant, params, knots.parse_corridor_file(path), cap=4096)
+    st, v = native.find_traj_last_status()
+    assert cost < 1e10 and st == 2 and len(ctrl) == 12 * n, (st, v)
+    assert np.abs(ctrl - x).max() <= 1e-4 * np.abs(x).max(), np.abs(ctrl - x).max() / np.abs(x).max()
+    os.environ["BTRAPZ_ELASTIC"] = "0"                      # strict mode: refused, as the exact solve refuses it
+    try:
+        assert native.find_traj_mem(variant, params, knots.parse_corridor_file(path), cap=4096)[0] >= 1e10
+    finally:
+        del os.environ["BTRAPZ_ELASTIC"]
