@@ -19,4 +19,5 @@ done
 timeout -k 10 600 python tests/fuzz/prisms_vs_restatement.py 5 3000 > "$OUT/prisms.log" 2>&1; tail -n 2 "$OUT/prisms.log"
 timeout -k 10 900 python tests/fuzz/warm_start_vs_oracle.py 4096 > "$OUT/warm_start.log" 2>&1; tail -n 3 "$OUT/warm_start.log"
 timeout -k 10 300 python tests/fuzz/fused_vs_two_launches.py 1 200 > "$OUT/fused_corridors.log" 2>&1; tail -n 1 "$OUT/fused_corridors.log"
+timeout -k 10 600 python tests/fuzz/corridors_vs_oracle.py 100 10 > "$OUT/corridors.log" 2>&1; tail -n 1 "$OUT/corridors.log"
 timeout -k 10 1200 python tests/fuzz/bench_batches_vs_oracle.py 65536 16 > "$OUT/bench_batches.log" 2>&1; tail -n 6 "$OUT/bench_batches.log"
