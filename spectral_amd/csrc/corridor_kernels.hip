@@ -11,8 +11,11 @@
 // The serial statements of corridor_core.h (what the host driver runs) remain the fallback for the shapes the
 // wave-wide code does not take (slope table larger than 24 KB, more than 64 base segments) and give the same
 // segments bit for bit.  This is the one stage of the path that streams HBM: num_obs * N * 4 doubles per candidate
-// (11 KB at N = 71, 5 obstacles); it runs on latency (wavefronts per CU x round trips per candidate), hence the LDS
-// overlays and the 4-wavefronts-per-SIMD register budget below.
+// (11 KB at N = 71, 5 obstacles); it runs on instruction issue and dependent latency (~1 700 vector and ~1 300 scalar
+// instructions per candidate, profiles/r03_corridor_pmc.json), so resident wavefronts pay: hence the LDS overlays, the
+// first-pass instantiations without the serial statement (52-60 registers) and the list sizes the host chooses.
+// The prism_ instantiations evaluate the bounds from the scene's obstacle prisms instead of reading them
+// (btrapz_prism_corridor_batch_device: prism_bounds_kernel + this kernel in one launch, same bits).
 // References: src/solve_3d.cc:323-486,488-714,729-772,835-845,1159-1166 ; src/cuboid_3d.cc:301-573.
 #include <hip/hip_runtime.h>
 
