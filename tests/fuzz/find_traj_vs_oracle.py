@@ -67,7 +67,8 @@ for it in range(count):
                 x, _, info, viol = qp.solve_elastic()
                 if abs(viol - 0.0125) < 0.0005: skipped = True
                 want_accept = info.status in (1, 2) and viol <= 0.0125
-                tol_x = 1e-4
+                tol_x = 1e-4 if info.status == 1 else 1e-3   # (status 2: the oracle's own relaxed solve stopped at ITS accuracy floor -- its x is not x*;
+                                                             #  seen once in 120 000 calls: 20 segments of 0.1-0.2 s, 64 obstacles, 1.9e-4 apart)
             if want_accept:   # the reference's CHECK_EQ(var_index, num_of_points_) (solve_3d.cc:1407) aborts: a failure here
                 rc, smp = O.sample(cubes, inp.delta, x, inp.init_s, inp.init_l)
                 want_accept = rc == 0
