@@ -150,12 +150,13 @@ enum {
   BTRAPZ_NUM_SEG_FIELDS
 };
 #define BTRAPZ_MAX_SEGMENTS 64
-/* Uniform cold batches (btrapz_solve_batch_device / _host without rescue pass) and find_traj take up to this many
- * segments per candidate: beyond 64 a candidate is solved by a workgroup of several wavefronts (same method, same
- * result, much slower per segment -- the reference has no limit, its bundled inputs have at most 14).  Ragged
- * batches, warm starts and the rescue pass stay at BTRAPZ_MAX_SEGMENTS. */
+/* Uniform cold batches (btrapz_solve_batch_device / _host) and find_traj take up to this many segments per candidate:
+ * beyond 64 a candidate is solved by a workgroup of several wavefronts (same method, same result, much slower per
+ * segment -- the reference has no limit, its bundled inputs have at most 14).  The rescue pass (btrapz_options.elastic
+ * = 1) follows up to BTRAPZ_MAX_SEGMENTS_LONG_RESCUE segments (three wavefronts: a fourth's LDS does not fit);
+ * ragged batches, warm starts and elastic = 2 stay at BTRAPZ_MAX_SEGMENTS. */
 #define BTRAPZ_MAX_SEGMENTS_LONG 256
-#define BTRAPZ_MAX_SEGMENTS_LONG_RESCUE 192 /* ... with a rescue pass (btrapz_options.elastic) behind it: three wavefronts */
+#define BTRAPZ_MAX_SEGMENTS_LONG_RESCUE 192
 
 /* Weights (Params) and limits (input-file header, trp_wrapper.cpp:59-64) shared by all
  * candidates of a batch. */
@@ -220,8 +221,11 @@ typedef struct btrapz_options {
    * (or still iterating four iterations later) hands its iterate over; the second launch carries those candidates on from
    * exactly where they stopped, like with like and the far-from-converged first -- same iterates, same results bit for
    * bit, but no wavefront runs at a third of its width for one slow candidate and no slow candidate starts last
-   * (-9 % on the scenario_1 bench batch).  0 -> automatic (6 for batches of 16..64 segments that fill
-   * the device at least eight times over); > 0 -> that many iterations, any uniform cold batch; -1 -> never. */
+   * (-9 % on the scenario_1 bench batch).  0 -> automatic (6 for uniform batches of 16..64 segments
+   * that fill the device at least eight times over; never for ragged batches); > 0 -> that many iterations, any cold
+   * batch -- a ragged one too (btrapz_solve_ragged_device: its second launch re-packs by segment count; it pays where
+   * iteration counts spread widely, e.g. a quarter of the candidates infeasible: -9 %, and costs up to 10 % where
+   * they do not); -1 -> never. */
   int cap_iter;
 } btrapz_options;
 /* Zeroes *opt (every field: "use the default") and sets struct_size.  Call it before filling the struct in. */

@@ -26,6 +26,8 @@
 // which lanes s and S-1-s own the pivots.  HBM is touched once to load the Cube records and once to store results.
 // Split form (few candidates, at most 21 segments; SPLIT in ipm_solve_body): ONE axis problem per wavefront, the rows
 // of every segment spread over three lanes, state in registers only, one scalar per row and phase exchanged through LDS.
+// Long form (65..256 segments; MULTI): one axis problem per workgroup of up to four wavefronts.  Large cold batches run
+// as two launches (CAPPED / RESUME): groups left alone in their wavefront hand their iterate over and are re-packed.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -293,7 +295,8 @@ __device__ __forceinline__ Red4 reduce4(double (*red)[64], double *wgs, int lane
 // SUSPENDS: it writes its iterate (joint states, slacks, multipliers, best iterate and the termination bookkeeping:
 // SUSP_FIELDS doubles per lane) to a slot of a.susp_state and reports BTRAPZ_SUSPENDED -- and the RESUME launch picks
 // the suspended axis problems up from per-axis lists, bucketed by how far from convergence they were (the machinery of
-// the rescue pass), restores the iterate and carries on: the same iterates, bit for bit, as the one-launch solve.
+// the rescue pass; ragged batches: by segment count), restores the iterate and carries on: the same iterates, bit for
+// bit, as the one-launch solve.
 enum { SUSP_FIELDS = 3 + 4 * 15 + 3 + 8 };
 template <bool WARM, bool ORDERED, bool ELASTIC = false, bool QUEUE = false, bool SPLIT = false, bool MULTI = false,
           bool CAPPED = false, bool RESUME = false>
