@@ -23,7 +23,6 @@ double parse_double(const char *p, const char **end) {
                                  1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
   const char *q = p;
   while (*q == ' ' || *q == '\n' || *q == '\t' || *q == '\r' || *q == '\f' || *q == '\v') ++q;
-  const char *tok = q;
   bool neg = false;
   if (*q == '+' || *q == '-') { neg = *q == '-'; ++q; }
   unsigned long long mant = 0;
@@ -59,7 +58,6 @@ double parse_double(const char *p, const char **end) {
     *end = e;
     return v;
   }
-  (void)tok;
   double v = (double)mant;                       // exact: below 1e15
   v = scale < 0 ? v / P10[-scale] : v * P10[scale];
   *end = q;
