@@ -43,6 +43,15 @@ def test_bad_arguments_are_reported_not_fatal():
                                             p(o["cost"]), p(o["cost"]), None) == EINVAL                     # N < 3
     assert lib.btrapz_corridor_batch_device(h, 0, 8, 71, 65, C.c_double(0.1), *[p(o["cost"])] * 6, 16, p(o["cost"]),
                                             p(o["status"]), p(o["cost"]), p(o["cost"]), None) == EINVAL     # num_obs > 64
+    # the fused prism + corridor entry point: the limits of the two calls it replaces
+    road = native.CRoad.reference()
+    pc = lambda P, N, O: lib.btrapz_prism_corridor_batch_device(h, 0, 8, P, N, C.byref(road), p(o["cost"]), O, C.c_double(0.1), *[p(o["cost"])] * 4,
+                                                                16, p(o["cost"]), p(o["status"]), p(o["cost"]), p(o["cost"]), None, None)
+    assert pc(17, 71, 5) == EINVAL and pc(0, 71, 5) == EINVAL          # 1..16 cars
+    assert pc(2, 2, 5) == EINVAL and pc(2, 513, 5) == EINVAL           # 3..512 knots
+    assert pc(2, 71, 0) == EINVAL and pc(2, 71, 65) == EINVAL          # 1..64 strips
+    assert lib.btrapz_prism_corridor_batch_device(h, 0, 8, 2, 71, None, p(o["cost"]), 5, C.c_double(0.1), *[p(o["cost"])] * 4, 16, p(o["cost"]),
+                                                  p(o["status"]), p(o["cost"]), p(o["cost"]), None, None) == EINVAL   # no road
     assert lib.btrapz_destroy(None) == EINVAL
     # the context still works, and gives the same answer
     o2 = solver.solve(db, sh)
