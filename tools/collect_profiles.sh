@@ -65,6 +65,10 @@ if [ "$QUICK" != "quick" ]; then
   step pipeline "$OUT/pipeline.json" python3 "$ROOT/tools/pipeline_bench.py"
   step pipeline_s1 "$OUT/pipeline_scenario1.json" python3 "$ROOT/tools/pipeline_bench.py" --scenario1
   step pipeline_prisms "$OUT/pipeline_prisms.json" python3 "$ROOT/tools/pipeline_bench.py" --prisms
+  # the ragged solve in two launches (btrapz_options.cap_iter = 8; on request only: DESIGN 3.8)
+  step pipeline_cap8 "$OUT/pipeline_cap8.json" python3 "$ROOT/tools/pipeline_bench.py" --cap 8
+  step pipeline_s1_cap8 "$OUT/pipeline_scenario1_cap8.json" python3 "$ROOT/tools/pipeline_bench.py" --scenario1 --cap 8
+  step pipeline_prisms_cap8 "$OUT/pipeline_prisms_cap8.json" python3 "$ROOT/tools/pipeline_bench.py" --prisms --cap 8
   step trace_pipeline "$OUT/pipeline_under_rocprof.json" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_pipeline" -- \
     python3 "$ROOT/tools/pipeline_bench.py"
   step bench_config2 "$OUT/bench_config2.json" python3 "$BENCH" --segments 10 --batch 4096 --no-cpu-baseline

@@ -32,6 +32,9 @@ def main(argv=None):
     ap.add_argument("--prisms", action="store_true",
                     help="start one stage earlier (SURVEY 8f rank 4): B scenes of two obstacle prisms (the harness's "
                          "constellation, cart_frenet.py:1536-1546, jittered) -> btrapz_prism_bounds_device -> corridors -> QP")
+    ap.add_argument("--cap", type=int, default=0,
+                    help="btrapz_options.cap_iter of the ragged solve (0: the library's choice = one launch; n > 0: two launches, "
+                         "hand-over after n iterations; DESIGN 3.8)")
     a = ap.parse_args(argv)
     import torch
     from spectral_amd import knots, synth, layout as L
@@ -89,12 +92,12 @@ def main(argv=None):
                                          rec["ref_end"], rec["dl_bounds"], stream=stream)
 
     for _ in range(2):
-        corridors(); out = solver.solve_ragged(rec, sh)
+        corridors(); out = solver.solve_ragged(rec, sh, cap_iter=a.cap)
     torch.cuda.synchronize()
     tc, ts = [], []
     for _ in range(a.reps):
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        e0.record(); corridors(); e1.record(); out = solver.solve_ragged(rec, sh); e2.record()
+        e0.record(); corridors(); e1.record(); out = solver.solve_ragged(rec, sh, cap_iter=a.cap); e2.record()
         torch.cuda.synchronize()
         tc.append(e0.elapsed_time(e1)); ts.append(e1.elapsed_time(e2))
     fused_ms = None
@@ -134,7 +137,7 @@ def main(argv=None):
     result = {**extra,
         "workload": "%s (N = %d knots, %d obstacles), %s constraints" %
                     (label, kb.N, kb.num_obs, "trapezoid" if a.variant == 0 else "cuboid"),
-        "corridor_ms": c_ms, "ragged_solve_ms": s_ms, "end_to_end_candidates_per_s": B / (c_ms + s_ms) * 1e3,
+        "corridor_ms": c_ms, "ragged_solve_ms": s_ms, "ragged_solve_cap_iter": a.cap, "ragged_solve_form": solver.ctx.last_solve_form(), "end_to_end_candidates_per_s": B / (c_ms + s_ms) * 1e3,
         "segments_per_candidate": {int(k): int(v) for k, v in zip(*np.unique(cnt, return_counts=True))},
         "solved_fraction": float(np.mean((status == 1) | (status == 2))),
         "corridor_roofline": {"bound": "hbm", "kernel": "btrapz::corridor_batch_kernel", "kernel_ms": c_ms,
