@@ -95,6 +95,7 @@ def main():
         if pstats:
             shutil.copy(max(pstats, key=os.path.getmtime), os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
     for name in ("mpc_warm", "mpc_cold", "mpc_warm_minfirst05", "mpc_cold_minfirst05", "pipeline", "pipeline_scenario1", "pipeline_prisms",
+                 "pipeline_cap8", "pipeline_scenario1_cap8", "pipeline_prisms_cap8", "cap_bench",
                  "bench_config2", "bench_config4", "bench_generic", "bench_2rank_gloo_strong", "split_bench", "mpc_warm_2rank_gloo"):
         if os.path.exists(os.path.join(src, name + ".json")):
             # the tools print ONE JSON line; libraries may print before it (gloo announces its ranks on stdout)
