@@ -940,7 +940,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     const double rd_eff = fmax(rr.b - 2e-13 * rr.d, 0.0);
     const double res = fmax(rd_eff / (1.0 + qn), rr.c / (1.0 + bnorm));
     const double score = fmax(res, mu);
-    const bool feasible_and_complementary = fmax(mu, rr.c / (1.0 + bnorm)) < 1e-7;   // (only the dual residual is left: see the dual floor below)
+    const double mu_primal = fmax(mu, rr.c / (1.0 + bnorm));
+    const bool feasible_and_complementary = mu_primal < 1e-7;   // (only the dual residual is left: see the dual floor below)
 #ifdef BTRAPZ_TRACE   // debugging aid: one line per iteration and axis problem (tools: build with -DBTRAPZ_TRACE)
     if (first && lane_in_group && valid && !done && gl == 0) printf("trace axis %d b %d eit %d score %.3e res %.3e (dual %.3e primal %.3e) mu %.3e best %.3e@%d res_it %d | rd %.3e dscale %.3e qn %.3e bnorm %.3e\n", axis, b, eit, score, res, rd_eff / (1.0 + qn), rr.c / (1.0 + bnorm), mu, best_score, best_it, res_it, rr.b, rr.d, qn, bnorm);
 #endif
@@ -967,7 +968,13 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       //  1e-4 for three iterations -- the accuracy of the block elimination on a badly scaled corridor (a 0.1 s segment
       //  among 1 s ones), not of the iterate's position: "solved inaccurate", instead of iterating on until the slacks
       //  underflow.  Found by the round-3 fuzz campaign: 1 call in 16 000.)
-      const bool at_floor = best_score < (feasible_and_complementary ? 1e-4 : 1e-5) && eit - best_it >= 3;
+      // (the Newton floor: below 1e-7 -- "solved" whatever follows -- with complementarity and feasibility a hundred
+      //  times smaller than the score, the score IS the dual residual and the iteration a pure Newton step, which
+      //  squares the residual or, at the accuracy of the block elimination, leaves it where it is.  An iterate that
+      //  does not improve on such a best one ends the solve at once instead of after three: the typical scenario_1
+      //  solve reached 2e-9 at iteration 6 and spent iterations 7-9 finding that out.)
+      const int patience = (best_score < 1e-7 && mu_primal < 1e-2 * best_score) ? 1 : 3;   // iterations without a better score
+      const bool at_floor = best_score < (feasible_and_complementary ? 1e-4 : 1e-5) && eit - best_it >= patience;
       if (at_floor && feasible_and_complementary) res_it = -1;   // (the mark write_back reads: the stall bookkeeping is over)
       if (score < eps || at_floor) done = true;
       else if (WARM && !restarted && (stalled || (eit - it0 >= 12 && best_score > 1e-4) || eit - it0 >= 24)) restart_now = true;

@@ -302,6 +302,9 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   btrapz_options opt1;
   btrapz_options_init(&opt1);
   if (const char *mi = getenv("BTRAPZ_MAX_ITER")) opt1.max_iter = atoi(mi);   // (experiments: cost per iteration)
+  // BTRAPZ_EPS: the solve's tolerance (btrapz_options.eps; default 1e-9, control points within ~2e-6 of x*).  The
+  // reference's OSQP runs at 1e-5; 1e-6 saves about one iteration per call ("Tolerance").
+  if (const char *ep = getenv("BTRAPZ_EPS")) { const double v = atof(ep); if (v > 0.0 && v < 1e-2) opt1.eps = v; }
   if (long_form) {
     h_status[0] = BTRAPZ_MAX_ITER_REACHED;   // (nothing solved yet: the block below does it, without the rescue rows)
   } else
