@@ -973,7 +973,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       //  squares the residual or, at the accuracy of the block elimination, leaves it where it is.  An iterate that
       //  does not improve on such a best one ends the solve at once instead of after three: the typical scenario_1
       //  solve reached 2e-9 at iteration 6 and spent iterations 7-9 finding that out.)
-      const int patience = (best_score < 1e-7 && mu_primal < 1e-2 * best_score) ? 1 : 3;   // iterations without a better score
+      // (not in the rescue pass: the relaxed problem's x moves by 1e-3 while its score moves from 5e-9 to 1e-9)
+      const int patience = (!ELASTIC && best_score < 1e-7 && mu_primal < 1e-2 * best_score) ? 1 : 3;   // iterations without a better score
       const bool at_floor = best_score < (feasible_and_complementary ? 1e-4 : 1e-5) && eit - best_it >= patience;
       if (at_floor && feasible_and_complementary) res_it = -1;   // (the mark write_back reads: the stall bookkeeping is over)
       if (score < eps || at_floor) done = true;
