@@ -227,6 +227,12 @@ typedef struct btrapz_options {
    * iteration counts spread widely, e.g. a quarter of the candidates infeasible: -9 %, and costs up to 10 % where
    * they do not); -1 -> never. */
   int cap_iter;
+  /* Cold solves of at most 64 segments (uniform or ragged batches, one launch or the two of cap_iter): the form of the
+   * solve kernel that runs TWO wavefronts per SIMD -- the same iteration on half the per-lane state (slacks in registers,
+   * multipliers in LDS, everything else recomputed: btrapz_lean.hip).  Same problem, same method, same termination rules;
+   * results agree with the one-wavefront form to rounding.  0 -> automatic; 1 -> whenever the solve qualifies;
+   * -1 -> never.  (Warm starts, the rescue pass, start = 1 and the candidate queue always run the one-wavefront form.) */
+  int lean;
 } btrapz_options;
 /* Zeroes *opt (every field: "use the default") and sets struct_size.  Call it before filling the struct in. */
 void btrapz_options_init(btrapz_options *opt);
@@ -265,7 +271,8 @@ int btrapz_rescue_violations_device(btrapz_ctx *ctx, int B, double *viol, void *
 
 /* Which form of the solve kernel the context's last batched solve ran (scheduling only; results do not depend on it):
  * 0 packed (floor(64/S) candidates per wavefront), 1 split (btrapz_options.split), 2 long (65..256 segments),
- * 3 capped first launch + resume launch (btrapz_options.cap_iter), 4 candidate queue (btrapz_options.queue); -1 none yet. */
+ * 3 capped first launch + resume launch (btrapz_options.cap_iter), 4 candidate queue (btrapz_options.queue); -1 none yet.
+ * + 8 when the launch(es) ran the two-wavefronts-per-SIMD form (btrapz_options.lean). */
 int btrapz_last_solve_form(const btrapz_ctx *ctx);
 
 /* Arg-min of cost over contiguous groups of `group` candidates (B % group == 0).

@@ -56,6 +56,8 @@ using namespace btrapz;
 // its own unit and accepted 0.5 of it: the least-squares solution then leaves c7's lateral corridor by 0.09 m.)
 #define BTRAPZ_DEFAULT_ELASTIC_DELTA 1e-8
 #define BTRAPZ_DEFAULT_ELASTIC_TOL 0.0125
+// btrapz_options.lean = 0: whether the two-wavefronts-per-SIMD form is the automatic choice where it applies
+#define BTRAPZ_LEAN_AUTOMATIC 0
 
 struct btrapz_ctx {
   int device = 0;
@@ -413,6 +415,11 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     // 9.56 -> 9.79; two-car scenes, 7-9 segments, all feasible 3.21 -> 3.54 -- it pays where iteration counts spread
     // widely, which the library does not know.
     int cap_iter = cap_env > 0 ? cap_env : cap_env == 0 ? -1 : (opt ? opt->cap_iter : 0);   // BTRAPZ_CAP=0: never
+    // Two wavefronts per SIMD (btrapz_options.lean / BTRAPZ_LEAN; btrapz_lean.hip): cold solves of at most 64 segments
+    static const int lean_env = [] { const char *q = getenv("BTRAPZ_LEAN"); return q ? (*q == '0' ? -1 : 1) : 0; }();
+    const int lean_opt = lean_env ? lean_env : (opt ? opt->lean : 0);
+    const bool lean_ok = !warm_kernel && !long_form && !split_on && !queue_on && S >= 3 && S <= BTRAPZ_MAX_SEGMENTS && a.unc_start == 0;   // (S <= 2: the root of the elimination is an end lane -- the packed form has the fix-up)
+    const bool lean_on = lean_ok && (lean_opt > 0 || (lean_opt == 0 && BTRAPZ_LEAN_AUTOMATIC));
     const bool ragged = seg_count != nullptr;
     if (cap_iter == 0 && !ragged && S >= 16 && blocks >= 8u * (unsigned)c->resident_waves) cap_iter = 6;
     const bool capped = cap_iter > 0 && !long_form && !split_on && (!a.order || ragged) && !warm_kernel && !queue_on && S <= BTRAPZ_MAX_SEGMENTS &&
@@ -448,8 +455,13 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       static const int cap_hi_env = [] { const char *q = getenv("BTRAPZ_CAP_HI"); return q ? atoi(q) : 4; }();
       p1.cap_iter = cap_iter; p1.cap_alone = cap_alone_env; p1.cap_hi = cap_iter + cap_hi_env; p1.susp_cap = (int)slots; p1.susp_state = c->d_susp_state; p1.susp_count = count;
       p1.susp_slot = slot_of; p1.susp_key = keys;
-      if (ragged) hipLaunchKernelGGL(ipm_solve_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
-      else hipLaunchKernelGGL(ipm_solve_capped_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+      if (lean_on) {
+        if (ragged) hipLaunchKernelGGL(ipm_lean_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+        else hipLaunchKernelGGL(ipm_lean_capped_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+      } else {
+        if (ragged) hipLaunchKernelGGL(ipm_solve_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+        else hipLaunchKernelGGL(ipm_solve_capped_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+      }
       int *lists = c->d_rescue + 2 * (size_t)B;
       const unsigned nb = (unsigned)((B + 255) / 256);
       const int list_S = ragged ? 0 : -S;   // ragged: keys are segment counts; uniform: convergence classes, 0 = not listed
@@ -466,8 +478,9 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       p2.bucket_S = ragged ? 0 : S;
       // (ragged: no candidate has more than min(S, 64) segments, so no wavefront holds fewer groups than that allows)
       const unsigned rblocks = 2u * (unsigned)(slots / (size_t)(64 / (S < 64 ? S : 64)) + 65);
-      hipLaunchKernelGGL(ipm_solve_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
-      c->last_form = 3;
+      if (lean_on) hipLaunchKernelGGL(ipm_lean_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
+      else hipLaunchKernelGGL(ipm_solve_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
+      c->last_form = lean_on ? 11 : 3;
     } else if (long_form) {
       c->last_form = 2;
       hipLaunchKernelGGL(ipm_solve_long_kernel, dim3(2u * (unsigned)B), dim3(64u * (unsigned)((S + 63) / 64)), 0, stream, a,
@@ -480,6 +493,10 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       c->last_form = 4;
       hipLaunchKernelGGL(ipm_solve_queue_kernel, dim3((unsigned)c->resident_waves & ~1u), dim3(64), 0, stream, a,
                          (const double *)c->d_mqm);
+    } else if (lean_on) {
+      c->last_form = 8;
+      if (a.order) hipLaunchKernelGGL(ipm_lean_ordered_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
+      else hipLaunchKernelGGL(ipm_lean_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
     } else {
       c->last_form = 0;
       hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);

@@ -1,0 +1,230 @@
+// btrapz_ipm.h -- device helpers shared by the solve kernels (btrapz_kernels.hip: the packed / split / long forms and
+// their warm-start, rescue and capped instantiations; btrapz_lean.hip: the two-wavefronts-per-SIMD form): reciprocals,
+// DPP lane shifts, the constraint rows of a segment, the null-space maps, 3x3 LDL^T, group reductions.
+#ifndef BTRAPZ_IPM_H
+#define BTRAPZ_IPM_H
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "btrapz_device.h"
+
+namespace btrapz {
+
+#define UNROLL _Pragma("unroll")
+#define SYM(i, j) ((j) * ((j) + 1) / 2 + (i))  // i <= j, packed upper triangle, column-wise
+
+// 1/x: v_rcp_f64 seed (measured 4.6e-8 relative on gfx950) + one Newton step -> 2.2e-15.  No
+// denormal / overflow fix-ups: every operand here is a positive slack, multiplier or pivot.
+__device__ __forceinline__ double rcp(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
+// seed only: good to 5e-8, enough for step-length ratios (they carry a 0.5 % safety factor).
+__device__ __forceinline__ double rcp_fast(double x) { return __builtin_amdgcn_rcp(x); }
+
+// lane i <- lane i-1 / lane i+1 over the whole wavefront (DPP wave_shr:1 / wave_shl:1, bound_ctrl: the lane
+// without a source reads 0, so the destination needs no initialisation).
+__device__ __forceinline__ double dpp_prev(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_next(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// ---- constraint rows of one segment (solve_3d.cc:823-888): 6 pos, 5 vel, 4 acc, 3 jerk ----
+// row r: first column, number of columns, coefficients (position rows carry the runtime t).
+__host__ __device__ constexpr int row_col0(int r) { return r < 6 ? r : r < 11 ? r - 6 : r < 15 ? r - 11 : r - 15; }
+__host__ __device__ constexpr int row_nnz(int r) { return r < 6 ? 1 : r < 11 ? 2 : r < 15 ? 3 : 4; }
+__host__ __device__ constexpr double row_coef(int r, int j) {
+  return r < 6 ? 1.0 : r < 11 ? (j == 0 ? -5.0 : 5.0) : r < 15 ? (j == 1 ? -40.0 : 20.0)
+                                                              : (j == 0 ? -60.0 : j == 1 ? 180.0 : j == 2 ? -180.0 : 60.0);
+}
+template <int R> __device__ __forceinline__ double row_dot(const double (&c)[6], double t) {
+  if constexpr (R < 6) return t * c[R];
+  else if constexpr (R < 11) return 5.0 * (c[R - 5] - c[R - 6]);
+  else if constexpr (R < 15) return 20.0 * ((c[R - 11] - 2.0 * c[R - 10]) + c[R - 9]);
+  else return 60.0 * ((c[R - 12] - c[R - 15]) + 3.0 * (c[R - 14] - c[R - 13]));
+}
+template <int R> __device__ __forceinline__ void row_scatter(double v, double t, double (&o)[6]) {  // o += G_r' v
+  if constexpr (R < 6) o[R] += t * v;
+  else {
+    UNROLL for (int j = 0; j < row_nnz(R); j++) o[row_col0(R) + j] += row_coef(R, j) * v;
+  }
+}
+template <int R> __device__ __forceinline__ void row_outer(double w, double t2, double (&H)[21]) {  // H += w G_r' G_r
+  if constexpr (R < 6) H[SYM(R, R)] += t2 * w;
+  else {
+    UNROLL for (int a = 0; a < row_nnz(R); a++)
+      UNROLL for (int b = a; b < row_nnz(R); b++)
+        H[SYM(row_col0(R) + a, row_col0(R) + b)] += (row_coef(R, a) * row_coef(R, b)) * w;
+  }
+}
+// Stops the optimiser from carrying row-sized temporaries (G c, residuals, LDS reloads) from one
+// row loop to the next: recomputing them is cheap, keeping 9 x 18 doubles alive spills to scratch.
+__device__ __forceinline__ void opaque6(double (&v)[6]) {
+  UNROLL for (int i = 0; i < 6; i++) asm volatile("" : "+v"(v[i]));
+}
+// First statement of a block guarded by a wave-uniform condition: keeps the block a real (scalar) branch -- the
+// optimiser would otherwise turn the rare path into selects executed on every pass.
+#define UNIFORM_BLOCK asm volatile("")
+#define PHASE_FENCE(...) do { asm volatile("" ::: "memory"); __VA_ARGS__; } while (0)
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+// Rows kept by a solve.  FULL: all 18 rows of a segment, as the reference assembles them.  Otherwise 15: the first
+// position, velocity and acceleration row of a segment (rows 0, 6, 11) state, about the joint at its start, what the
+// previous segment's last rows (5, 10, 14) state about the same joint from the other side -- t c_{k,5} = t' c_{k+1,0},
+// equal end / start velocities and accelerations are the continuity equalities (solve_3d.cc:918-949).  Two bounds on
+// one quantity are one bound: the previous lane keeps the row with the intersection, this lane drops it -- same
+// feasible set, same optimum, a sixth less row work and state.  (Segment 0's start rows constrain the given initial
+// state, a constant: checked once.)  The rescue pass counts violations row by row and keeps all 18.
+template <bool FULL> __host__ __device__ constexpr int rows_kept() { return FULL ? 18 : 15; }
+template <bool FULL> __host__ __device__ constexpr int row_id(int i) {   // i-th kept row -> row of the segment
+  return FULL ? i : (i < 5 ? i + 1 : i < 9 ? i + 2 : i < 12 ? i + 3 : i + 3);
+}
+template <bool FULL> __host__ __device__ constexpr int state_index(int r) {   // row of the segment -> slot in the state arrays
+  return FULL ? r : (r < 6 ? r - 1 : r < 11 ? r - 2 : r < 15 ? r - 3 : r - 3);
+}
+template <bool FULL> __host__ __device__ constexpr int next_row(int r) {      // the kept row after r, -1 after the last
+  return r >= 17 ? -1 : (FULL ? r + 1 : (r + 1 == 6 || r + 1 == 11) ? r + 2 : r + 1);
+}
+// Split form (SPLIT in ipm_solve_body): which lane group j = 0..2 owns row r of a segment, and in which of its five
+// slots.  Slot 0: jerk row 15 + j; 1: acceleration row 12 + j; 2: velocity row 7 + j; 3: position row 1 / 3 / 5;
+// 4: position row 2 / 4 for j = 0 / 1, velocity row 10 for j = 2 (rows 0, 6, 11 are not kept: rows_kept).
+__host__ __device__ constexpr int split_owner_j(int r) {
+  return r >= 15 ? r - 15 : r >= 12 ? r - 12 : (r >= 7 && r <= 9) ? r - 7 : r == 10 ? 2 : (r & 1) ? (r - 1) / 2 : (r - 2) / 2;
+}
+__host__ __device__ constexpr int split_owner_slot(int r) {
+  return r >= 15 ? 0 : r >= 12 ? 1 : (r >= 7 && r <= 9) ? 2 : r == 10 ? 4 : (r & 1) ? 3 : 4;
+}
+#define FOR_ROWS(r) static_for<NR>([&](auto r##_c) { constexpr int r = row_id<FULL>(decltype(r##_c)::value);
+#define END_ROWS });
+#define SI(r) state_index<FULL>(r)
+
+// Null-space maps.  X = (p, v, a) physical state at a joint; segment duration t.
+//   start of segment:  c0 = p/t, c1 = c0 + v/5, c2 = c0 + 2v/5 + a t/20
+//   end of segment:    c5 = p/t, c4 = c5 - v/5, c3 = c5 - 2v/5 + a t/20
+// (the inverse of the reference's equality rows solve_3d.cc:896-949).
+struct NullMap { double it, t20; };
+__device__ __forceinline__ void U_apply(const NullMap m, const double (&X)[3], double &c0, double &c1, double &c2) {
+  c0 = m.it * X[0]; c1 = c0 + 0.2 * X[1]; c2 = c0 + 0.4 * X[1] + m.t20 * X[2];
+}
+__device__ __forceinline__ void V_apply(const NullMap m, const double (&X)[3], double &c3, double &c4, double &c5) {
+  c5 = m.it * X[0]; c4 = c5 - 0.2 * X[1]; c3 = c5 - 0.4 * X[1] + m.t20 * X[2];
+}
+__device__ __forceinline__ void UT_apply(const NullMap m, double h0, double h1, double h2, double (&o)[3]) {
+  o[0] = m.it * ((h0 + h1) + h2); o[1] = 0.2 * h1 + 0.4 * h2; o[2] = m.t20 * h2;
+}
+__device__ __forceinline__ void VT_apply(const NullMap m, double h3, double h4, double h5, double (&o)[3]) {
+  o[0] = m.it * ((h3 + h4) + h5); o[1] = -0.4 * h3 - 0.2 * h4; o[2] = m.t20 * h3;
+}
+
+// ---- 3x3 SPD helpers: LDL^T factor F = (l10, l20, l21, 1/d0, 1/d1, 1/d2) ----
+__device__ __forceinline__ void ldl3(const double (&A)[6] /*00 01 02 11 12 22*/, double (&F)[6]) {
+  const double id0 = rcp(A[0]);
+  const double l10 = A[1] * id0, l20 = A[2] * id0;
+  const double d1 = A[3] - l10 * A[1];
+  const double id1 = rcp(d1);
+  const double e = A[4] - l20 * A[1];
+  const double l21 = e * id1;
+  const double d2 = A[5] - l20 * A[2] - l21 * e;
+  F[0] = l10; F[1] = l20; F[2] = l21; F[3] = id0; F[4] = id1; F[5] = rcp(d2);
+}
+__device__ __forceinline__ void ldl3_solve(const double (&F)[6], double b0, double b1, double b2, double &x0, double &x1, double &x2) {
+  const double z0 = b0, z1 = b1 - F[0] * z0, z2 = b2 - F[1] * z0 - F[2] * z1;
+  x2 = z2 * F[5];
+  x1 = z1 * F[4] - F[2] * x2;
+  x0 = z0 * F[3] - F[0] * x1 - F[1] * x2;
+}
+
+// ---- LDS: one 64-wide row per per-lane scalar; a lane only ever touches its own column ----
+// (row offsets: L_LL = 0, L_LU = NR, L_ISL = 2 NR, L_ISU = 3 NR, four reduction rows behind them)
+template <bool FULL> __host__ __device__ constexpr int lds_rows() { return 4 * rows_kept<FULL>() + 4; }
+
+// Reductions over the S lanes of a group: every lane publishes 4 values, then reads its
+// group's S entries in batches of RB (reads issued back to back, one wait per batch; fixed order
+// -> bit-reproducible).  OPn: 0 sum, 1 max, 2 min.
+struct Red4 { double a, b, c, d; };
+enum { RB = 10 };   // entries read per batch (pairs of lanes, see group_reduce): 20 segments = 1 batch
+template <int OP> __device__ __forceinline__ double red_init() { return OP == 0 ? 0.0 : OP == 1 ? -1e300 : 1e300; }
+// (max / min of values that come back from LDS or a DPP move carry a v_max_f64 x, x, x each -- IEEE-mode
+// canonicalisation the compiler cannot prove away, ~90 instructions per iteration.  Writing the instruction as inline
+// asm removes them and costs far more: the "v" constraints pin operands that now live in AGPRs and the allocator
+// answers with 476 B of scratch per lane, 5.57 -> 8.27 ms.  Measured, rejected.)
+template <int OP> __device__ __forceinline__ double red_op(double acc, double v, bool in_range) {
+  if constexpr (OP == 0) return acc + (in_range ? v : 0.0);   // padded slots repeat entry S-1: harmless for max/min
+  else if constexpr (OP == 1) return fmax(acc, v);
+  else return fmin(acc, v);
+}
+// One wavefront per workgroup and LDS operations of a wavefront complete in issue order, so publishing and
+// reading need no s_barrier and no wait in between: a wavefront-scope fence keeps the compiler from reordering.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int OP> __device__ __forceinline__ double pair_op(double v, bool has_next) {
+  const double n = dpp_next(v);
+  if constexpr (OP == 0) return v + (has_next ? n : 0.0);
+  else if constexpr (OP == 1) return has_next ? fmax(v, n) : v;
+  else return has_next ? fmin(v, n) : v;
+}
+// Every lane first combines its value with its right neighbour's (DPP, if that lane belongs to the same group), so
+// only the even lanes' entries have to be read back: half the LDS reads and half the combining operations.
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ Red4 group_reduce(double (*red)[64], int lane, int gbase, int k, int S, double v0, double v1,
+                                             double v2, double v3) {
+  const bool has_next = k + 1 < S;
+  v0 = pair_op<O0>(v0, has_next); v1 = pair_op<O1>(v1, has_next); v2 = pair_op<O2>(v2, has_next); v3 = pair_op<O3>(v3, has_next);
+  wave_lds_sync();
+  red[0][lane] = v0; red[1][lane] = v1; red[2][lane] = v2; red[3][lane] = v3;
+  wave_lds_sync();
+  Red4 r = {red_init<O0>(), red_init<O1>(), red_init<O2>(), red_init<O3>()};
+  const int n2 = (S + 1) >> 1;   // pairs (the last one may be a single lane)
+  for (int j0 = 0; j0 < n2; j0 += RB) {
+    double a[RB], b[RB], c[RB], d[RB];
+    UNROLL for (int u = 0; u < RB; u++) {
+      const int j = gbase + 2 * (j0 + u < n2 ? j0 + u : n2 - 1);
+      a[u] = red[0][j]; b[u] = red[1][j]; c[u] = red[2][j]; d[u] = red[3][j];
+    }
+    UNROLL for (int u = 0; u < RB; u++) {
+      const bool in = j0 + u < n2;
+      r.a = red_op<O0>(r.a, a[u], in); r.b = red_op<O1>(r.b, b[u], in);
+      r.c = red_op<O2>(r.c, c[u], in); r.d = red_op<O3>(r.d, d[u], in);
+    }
+  }
+  return r;
+}
+
+// Long form (MULTI in ipm_solve_body: more than 64 segments, one axis problem per WORKGROUP of up to four wavefronts):
+// the reduction goes over all the workgroup's lanes through a shared block rm[4][256] behind the 8 seam slots of wgs.
+enum { WGS_SEAM = 8, WGS_LANES = 256 };
+template <bool MULTI, int O0, int O1, int O2, int O3>
+__device__ __forceinline__ Red4 reduce4(double (*red)[64], double *wgs, int lane, int wv, int gbase, int k, int S, double v0,
+                                        double v1, double v2, double v3) {
+  if constexpr (!MULTI) {
+    return group_reduce<O0, O1, O2, O3>(red, lane, gbase, k, S, v0, v1, v2, v3);
+  } else {
+    double *rm = wgs + WGS_SEAM;
+    const int K = wv * 64 + lane;
+    __syncthreads();
+    rm[K] = v0; rm[WGS_LANES + K] = v1; rm[2 * WGS_LANES + K] = v2; rm[3 * WGS_LANES + K] = v3;
+    __syncthreads();
+    Red4 r = {red_init<O0>(), red_init<O1>(), red_init<O2>(), red_init<O3>()};
+    for (int j = 0; j < S; j++) {   // (fixed order: bit-reproducible; every lane reads the same addresses: broadcasts)
+      r.a = red_op<O0>(r.a, rm[j], true); r.b = red_op<O1>(r.b, rm[WGS_LANES + j], true);
+      r.c = red_op<O2>(r.c, rm[2 * WGS_LANES + j], true); r.d = red_op<O3>(r.d, rm[3 * WGS_LANES + j], true);
+    }
+    return r;
+  }
+}
+
+}  // namespace btrapz
+#endif

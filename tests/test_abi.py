@@ -54,11 +54,12 @@ def test_params_layout_is_the_reference_abi():
         assert P.iteration.offset == 80
     assert C.sizeof(native.CShared) == 21 * 8 + 8
     assert C.sizeof(native.CSegment) == 104
-    assert C.sizeof(native.COptions) == 72               # btrapz_options: two ints, three doubles, int (+pad), two doubles, three ints (+pad)
+    assert C.sizeof(native.COptions) == 80               # btrapz_options: two ints, three doubles, int (+pad), two doubles, five ints (+pad)
     assert native.COptions.struct_size.offset == 0 and native.COptions.max_iter.offset == 4
     assert native.COptions.elastic.offset == 32 and native.COptions.elastic_delta.offset == 48
     o = native.COptions(); o.max_iter = 7; native.lib().btrapz_options_init(C.byref(o))
-    assert (o.struct_size, o.max_iter, o.elastic, o.queue, o.split, o.start, o.cap_iter) == (72, 0, 0, 0, 0, 0, 0)
+    assert (o.struct_size, o.max_iter, o.elastic, o.queue, o.split, o.start, o.cap_iter, o.lean) == (80, 0, 0, 0, 0, 0, 0, 0)
+    assert native.COptions.cap_iter.offset == 68 and native.COptions.lean.offset == 72
     assert C.sizeof(native.CWarm) == 3 * 8 + 2 * 8 + 8   # btrapz_warm: three pointers, two doubles, one pointer
     assert [f[0] for f in native.CWarm._fields_] == ["x0", "lam0", "lam_out", "mu0", "smin", "hint"]
     assert C.sizeof(native.CTrajInput) == 2 * 4 + 8 + 6 * 8 + 2 * 8 + 8 * 8 + 6 * 8     # btrapz_traj_input
