@@ -203,6 +203,64 @@ __device__ __forceinline__ Red4 group_reduce(double (*red)[64], int lane, int gb
   return r;
 }
 
+// The same reduction with the maxima and minima through LDS atomics (ds_max_f64 / ds_min_f64 on the group's own entry:
+// order-independent, so the result is the one of the ordered loop, bit for bit) and only the sums through the ordered
+// reads -- a sum's rounding depends on its order.  OPn: 0 sum, 1 max, 2 min, -1 unused (returns 0).  Lanes outside
+// every group (the idle tail of a wavefront) take no part: their values are not those of a real segment.
+template <int OP> __device__ __forceinline__ void red_atomic(double *slot, double v) {
+  if constexpr (OP == 1) __hip_atomic_fetch_max(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  else if constexpr (OP == 2) __hip_atomic_fetch_min(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ Red4 group_reduce_mixed(double (*red)[64], int lane, int gbase, int k, int S, bool in_group,
+                                                   double v0, double v1, double v2, double v3) {
+  const bool has_next = k + 1 < S;
+  if constexpr (O0 == 0) v0 = pair_op<0>(v0, has_next);
+  if constexpr (O1 == 0) v1 = pair_op<0>(v1, has_next);
+  if constexpr (O2 == 0) v2 = pair_op<0>(v2, has_next);
+  if constexpr (O3 == 0) v3 = pair_op<0>(v3, has_next);
+  wave_lds_sync();
+  // sums: every lane's entry; maxima / minima: the entry of the group's first lane, set to the identity by that lane
+  if constexpr (O0 == 0) red[0][lane] = v0; else if constexpr (O0 > 0) { if (k == 0) red[0][lane] = red_init<O0>(); }
+  if constexpr (O1 == 0) red[1][lane] = v1; else if constexpr (O1 > 0) { if (k == 0) red[1][lane] = red_init<O1>(); }
+  if constexpr (O2 == 0) red[2][lane] = v2; else if constexpr (O2 > 0) { if (k == 0) red[2][lane] = red_init<O2>(); }
+  if constexpr (O3 == 0) red[3][lane] = v3; else if constexpr (O3 > 0) { if (k == 0) red[3][lane] = red_init<O3>(); }
+  wave_lds_sync();   // (LDS operations of a wavefront complete in issue order: the atomics see the identities)
+  if (in_group) {
+    if constexpr (O0 > 0) red_atomic<O0>(&red[0][gbase], v0);
+    if constexpr (O1 > 0) red_atomic<O1>(&red[1][gbase], v1);
+    if constexpr (O2 > 0) red_atomic<O2>(&red[2][gbase], v2);
+    if constexpr (O3 > 0) red_atomic<O3>(&red[3][gbase], v3);
+  }
+  wave_lds_sync();
+  Red4 r = {0.0, 0.0, 0.0, 0.0};
+  if constexpr (O0 > 0) r.a = red[0][gbase];
+  if constexpr (O1 > 0) r.b = red[1][gbase];
+  if constexpr (O2 > 0) r.c = red[2][gbase];
+  if constexpr (O3 > 0) r.d = red[3][gbase];
+  if constexpr (O0 == 0 || O1 == 0 || O2 == 0 || O3 == 0) {
+    const int n2 = (S + 1) >> 1;
+    for (int j0 = 0; j0 < n2; j0 += RB) {
+      double a[RB], b[RB], c[RB], d[RB];
+      UNROLL for (int u = 0; u < RB; u++) {
+        const int j = gbase + 2 * (j0 + u < n2 ? j0 + u : n2 - 1);
+        if constexpr (O0 == 0) a[u] = red[0][j];
+        if constexpr (O1 == 0) b[u] = red[1][j];
+        if constexpr (O2 == 0) c[u] = red[2][j];
+        if constexpr (O3 == 0) d[u] = red[3][j];
+      }
+      UNROLL for (int u = 0; u < RB; u++) {
+        const bool in = j0 + u < n2;
+        if constexpr (O0 == 0) r.a = red_op<0>(r.a, a[u], in);
+        if constexpr (O1 == 0) r.b = red_op<0>(r.b, b[u], in);
+        if constexpr (O2 == 0) r.c = red_op<0>(r.c, c[u], in);
+        if constexpr (O3 == 0) r.d = red_op<0>(r.d, d[u], in);
+      }
+    }
+  }
+  return r;
+}
+
 // Long form (MULTI in ipm_solve_body: more than 64 segments, one axis problem per WORKGROUP of up to four wavefronts):
 // the reduction goes over all the workgroup's lanes through a shared block rm[4][256] behind the 8 seam slots of wgs.
 enum { WGS_SEAM = 8, WGS_LANES = 256 };

@@ -343,7 +343,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     if (!(mu_part == mu_part) || !(rd_part == rd_part) || !(rp_part == rp_part) || !(dscale == dscale) ||
         !(fabs(rd_part) < 1e300) || !(fabs(mu_part) < 1e300))
       rp_part = 1e300;
-    const Red4 rr = group_reduce<0, 1, 1, 1>(lds + LN_RED, lane, gbase, k, S, mu_part, rd_part, rp_part, dscale);
+    const Red4 rr = group_reduce_mixed<0, 1, 1, 1>(lds + LN_RED, lane, gbase, k, S, lane_in_group, mu_part, rd_part, rp_part, dscale);
     const double mu = rr.a * inv_m;
     // ---- termination (the packed form's rules: DESIGN.md 3.4) ----
     {
@@ -573,7 +573,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         S1 += al + au;
         S4 += al * ql + au * qu;
       END_ROWS
-      const Red4 ra = group_reduce<0, 0, 1, 2>(lds + LN_RED, lane, gbase, k, S, S1, S4, qmax, qmin);
+      const Red4 ra = group_reduce_mixed<0, 0, 1, 2>(lds + LN_RED, lane, gbase, k, S, lane_in_group, S1, S4, qmax, qmin);
       const double ap = rcp(fmax(-ra.d, 1.0)), ad = rcp(fmax(1.0 + ra.c, 1.0));
       const double mua = ((1.0 - ad) * rr.a + (ap - ad - ap * ad) * ra.a - ap * ad * ra.b) * inv_m;
       const double sr = mua * rcp(mu);
@@ -611,16 +611,26 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       backward_u(u, dX, dc);
     }
     // ---- E. step to the boundary, then the step ----
+    // LEAN_E_CACHE: the corrected complementarity targets rc / s of the ratio pass kept for the update pass (60 registers
+    // the factorisation's blocks have just left) -- with the ordered reduction in between; without: recomputed there, and
+    // the two maxima go through LDS atomics.  (The register allocator does not survive both: measured)
+#ifndef LEAN_E_CACHE
+#define LEAN_E_CACHE 1
+#endif
     {
       double pr = 0.0, dr = 0.0;
-      double el_[NR], eu_[NR];   // rc / s of the corrected complementarity targets: the factorisation's blocks are dead by now
+#if LEAN_E_CACHE
+      double el_[NR], eu_[NR];
+#endif
       PHASE_FENCE(opaque6(c); opaque6(dca); opaque6(dc); fence_slacks());
       {
         ROW_LIMITS();
         FOR_ROWS(r)
           LROW(r, rcp)
           LROW_CORR(r)
+#if LEAN_E_CACHE
           el_[SI(r)] = el; eu_[SI(r)] = eu;
+#endif
           const double gd = row_dot<r>(dc, t);
           const double dsl = gd + rpl, dsu = -gd - rpu;
           const double dll = -el - wl * dsl, dlu = -eu - wu * dsu;
@@ -628,22 +638,34 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           dr = fmax(dr, fmax(-dll * rcp_fast(ll), -dlu * rcp_fast(lu)));
         END_ROWS
       }
+#if LEAN_E_CACHE
       const Red4 rs = group_reduce<0, 1, 1, 1>(lds + LN_RED, lane, gbase, k, S, 0.0, pr, dr, 0.0);
+#else
+      const Red4 rs = group_reduce_mixed<-1, 1, 1, -1>(lds + LN_RED, lane, gbase, k, S, lane_in_group, 0.0, pr, dr, 0.0);
+#endif
       const double m_ = fmax(rs.b, rs.c);
       const double tau = (m_ * a.tau_thr <= 1.0 && eit < a.tau_iters) ? a.tau : fmin(a.tau, 0.995);
       const double alpha = fmin(1.0, tau * rcp(fmax(m_, tau)));
       if (!done && alpha == alpha) {
+        UNROLL for (int i = 0; i < 3; i++) X[i] += alpha * dX[i];
+#if LEAN_E_CACHE
         PHASE_FENCE(opaque6(c); opaque6(dc); fence_slacks());
+#else
+        PHASE_FENCE(opaque6(c); opaque6(dca); opaque6(dc); fence_slacks());
+#endif
         ROW_LIMITS();
         FOR_ROWS(r)
           LROW(r, rcp)
-          const double wl = ll * isl, wu = lu * isu;
+#if LEAN_E_CACHE
+          const double wl = ll * isl, wu = lu * isu, el = el_[SI(r)], eu = eu_[SI(r)];
+#else
+          LROW_CORR(r)
+#endif
           const double gd = row_dot<r>(dc, t);
           const double dsl = gd + rpl, dsu = -gd - rpu;
           sl[SI(r)] = s_l + alpha * dsl; su[SI(r)] = s_u + alpha * dsu;
-          LL(r) = ll + alpha * (-el_[SI(r)] - wl * dsl); LU(r) = lu + alpha * (-eu_[SI(r)] - wu * dsu);
+          LL(r) = ll + alpha * (-el - wl * dsl); LU(r) = lu + alpha * (-eu - wu * dsu);
         END_ROWS
-        UNROLL for (int i = 0; i < 3; i++) X[i] += alpha * dX[i];
       }
     }
 #undef LROW
@@ -670,7 +692,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       const double qi = (qB + qA * (double)(i + 1)) + (i == 0 ? -qC : i == 5 ? qC + qend : 0.0);
       obj += c[i] * (0.5 * s + qi);
     }
-    const Red4 ro = group_reduce<0, 1, 1, 1>(lds + LN_RED, lane, gbase, k, S, obj, 0.0, 0.0, 0.0);
+    const Red4 ro = group_reduce_mixed<0, -1, -1, -1>(lds + LN_RED, lane, gbase, k, S, lane_in_group, obj, 0.0, 0.0, 0.0);
     if (valid && !(CAPPED && suspended)) {
       double *dst = a.ctrl + (size_t)b * 12 * a.seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
       UNROLL for (int i = 0; i < 6; i++) dst[i] = c[i];

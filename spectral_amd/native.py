@@ -14,7 +14,8 @@ from . import layout as L
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 CSRC_DIR = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(LIB_DIR, "libbtrapz_hip.so")
+# BTRAPZ_HIP_LIB: another build of the library (tools: A/B runs of kernel variants on one GPU box); default: the in-tree build
+LIB_PATH = os.environ.get("BTRAPZ_HIP_LIB") or os.path.join(LIB_DIR, "libbtrapz_hip.so")
 
 
 class BtrapzError(RuntimeError):
