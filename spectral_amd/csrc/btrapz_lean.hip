@@ -126,6 +126,18 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   // LDS reads of all fifteen rows at the top of a pass (latency it cannot know the second wavefront hides) and the
   // register allocator pays with scratch.
 #define ROW_SEP() __builtin_amdgcn_sched_barrier(0)
+  // Reciprocal slacks of the passes that form the step (Newton block, corrector, ratios, update).  The bare v_rcp_f64
+  // seed (5e-8 relative) perturbs the Newton direction by as much -- an inexact Newton step; the iterate is EVALUATED
+  // (residuals, complementarity, score: pass A1) without any reciprocal, so what the solve converges to and when it
+  // stops do not depend on it.  LEAN_SEED=0: one Newton step on every reciprocal, as the packed form has it.
+#ifndef LEAN_SEED
+#define LEAN_SEED 1
+#endif
+#if LEAN_SEED
+#define LEAN_RCP rcp_fast
+#else
+#define LEAN_RCP rcp
+#endif
   // termination bookkeeping (group-uniform)
   double best_score = 1e300;
   float best_res = 3e38f;
@@ -417,7 +429,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           const double gcr = row_dot<r>(c, t);
           const double s_l = sl[SI(r)], s_u = su[SI(r)];
           const double rpl = gcr - s_l - LLO(r), rpu = gcr + s_u - LUP(r);
-          const double wl = ll * rcp(s_l), wu = lu * rcp(s_u);
+          const double wl = ll * LEAN_RCP(s_l), wu = lu * LEAN_RCP(s_u);
           row_outer<r>(wl + wu, t2, H);
           row_scatter<r>(wl * (s_l + rpl) - wu * (s_u - rpu), t, hr);
         END_ROWS
@@ -595,7 +607,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       {
         ROW_LIMITS();
         FOR_ROWS(r)
-          LROW(r, rcp)
+          LROW(r, LEAN_RCP)
           LROW_CORR(r)
           row_scatter<r>((el - eu) + (wl * rpl + wu * rpu), t, h);
         END_ROWS
@@ -626,7 +638,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       {
         ROW_LIMITS();
         FOR_ROWS(r)
-          LROW(r, rcp)
+          LROW(r, LEAN_RCP)
           LROW_CORR(r)
 #if LEAN_E_CACHE
           el_[SI(r)] = el; eu_[SI(r)] = eu;
@@ -655,7 +667,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 #endif
         ROW_LIMITS();
         FOR_ROWS(r)
-          LROW(r, rcp)
+          LROW(r, LEAN_RCP)
 #if LEAN_E_CACHE
           const double wl = ll * isl, wu = lu * isu, el = el_[SI(r)], eu = eu_[SI(r)];
 #else
@@ -710,6 +722,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     }
   }
 #undef ROW_SEP
+#undef LEAN_RCP
 #undef LLO
 #undef LUP
 #undef ROW_LIMITS
