@@ -311,11 +311,11 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     double rd[3];
     double mu_part = 0.0, rp_part = 0.0, dscale = 0.0, rd_part;
     PHASE_FENCE(fence_slacks());
+    double c[6], H[21];   // control points and P block: A1's gradient, then (H += G' W G) A2's Newton block
+    control_points(X, c);
     {
-      double c[6], gr[6];
-      control_points(X, c);
+      double gr[6];
       {
-        double H[21];
         LEAN_LOAD_P(H)
         const double qC = qC0 * t;
         UNROLL for (int i = 0; i < 6; i++) {
@@ -414,11 +414,9 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     // ---- A2. Newton block H = P + G' W G and the predictor's right-hand side (rc = s lambda: tv = lambda_l (s_l +
     // rp_l) / s_l - lambda_u (s_u - rp_u) / s_u), then M = Phi' H Phi: block tridiagonal T, M01 ----
     double M01[9], T[6], up[3];
-    PHASE_FENCE(fence_slacks());
+    PHASE_FENCE(opaque6(c); fence_slacks());
     {
-      double c[6], H[21], hr[6];
-      control_points(X, c);
-      LEAN_LOAD_P(H)
+      double hr[6];
       UNROLL for (int i = 0; i < 6; i++) hr[i] = 0.0;
       {
         ROW_LIMITS();
@@ -567,7 +565,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       const double gcr = row_dot<r>(c, t);                                                            \
       const double rpl = gcr - s_l - LLO(r), rpu = gcr + s_u - LUP(r);                                \
       const double isl = RCP(s_l), isu = RCP(s_u);
-    double c[6], dca[6], dX[3];
+    double dca[6], dX[3];
     double sigma_mu, second_order;
     backward_u(up, dX, dca);
     control_points(X, c);
