@@ -138,6 +138,10 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 #else
 #define LEAN_RCP rcp
 #endif
+  // 1 / a and 1 / b from ONE reciprocal (v_rcp_f64 issues at a quarter of the rate of a multiplication): r = 1 / (a b),
+  // 1 / a = b r, 1 / b = a r.  Slacks and multipliers lie between 1e-13 and 1e4: the product is far from the ends of
+  // the exponent range.
+#define RCP_PAIR(RCP, a_, b_, ia_, ib_) const double rab_ = RCP((a_) * (b_)); const double ia_ = (b_) * rab_, ib_ = (a_) * rab_
   // termination bookkeeping (group-uniform)
   double best_score = 1e300;
   float best_res = 3e38f;
@@ -427,7 +431,8 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           const double gcr = row_dot<r>(c, t);
           const double s_l = sl[SI(r)], s_u = su[SI(r)];
           const double rpl = gcr - s_l - LLO(r), rpu = gcr + s_u - LUP(r);
-          const double wl = ll * LEAN_RCP(s_l), wu = lu * LEAN_RCP(s_u);
+          RCP_PAIR(LEAN_RCP, s_l, s_u, isl, isu);
+          const double wl = ll * isl, wu = lu * isu;
           row_outer<r>(wl + wu, t2, H);
           row_scatter<r>(wl * (s_l + rpl) - wu * (s_u - rpu), t, hr);
         END_ROWS
@@ -564,7 +569,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       const double s_l = sl[SI(r)], s_u = su[SI(r)];                                                  \
       const double gcr = row_dot<r>(c, t);                                                            \
       const double rpl = gcr - s_l - LLO(r), rpu = gcr + s_u - LUP(r);                                \
-      const double isl = RCP(s_l), isu = RCP(s_u);
+      RCP_PAIR(RCP, s_l, s_u, isl, isu);
     double dca[6], dX[3];
     double sigma_mu, second_order;
     backward_u(up, dX, dca);
@@ -645,7 +650,8 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           const double dsl = gd + rpl, dsu = -gd - rpu;
           const double dll = -el - wl * dsl, dlu = -eu - wu * dsu;
           pr = fmax(pr, fmax(-dsl * isl, -dsu * isu));
-          dr = fmax(dr, fmax(-dll * rcp_fast(ll), -dlu * rcp_fast(lu)));
+          const double rll_ = rcp_fast(ll * lu);
+          dr = fmax(dr, fmax(-dll * (lu * rll_), -dlu * (ll * rll_)));
         END_ROWS
       }
 #if LEAN_E_CACHE
@@ -721,6 +727,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   }
 #undef ROW_SEP
 #undef LEAN_RCP
+#undef RCP_PAIR
 #undef LLO
 #undef LUP
 #undef ROW_LIMITS
