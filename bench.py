@@ -37,7 +37,11 @@ FLOPS_PER_SEGMENT_ITER = 1700.0
 SOLVE_FORMS = {0: "btrapz::ipm_solve_kernel", 1: "btrapz::ipm_solve_split_kernel", 2: "btrapz::ipm_solve_long_kernel",
                3: "btrapz::ipm_solve_capped_kernel + btrapz::ipm_solve_resume_kernel (one solve = two launches: every candidate stops when "
                   "left alone in its wavefront after 6 iterations, the second launch carries those on; + 6 bucketing launches of ~5 us)",
-               4: "btrapz::ipm_solve_queue_kernel"}
+               4: "btrapz::ipm_solve_queue_kernel",
+               8: "btrapz::ipm_solve_lean_kernel (two wavefronts per SIMD)",
+               11: "btrapz::ipm_solve_lean_capped_kernel + btrapz::ipm_solve_lean_resume_kernel (two wavefronts per SIMD; one solve = two launches: "
+                   "every candidate stops when left alone in its wavefront after 6 iterations, the second launch carries those on; + 6 bucketing "
+                   "launches of ~5 us)"}
 
 
 def parse():
@@ -58,6 +62,10 @@ def parse():
                          "kernel's average duration is the batch launch alone)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--lean", type=int, default=0,
+                    help="btrapz_options.lean: 0 the library's choice by batch size (two wavefronts per SIMD from ~3 wavefronts per SIMD "
+                         "on), 1 / -1 pin the form -- the two forms agree to rounding, so a strong-scaling run that must return the "
+                         "1-rank winner's control points bit for bit pins it")
     ap.add_argument("--share-device", action="store_true",
                     help="dry run of the N > 1 flow on a 1-GPU box: every rank uses device 0 (use with --backend gloo)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0: pick a free one)")
@@ -224,7 +232,7 @@ def main():
         return global_argmin_with_winner(bc, bi, mine, ctx=solver.ctx)
 
     def step():
-        o = solver.solve(db, shared)                                   # assembly + solve: one launch
+        o = solver.solve(db, shared, lean=a.lean)                      # assembly + solve: one launch
         wc, wi, wctrl = winner(o)
         return o, wi[0], wc[0]
 
@@ -241,7 +249,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         ev[i][0].record()                       # torch's current stream == the stream the solve is launched on
-        o = solver.solve(db, shared)
+        o = solver.solve(db, shared, lean=a.lean)
         ev[i][1].record()
         wc, wi, wctrl = winner(o)
         win_idx, win_cost = wi[0], wc[0]
@@ -314,7 +322,7 @@ def main():
                                  "(SURVEY 8d); see fp64_valu" + ("; traffic above the algorithmic bytes is the iterate of the candidates the "
                                  "first launch hands to the second (74 doubles per segment, written once and read once, for the ~12 % of "
                                  "the axis problems that are handed over) and their records read a second time: not re-reads of a "
-                                 "working set" if solve_form == 3 else ""),
+                                 "working set" if solve_form in (3, 11) else ""),
                          "fp64_valu": {"achieved_tflops": flops / (kernel_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                                        "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                        "model": "%.0f useful flops per segment per iteration x %.2f mean iterations" %

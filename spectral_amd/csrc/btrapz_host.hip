@@ -56,8 +56,6 @@ using namespace btrapz;
 // its own unit and accepted 0.5 of it: the least-squares solution then leaves c7's lateral corridor by 0.09 m.)
 #define BTRAPZ_DEFAULT_ELASTIC_DELTA 1e-8
 #define BTRAPZ_DEFAULT_ELASTIC_TOL 0.0125
-// btrapz_options.lean = 0: whether the two-wavefronts-per-SIMD form is the automatic choice where it applies
-#define BTRAPZ_LEAN_AUTOMATIC 0
 
 struct btrapz_ctx {
   int device = 0;
@@ -418,8 +416,13 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     // Two wavefronts per SIMD (btrapz_options.lean / BTRAPZ_LEAN; btrapz_lean.hip): cold solves of at most 64 segments
     static const int lean_env = [] { const char *q = getenv("BTRAPZ_LEAN"); return q ? (*q == '0' ? -1 : 1) : 0; }();
     const int lean_opt = lean_env ? lean_env : (opt ? opt->lean : 0);
-    const bool lean_ok = !warm_kernel && !long_form && !split_on && !queue_on && S >= 3 && S <= BTRAPZ_MAX_SEGMENTS && a.unc_start == 0;   // (S <= 2: the root of the elimination is an end lane -- the packed form has the fix-up)
-    const bool lean_on = lean_ok && (lean_opt > 0 || (lean_opt == 0 && BTRAPZ_LEAN_AUTOMATIC));
+    const bool lean_ok = !warm_kernel && !long_form && !split_on && !queue_on && S <= BTRAPZ_MAX_SEGMENTS && a.unc_start == 0;
+    // Automatic: batches that give every SIMD its two wavefronts several times over.  Measured (tools/lean_bench.py,
+    // scenario_1 x 20, packed -> lean, one launch): 512 candidates 0.375 -> 0.435 ms, 2 048 0.447 -> 0.517, 8 192 1.117 ->
+    // 1.032, 16 384 1.964 -> 1.733, 65 536 7.05 -> 5.61: a lone wavefront per SIMD runs the packed form's shorter
+    // instruction stream faster; from about three wavefronts per SIMD on the second resident one pays.
+    const unsigned est_waves = 2u * (unsigned)((size_t)B / (size_t)(64 / (S < 64 ? S : 64)) + 1);
+    const bool lean_on = lean_ok && (lean_opt > 0 || (lean_opt == 0 && est_waves >= 3u * (unsigned)c->resident_waves));
     const bool ragged = seg_count != nullptr;
     if (cap_iter == 0 && !ragged && S >= 16 && blocks >= 8u * (unsigned)c->resident_waves) cap_iter = 6;
     const bool capped = cap_iter > 0 && !long_form && !split_on && (!a.order || ragged) && !warm_kernel && !queue_on && S <= BTRAPZ_MAX_SEGMENTS &&
@@ -456,8 +459,8 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       p1.cap_iter = cap_iter; p1.cap_alone = cap_alone_env; p1.cap_hi = cap_iter + cap_hi_env; p1.susp_cap = (int)slots; p1.susp_state = c->d_susp_state; p1.susp_count = count;
       p1.susp_slot = slot_of; p1.susp_key = keys;
       if (lean_on) {
-        if (ragged) hipLaunchKernelGGL(ipm_lean_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
-        else hipLaunchKernelGGL(ipm_lean_capped_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+        if (ragged) hipLaunchKernelGGL(ipm_solve_lean_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+        else hipLaunchKernelGGL(ipm_solve_lean_capped_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
       } else {
         if (ragged) hipLaunchKernelGGL(ipm_solve_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
         else hipLaunchKernelGGL(ipm_solve_capped_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
@@ -478,7 +481,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       p2.bucket_S = ragged ? 0 : S;
       // (ragged: no candidate has more than min(S, 64) segments, so no wavefront holds fewer groups than that allows)
       const unsigned rblocks = 2u * (unsigned)(slots / (size_t)(64 / (S < 64 ? S : 64)) + 65);
-      if (lean_on) hipLaunchKernelGGL(ipm_lean_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
+      if (lean_on) hipLaunchKernelGGL(ipm_solve_lean_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
       else hipLaunchKernelGGL(ipm_solve_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
       c->last_form = lean_on ? 11 : 3;
     } else if (long_form) {
@@ -495,8 +498,8 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
                          (const double *)c->d_mqm);
     } else if (lean_on) {
       c->last_form = 8;
-      if (a.order) hipLaunchKernelGGL(ipm_lean_ordered_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
-      else hipLaunchKernelGGL(ipm_lean_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
+      if (a.order) hipLaunchKernelGGL(ipm_solve_lean_ordered_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
+      else hipLaunchKernelGGL(ipm_solve_lean_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
     } else {
       c->last_form = 0;
       hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);

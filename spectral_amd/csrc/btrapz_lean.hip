@@ -485,8 +485,18 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       UNROLL for (int i = 0; i < 6; i++) TF[i] = T[i];
       for (int step = 0; step <= m; ++step) {
         double zin[6], win[3];
-        UNROLL for (int i = 0; i < 6; i++) { const double p = from_prev(Z[i]), n = from_next(Z[i]); zin[i] = p + n; }
-        UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(wp[i]), n = from_next(wp[i]); win[i] = p + n; }
+        {
+          double pz[6], nz[6], pw[3], nw[3];
+          UNROLL for (int i = 0; i < 6; i++) { pz[i] = from_prev(Z[i]); nz[i] = from_next(Z[i]); }
+          UNROLL for (int i = 0; i < 3; i++) { pw[i] = from_prev(wp[i]); nw[i] = from_next(wp[i]); }
+          if (S <= 2) {   // the root is an end lane: its missing neighbour is another group's lane (ragged batches: buckets of 1 or 2 segments)
+            UNIFORM_BLOCK;
+            UNROLL for (int i = 0; i < 6; i++) { pz[i] = first ? 0.0 : pz[i]; nz[i] = last ? 0.0 : nz[i]; }
+            UNROLL for (int i = 0; i < 3; i++) { pw[i] = first ? 0.0 : pw[i]; nw[i] = last ? 0.0 : nw[i]; }
+          }
+          UNROLL for (int i = 0; i < 6; i++) zin[i] = pz[i] + nz[i];
+          UNROLL for (int i = 0; i < 3; i++) win[i] = pw[i] + nw[i];
+        }
         if (step == my_step) {
           double Sk[6], F[6];
           UNROLL for (int i = 0; i < 6; i++) Sk[i] = TF[i] - zin[i];
@@ -529,7 +539,12 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       double w[3] = {0.0, 0.0, 0.0};
       for (int step = 0; step <= m; ++step) {
         double win[3];
-        UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(w[i]), n = from_next(w[i]); win[i] = p + n; }
+        {
+          double pw[3], nw[3];
+          UNROLL for (int i = 0; i < 3; i++) { pw[i] = from_prev(w[i]); nw[i] = from_next(w[i]); }
+          if (S <= 2) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) { pw[i] = first ? 0.0 : pw[i]; nw[i] = last ? 0.0 : nw[i]; } }
+          UNROLL for (int i = 0; i < 3; i++) win[i] = pw[i] + nw[i];
+        }
         if (step == my_step) {
           UNROLL for (int i = 0; i < 3; i++) u[i] -= win[i];
           if (!mid) {
@@ -546,7 +561,12 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       UNROLL for (int i = 0; i < 3; i++) y[i] = mid ? dX[i] : 0.0;
       for (int step = m - 1; step >= 0; --step) {
         double xin[3];
-        UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(y[i]), n = from_next(y[i]); xin[i] = p + n; }
+        {
+          double py[3], ny[3];
+          UNROLL for (int i = 0; i < 3; i++) { py[i] = from_prev(y[i]); ny[i] = from_next(y[i]); }
+          if (S <= 2) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) { py[i] = first ? 0.0 : py[i]; ny[i] = last ? 0.0 : ny[i]; } }
+          UNROLL for (int i = 0; i < 3; i++) xin[i] = py[i] + ny[i];
+        }
         if (step == my_step) {
           UNROLL for (int i = 0; i < 3; i++) {
             dX[i] -= MK[3 * i] * xin[0] + MK[3 * i + 1] * xin[1] + MK[3 * i + 2] * xin[2];
@@ -739,23 +759,23 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 
 // 256 registers per lane, 20 KB of LDS per wavefront: two wavefronts per SIMD, eight per CU.
 #define LEAN_KERNEL __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-LEAN_KERNEL void ipm_lean_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+LEAN_KERNEL void ipm_solve_lean_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[LN_ROWS][64];
   lean_solve_body<false, false, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
-LEAN_KERNEL void ipm_lean_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+LEAN_KERNEL void ipm_solve_lean_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[LN_ROWS][64];
   lean_solve_body<true, false, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
-LEAN_KERNEL void ipm_lean_capped_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+LEAN_KERNEL void ipm_solve_lean_capped_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[LN_ROWS][64];
   lean_solve_body<false, true, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
-LEAN_KERNEL void ipm_lean_capped_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+LEAN_KERNEL void ipm_solve_lean_capped_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[LN_ROWS][64];
   lean_solve_body<true, true, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
-LEAN_KERNEL void ipm_lean_resume_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+LEAN_KERNEL void ipm_solve_lean_resume_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[LN_ROWS][64];
   lean_solve_body<true, false, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }

@@ -1,0 +1,142 @@
+"""The solve kernel at two wavefronts per SIMD (btrapz_options.lean, spectral_amd/csrc/btrapz_lean.hip) through the
+C-ABI: against the oracle's exact optimum x* (the bar of test_gpu_parity.py: 1e-5 relative on control points), against
+the one-wavefront packed form (same accept set, control points to rounding), in two launches (btrapz_options.cap_iter:
+bit for bit the one-launch results), on ragged batches, and at one and two segments.  Replaces the reference's per-instance osqp_setup + osqp_solve (src/solve_3d.cc:1246-1249)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import O
+from spectral_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def solver():
+    from spectral_amd.solver import BatchSolver
+    return BatchSolver(0)
+
+
+def run(solver, batch, sh, **kw):
+    import torch
+    o = solver.solve(solver.upload(batch), sh, split=-1, **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy().copy() for k, v in o.items()}, solver.ctx.last_solve_form()
+
+
+@pytest.mark.parametrize("cfg,S,variant", [(2, 10, 0), (3, 20, 0), (4, 20, 1), (9, 7, 0), (8, 13, 1)])
+def test_lean_against_committed_xstar(solver, cfg, S, variant):
+    g = np.load(os.path.join(GOLD, "synthetic_xstar.npz"))
+    B, S_, v_, nb = g["cfg%d/meta" % cfg]
+    batch, sh = synth.make_batch(int(B), S, config=cfg, variant=variant)
+    r, form = run(solver, batch, sh, lean=1, cap_iter=-1)
+    assert form == 8
+    assert (r["status"] == 1).all()
+    xs, obj = g["cfg%d/xstar" % cfg], g["cfg%d/obj" % cfg]
+    for b in range(int(nb)):
+        assert np.abs(r["ctrl"][b] - xs[b]).max() <= RTOL * np.abs(xs[b]).max()
+        assert abs(r["cost"][b] - obj[b]) <= 1e-8 * abs(obj[b])
+
+
+@pytest.mark.parametrize("S,variant", [(20, 0), (20, 1), (10, 0)])
+def test_lean_scenario1_batches_against_committed_xstar(solver, S, variant):
+    """BASELINE configs 3 / 4 on the workload bench.py times; solvable candidates agree with x*, the others are
+    flagged by both."""
+    g = np.load(os.path.join(GOLD, "scenario1_xstar.npz"))
+    key = "S%d_v%d" % (S, variant)
+    B, S_, v_, nb = g[key + "/meta"]
+    batch, sh = synth.make_scenario1_batch(int(B), S, variant)
+    r, form = run(solver, batch, sh, lean=1, cap_iter=-1)
+    assert form == 8
+    xs, st = g[key + "/xstar"], g[key + "/status"]
+    n = 0
+    for b in range(int(nb)):
+        assert (st[b] > 0) == (r["status"][b] > 0), b
+        if st[b] > 0:
+            assert np.abs(r["ctrl"][b] - xs[b]).max() <= RTOL * np.abs(xs[b]).max(), b
+            n += 1
+    assert n > 0
+
+
+@pytest.mark.parametrize("S", [3, 4, 5, 6, 9, 16, 21, 32, 33, 64])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_lean_agrees_with_the_oracle_and_the_packed_form_at_every_width(solver, S, variant):
+    """Segment counts around the edges of the mapping (64 / S groups per wavefront: 21 groups at S = 3, one at S >= 33;
+    odd and even roots of the two-sided elimination; a full wavefront at S = 64)."""
+    B = 96 if S <= 33 else 24
+    batch, sh = synth.make_batch(B, S, config=2, variant=variant)
+    lean, form = run(solver, batch, sh, lean=1, cap_iter=-1)
+    packed, form0 = run(solver, batch, sh, lean=-1, cap_iter=-1)
+    assert (form, form0) == (8, 0)
+    assert np.array_equal(lean["status"] > 0, packed["status"] > 0)
+    ok = packed["status"] > 0
+    assert ok.any()
+    scale = np.abs(packed["ctrl"][ok]).max(axis=1, keepdims=True)
+    assert (np.abs(lean["ctrl"][ok] - packed["ctrl"][ok]) <= 1e-6 * scale).all()
+    assert np.abs(lean["iters"][ok].astype(int) - packed["iters"][ok]).max() <= 2
+    n = 6
+    xs, obj, st, _ = O.batch_solve(batch, sh, 0, n, exact=True)
+    for b in range(n):
+        assert (st[b] > 0) == (lean["status"][b] > 0)
+        if st[b] > 0:
+            assert np.abs(lean["ctrl"][b] - xs[b]).max() <= RTOL * np.abs(xs[b]).max(), (S, variant, b)
+
+
+def test_one_and_two_segments(solver):
+    """The root of the two-sided elimination is an end lane: the neighbour it lacks is another group's lane."""
+    for S in (1, 2):
+        batch, sh = synth.make_batch(64, S, config=2)
+        r, form = run(solver, batch, sh, lean=1, cap_iter=-1)
+        assert form == 8 and (r["status"] > 0).all()
+        xs, obj, st, _ = O.batch_solve(batch, sh, 0, 8, exact=True)
+        for b in range(8):
+            assert np.abs(r["ctrl"][b] - xs[b]).max() <= RTOL * np.abs(xs[b]).max(), (S, b)
+
+
+@pytest.mark.parametrize("make,cap", [(lambda: synth.make_scenario1_batch(6144, 20, 0), 6), (lambda: synth.make_scenario1_batch(6144, 20, 1), 5),
+                                      (lambda: synth.make_batch(4096, 10, config=2), 4)])
+def test_lean_in_two_launches_gives_the_one_launch_results_bit_for_bit(solver, make, cap):
+    """The capped first launch hands iterates over, the resume launch carries them on without evaluating them a second
+    time: statuses, iteration counts, costs and control points of the one-launch solve, bit for bit."""
+    batch, sh = make()
+    one, f1 = run(solver, batch, sh, lean=1, cap_iter=-1)
+    two, f2 = run(solver, batch, sh, lean=1, cap_iter=cap)
+    assert (f1, f2) == (8, 11)
+    assert np.array_equal(one["status"], two["status"]) and np.array_equal(one["iters"], two["iters"])
+    assert np.array_equal(one["cost"], two["cost"])
+    ok = one["status"] > 0
+    assert np.array_equal(one["ctrl"][ok], two["ctrl"][ok])
+    keys = solver.ctx.debug_resume_keys(batch.B)
+    assert (keys > 0).sum() > 0          # some axis problems did go through the second launch
+
+
+def test_lean_on_ragged_batches(solver):
+    """knots -> corridors -> ragged QP batch (segment counts 1..24): the lean ordered kernel against the packed one
+    and, in two launches, against itself."""
+    import torch
+    from spectral_amd import knots
+    gold = os.path.join(GOLD, "inputs")
+    W = np.loadtxt(os.path.join(gold, "weights.txt"))
+    for name in ("c_road_s1_3", "c1", "c2"):
+        kb = knots.jittered(knots.parse_corridor_file(os.path.join(gold, name + ".txt")), 2048, seed=11)
+        sh = synth.shared_params(0, weights=W)
+        sh.ds_ref, sh.dl_ref = kb.header["ds_ref"], kb.header["dl_ref"]
+        sh.dds, sh.ddds, sh.ddl, sh.dddl = kb.header["dds"], kb.header["ddds"], kb.header["ddl"], kb.header["dddl"]
+        rec = solver.corridor_batch(kb, 0, seg_stride=32)
+        res = {}
+        for label, kw in (("packed", dict(lean=-1, cap_iter=-1)), ("lean", dict(lean=1, cap_iter=-1)), ("lean2", dict(lean=1, cap_iter=6))):
+            o = solver.solve_ragged(rec, sh, **kw)
+            torch.cuda.synchronize()
+            res[label] = ({k: v.cpu().numpy().copy() for k, v in o.items()}, solver.ctx.last_solve_form())
+        assert (res["packed"][1], res["lean"][1], res["lean2"][1]) == (0, 8, 11)
+        p, l, l2 = res["packed"][0], res["lean"][0], res["lean2"][0]
+        assert np.array_equal(l["status"] > 0, p["status"] > 0), name
+        ok = p["status"] > 0
+        scale = np.abs(p["ctrl"][ok]).max(axis=1, keepdims=True)
+        assert (np.abs(l["ctrl"][ok] - p["ctrl"][ok]) <= 1e-6 * scale).all()
+        assert np.array_equal(l["status"], l2["status"]) and np.array_equal(l["iters"], l2["iters"]) and np.array_equal(l["cost"], l2["cost"])
+        assert np.array_equal(l["ctrl"][ok], l2["ctrl"][ok])

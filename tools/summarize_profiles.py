@@ -14,7 +14,8 @@ import shutil
 import sys
 
 KERNEL = "ipm_solve_"        # every kernel of a solve call: ipm_solve_kernel, or ipm_solve_capped_kernel + ipm_solve_resume_kernel
-PRIMARY = ("ipm_solve_kernel", "ipm_solve_capped_kernel", "ipm_solve_queue_kernel", "ipm_solve_split_kernel")   # one launch of these = one solve
+PRIMARY = ("ipm_solve_kernel", "ipm_solve_capped_kernel", "ipm_solve_queue_kernel", "ipm_solve_split_kernel",
+           "ipm_solve_lean_kernel", "ipm_solve_lean_capped_kernel")   # one launch of these = one solve
 
 
 def counter_means(root, pattern="pmc_*", kernel=KERNEL):
@@ -171,7 +172,7 @@ def main():
                             f64.get("SQ_INSTS_VALU_ADD_F64", 0) + f64.get("SQ_INSTS_VALU_TRANS_F64", 0))
             derived["fp64_flops_per_launch_all_lanes"] = flops
             derived["fp64_share_of_valu_instructions"] = sum(f64.values()) / sq["SQ_INSTS_VALU"]
-        json.dump(dict(kernel=primary + (" + ipm_solve_resume_kernel" if primary == "ipm_solve_capped_kernel" else ""), workload=wl, kernel_source_hash=stamp, compiler_resources=cres, per_launch=sq, derived=derived,
+        json.dump(dict(kernel=primary + (" + ipm_solve_resume_kernel" if primary == "ipm_solve_capped_kernel" else " + ipm_solve_lean_resume_kernel" if primary == "ipm_solve_lean_capped_kernel" else ""), workload=wl, kernel_source_hash=stamp, compiler_resources=cres, per_launch=sq, derived=derived,
                        note="rocprofv3 --pmc passes (tools/collect_profiles.sh), means over the launches of one "
                             "bench.py --steps 3 --warmup 1 run; SQ cycle counters are in units of 4 clock cycles."),
                   open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)
