@@ -89,8 +89,9 @@ def self_launch(a):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
+    # (dmabuf IPC: the only mode this pool's host driver supports -- see spectral_amd.dist.init_process_group)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    return subprocess.call(cmd, env=env)   # the launcher's exit code: non-zero when any rank failed (it ends the others)
 
 
 def kernel_stamp():
@@ -204,10 +205,8 @@ def main():
         raise SystemExit("rank %d: local rank %d but %d HIP device(s)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(a.backend)
+        from spectral_amd.dist import init_process_group
+        init_process_group(a.backend, local_rank)      # 60 s timeout on every collective; RCCL bound to the device at once
     solver = BatchSolver(local_rank)
     dev = solver.device
 

@@ -64,7 +64,10 @@ double btrapz_find_traj(int variant, const char *input_path, const char *output_
  * precision.  Same computation, same return value (a_cost or 1e11) as btrapz_find_traj.
  *   traj [7][cap]: rows t, s, l, ds, dl, dds, ddl (the columns of the reference's output file); at most cap
  *                  samples are written, *n_points receives the trajectory's sample count.
- *   ctrl [12*BTRAPZ_MAX_SEGMENTS_LONG] (may be NULL): control points, s axis then l axis; *n_segments receives S. */
+ *   ctrl [12*BTRAPZ_MAX_SEGMENTS] (may be NULL): control points, s axis (6 S) then l axis (6 S); *n_segments receives
+ *                  S.  A horizon of more than 64 segments (solved since round 3, up to BTRAPZ_MAX_SEGMENTS_LONG) does
+ *                  not fit this buffer: the first 12*64 values are written, S is reported, and the caller that wants
+ *                  them all calls btrapz_find_traj_mem_cap with a buffer of 12 S (ctrl_cap: its size in doubles). */
 typedef struct btrapz_traj_input {
   int N, num_obs;
   double delta;
@@ -80,6 +83,8 @@ typedef struct btrapz_traj_input {
 } btrapz_traj_input;
 double btrapz_find_traj_mem(int variant, const btrapz_traj_input *in, const Params *p, int cap,
                             double *traj, int *n_points, double *ctrl, int *n_segments);
+double btrapz_find_traj_mem_cap(int variant, const btrapz_traj_input *in, const Params *p, int cap,
+                                double *traj, int *n_points, double *ctrl, int ctrl_cap, int *n_segments);
 
 /* Interior-point iterations of the calling thread's last find_traj / btrapz_find_traj_mem call (-1: none yet).
  * Diagnostics: with BTRAPZ_WARM=1 a call starts from the joint states and multipliers the thread's previous call

@@ -14,6 +14,18 @@
 
 using namespace btrapz;
 
+// Environment overrides of btrapz_options for experiments (BTRAPZ_CAP, _QUEUE, _LEAN, _SPLIT, _START, _STALL_FACTOR: A/B
+// runs of tools/ without touching the caller).  Only in a -DBTRAPZ_EXPERIMENTS build: the shipped drop-in library takes
+// these choices from btrapz_options alone, so a stray variable in the harness's environment cannot change what it does.
+static inline const char *experiment_env(const char *name) {
+#ifdef BTRAPZ_EXPERIMENTS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 // Step-length rule of the interior-point iterations (btrapz_options).  Measured on MI355X, 65 536 x 20 synthetic
 // candidates (mean iterations / kernel ms) and 65 536 jittered copies of c_road_s1_3.txt, a quarter of them infeasible
 // and many close to it (candidates the 0.995 rule solves and the setting loses):
@@ -56,6 +68,15 @@ using namespace btrapz;
 // its own unit and accepted 0.5 of it: the least-squares solution then leaves c7's lateral corridor by 0.09 m.)
 #define BTRAPZ_DEFAULT_ELASTIC_DELTA 1e-8
 #define BTRAPZ_DEFAULT_ELASTIC_TOL 0.0125
+// Two-launch solve (btrapz_options.cap_iter): who hands over -- a group that is the only one of its wavefront still
+// iterating after cap_iter iterations, and any group still iterating BTRAPZ_CAP_HI iterations later; hand-over slots for
+// BTRAPZ_SUSP_PERCENT of the axis problems, at most BTRAPZ_SUSP_BYTES_MAX of workspace.  (Tuned on the bench batches,
+// cap_alone 1 / 2 / 3: 6.39 / 6.47 / 6.58 ms; cap_hi 2 / 4 / 8: 6.44 / 6.39 / 6.41; 12-21 % of the problems
+// hand over.)  Compile-time constants: a stray environment variable must not change what a drop-in library does.
+#define BTRAPZ_CAP_ALONE 1
+#define BTRAPZ_CAP_HI 4
+#define BTRAPZ_SUSP_PERCENT 25
+#define BTRAPZ_SUSP_BYTES_MAX (1ull << 30)
 
 struct btrapz_ctx {
   int device = 0;
@@ -187,7 +208,7 @@ static void fill_parameters(KernelArgs &a, const btrapz_shared *sh, const btrapz
   a.tau = (opt && opt->step_fraction > 0 && opt->step_fraction < 1) ? opt->step_fraction : BTRAPZ_DEFAULT_STEP_FRACTION;
   a.tau_iters = BTRAPZ_AGGRESSIVE_ITERATIONS;
   a.stall_start = BTRAPZ_STALL_START; a.stall_len = BTRAPZ_STALL_LENGTH;
-  static const float stall_factor_env = [] { const char *v = getenv("BTRAPZ_STALL_FACTOR"); return v ? (float)atof(v) : 0.0f; }();   // (experiments)
+  static const float stall_factor_env = [] { const char *v = experiment_env("BTRAPZ_STALL_FACTOR"); return v ? (float)atof(v) : 0.0f; }();   // (experiments)
   a.stall_factor = stall_factor_env > 0.0f ? stall_factor_env : BTRAPZ_STALL_FACTOR;
   a.diverge_factor = BTRAPZ_DIVERGE_FACTOR;
   a.tau_thr = (opt && opt->step_threshold > 0) ? opt->step_threshold : BTRAPZ_DEFAULT_STEP_THRESHOLD;
@@ -198,7 +219,7 @@ static void fill_parameters(KernelArgs &a, const btrapz_shared *sh, const btrapz
   a.elastic_tol = (opt && opt->elastic_tol > 0) ? opt->elastic_tol : BTRAPZ_DEFAULT_ELASTIC_TOL;
   a.bucket_S = 0;
   a.cap_iter = 0; a.cap_alone = 0; a.cap_hi = 0; a.susp_cap = 0; a.susp_state = nullptr; a.susp_count = nullptr; a.susp_slot = nullptr; a.susp_key = nullptr;
-  static const int start_env = [] { const char *e = getenv("BTRAPZ_START"); return e ? atoi(e) : -1; }();
+  static const int start_env = [] { const char *e = experiment_env("BTRAPZ_START"); return e ? atoi(e) : -1; }();
   a.unc_start = start_env >= 0 ? start_env : (opt ? opt->start : 0);
 }
 
@@ -389,11 +410,11 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     // candidates, kernel ms off -> on): scenario_1 x 20 6.93 -> 6.59, its cuboid variant (16 % stalling) 6.57 -> 5.71,
     // generic x 20 5.12 -> 5.33, scenario_1 x 10 2.13 -> 2.34: it pays where iteration counts spread widely, so it is
     // the caller's choice and off by default.
-    static const int queue_env = [] { const char *q = getenv("BTRAPZ_QUEUE"); return q ? (*q == '0' ? -1 : 1) : 0; }();
+    static const int queue_env = [] { const char *q = experiment_env("BTRAPZ_QUEUE"); return q ? (*q == '0' ? -1 : 1) : 0; }();
     const bool queue_on = queue_env ? queue_env > 0 : (opt && opt->queue > 0);
     a.queue = c->d_queue;
     // Few candidates: one per wavefront, rows over three lanes (btrapz_options.split; ipm_solve_split_kernel)
-    const char *split_q = getenv("BTRAPZ_SPLIT");
+    const char *split_q = experiment_env("BTRAPZ_SPLIT");
     const int split_env = split_q ? (*split_q == '0' ? -1 : 1) : 0;
     const int split_opt = split_env ? split_env : (opt ? opt->split : 0);
     const bool split_on = !a.order && !warm_kernel && S <= 21 &&
@@ -401,7 +422,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     // Two launches for uniform cold batches much larger than the machine (btrapz_options.cap_iter / BTRAPZ_CAP): every
     // group stops at cap_iter iterations, the unfinished ones are carried on by a second launch, like with like, the
     // far-from-converged first (CAPPED / RESUME in btrapz_kernels.hip).  Same iterates, same results.
-    static const int cap_env = [] { const char *q = getenv("BTRAPZ_CAP"); return q ? atoi(q) : -1; }();
+    static const int cap_env = [] { const char *q = experiment_env("BTRAPZ_CAP"); return q ? atoi(q) : -1; }();
     // Measured (tools/cap_bench.py, 65 536 candidates, one launch -> two): scenario_1 x 20 7.00 -> 6.39 ms, its cuboid
     // variant 6.70 -> 6.35, generic x 20 5.21 -> 5.18, scenario_1 x 10 2.24 -> 2.46 (six groups per wavefront: what a
     // lone straggler wastes is less than what the second launch costs).  Automatic (cap_iter = 0): 6 for uniform cold
@@ -414,7 +435,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     // widely, which the library does not know.
     int cap_iter = cap_env > 0 ? cap_env : cap_env == 0 ? -1 : (opt ? opt->cap_iter : 0);   // BTRAPZ_CAP=0: never
     // Two wavefronts per SIMD (btrapz_options.lean / BTRAPZ_LEAN; btrapz_lean.hip): cold solves of at most 64 segments
-    static const int lean_env = [] { const char *q = getenv("BTRAPZ_LEAN"); return q ? (*q == '0' ? -1 : 1) : 0; }();
+    static const int lean_env = [] { const char *q = experiment_env("BTRAPZ_LEAN"); return q ? (*q == '0' ? -1 : 1) : 0; }();
     const int lean_opt = lean_env ? lean_env : (opt ? opt->lean : 0);
     const bool lean_ok = !warm_kernel && !long_form && !split_on && !queue_on && S <= BTRAPZ_MAX_SEGMENTS && a.unc_start == 0;
     // Automatic: batches that give every SIMD its two wavefronts several times over.  Measured (tools/lean_bench.py,
@@ -424,39 +445,53 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     const unsigned est_waves = 2u * (unsigned)((size_t)B / (size_t)(64 / (S < 64 ? S : 64)) + 1);
     const bool lean_on = lean_ok && (lean_opt > 0 || (lean_opt == 0 && est_waves >= 3u * (unsigned)c->resident_waves));
     const bool ragged = seg_count != nullptr;
+    const bool cap_requested = cap_iter > 0;   // (by the caller; the automatic choice below falls back to one launch when the workspace cannot be had)
     if (cap_iter == 0 && !ragged && S >= 16 && blocks >= 8u * (unsigned)c->resident_waves) cap_iter = 6;
     const bool capped = cap_iter > 0 && !long_form && !split_on && (!a.order || ragged) && !warm_kernel && !queue_on && S <= BTRAPZ_MAX_SEGMENTS &&
                         cap_iter < a.max_iter && elastic != 2;
+    // Workspace of the two launches: hand-over slots for a quarter of the axis problems (a group that finds none simply
+    // goes on), 74 doubles per segment each -- 19 KB per slot at 64 segments, 388 MB for 65 536 candidates of 20 -- but
+    // never more than BTRAPZ_SUSP_BYTES_MAX.  When the device cannot give it, a solve that chose the two launches by
+    // itself (cap_iter = 0) runs as one launch; one that was asked for them (cap_iter > 0) fails with BTRAPZ_ENOMEM.
+    size_t slots = 0;
+    bool capped_ws = false;
     if (capped) {
-      // slots for a quarter of the axis problems (BTRAPZ_SUSP_PERCENT: experiments); a group that finds none goes on
-      static const int susp_percent = [] { const char *q = getenv("BTRAPZ_SUSP_PERCENT"); return q ? atoi(q) : 25; }();
-      size_t slots = 2 * (size_t)B * (size_t)(susp_percent < 1 ? 1 : susp_percent > 100 ? 100 : susp_percent) / 100;
+      slots = 2 * (size_t)B * (size_t)BTRAPZ_SUSP_PERCENT / 100;
       if (slots < 1024) slots = 1024;
+      const size_t slots_max = (size_t)BTRAPZ_SUSP_BYTES_MAX / (sizeof(double) * 74 * (size_t)S);
+      if (slots > slots_max) slots = slots_max;
+      if (slots > (size_t)0x7fffffff) slots = (size_t)0x7fffffff;   // (susp_cap is an int)
       const size_t need_state = slots * 74 * (size_t)S, need_ints = 4 + 4 * (size_t)B;
-      if (need_state > c->susp_state_doubles) {
+      bool ok = slots >= 64;
+      if (ok && need_state > c->susp_state_doubles) {
         (void)hipFree(c->d_susp_state); c->d_susp_state = nullptr; c->susp_state_doubles = 0;
-        HIPCHK(c, hipMalloc(&c->d_susp_state, sizeof(double) * need_state));
-        c->susp_state_doubles = need_state;
+        if (hipMalloc(&c->d_susp_state, sizeof(double) * need_state) == hipSuccess) c->susp_state_doubles = need_state;
+        else { c->d_susp_state = nullptr; ok = false; }
       }
-      if (need_ints > c->susp_ints) {
+      if (ok && need_ints > c->susp_ints) {
         (void)hipFree(c->d_susp_ints); c->d_susp_ints = nullptr; c->susp_ints = 0;
-        HIPCHK(c, hipMalloc(&c->d_susp_ints, sizeof(int) * need_ints));
-        c->susp_ints = need_ints;
+        if (hipMalloc(&c->d_susp_ints, sizeof(int) * need_ints) == hipSuccess) c->susp_ints = need_ints;
+        else { c->d_susp_ints = nullptr; ok = false; }
       }
-      if (2 * (size_t)B > c->rescue_cap) {
+      if (ok && 2 * (size_t)B > c->rescue_cap) {
         (void)hipFree(c->d_rescue); c->d_rescue = nullptr; c->rescue_cap = 0;
-        HIPCHK(c, hipMalloc(&c->d_rescue, sizeof(int) * 4 * (size_t)B));
-        c->rescue_cap = 2 * (size_t)B;
+        if (hipMalloc(&c->d_rescue, sizeof(int) * 4 * (size_t)B) == hipSuccess) c->rescue_cap = 2 * (size_t)B;
+        else { c->d_rescue = nullptr; ok = false; }
       }
-      if (!c->d_rescue_meta) HIPCHK(c, hipMalloc(&c->d_rescue_meta, sizeof(int) * 2 * 198));
+      if (ok && !c->d_rescue_meta && hipMalloc(&c->d_rescue_meta, sizeof(int) * 2 * 198) != hipSuccess) { c->d_rescue_meta = nullptr; ok = false; }
+      if (!ok) {
+        (void)hipGetLastError();   // (the failed allocation's error is handled here)
+        if (cap_requested) { c->err = "btrapz_options.cap_iter: no memory for the hand-over workspace"; return BTRAPZ_ENOMEM; }
+      }
+      capped_ws = ok;
+    }
+    if (capped && capped_ws) {
       int *count = c->d_susp_ints, *slot_of = c->d_susp_ints + 4, *keys = slot_of + 2 * (size_t)B;
       HIPCHK(c, hipMemsetAsync(count, 0, sizeof(int) * 4, stream));
       HIPCHK(c, hipMemsetAsync(keys, 0, sizeof(int) * 2 * (size_t)B, stream));
       HIPCHK(c, hipMemsetAsync(c->d_rescue_meta, 0, sizeof(int) * 2 * 198, stream));
       KernelArgs p1 = a;
-      static const int cap_alone_env = [] { const char *q = getenv("BTRAPZ_CAP_ALONE"); return q ? atoi(q) : 1; }();
-      static const int cap_hi_env = [] { const char *q = getenv("BTRAPZ_CAP_HI"); return q ? atoi(q) : 4; }();
-      p1.cap_iter = cap_iter; p1.cap_alone = cap_alone_env; p1.cap_hi = cap_iter + cap_hi_env; p1.susp_cap = (int)slots; p1.susp_state = c->d_susp_state; p1.susp_count = count;
+      p1.cap_iter = cap_iter; p1.cap_alone = BTRAPZ_CAP_ALONE; p1.cap_hi = cap_iter + BTRAPZ_CAP_HI; p1.susp_cap = (int)slots; p1.susp_state = c->d_susp_state; p1.susp_count = count;
       p1.susp_slot = slot_of; p1.susp_key = keys;
       if (lean_on) {
         if (ragged) hipLaunchKernelGGL(ipm_solve_lean_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);

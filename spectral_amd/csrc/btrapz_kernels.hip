@@ -216,6 +216,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   [[maybe_unused]] bool unc_pass = false;
   bool done = true;
   [[maybe_unused]] bool suspended = false;   // capped launch: the group has handed its iterate over to the resume launch
+  [[maybe_unused]] bool handed_over = RESUME;   // resume launch, first pass: the iterate was evaluated by the capped launch
   [[maybe_unused]] int cand_live = 0;   // long form: the workgroup has a candidate
   // The group's own iteration count.  (Warm-start instantiations: when one group of the wavefront restarts cold the
   // others lose that pass of the loop; queue: the groups of a wavefront are at different iterations.  A candidate's
@@ -728,7 +729,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     if (first && lane_in_group && valid && !done && gl == 0) printf("trace axis %d b %d eit %d score %.3e res %.3e (dual %.3e primal %.3e) mu %.3e best %.3e@%d res_it %d | rd %.3e dscale %.3e qn %.3e bnorm %.3e\n", axis, b, eit, score, res, rd_eff / (1.0 + qn), rr.c / (1.0 + bnorm), mu, best_score, best_it, res_it, rr.b, rr.d, qn, bnorm);
 #endif
     bool restart_now = false;
-    if (!done && !unc_pass) {
+    if (!done && !unc_pass && !(RESUME && handed_over)) {
       iters = eit;
       if (score < best_score) { best_score = score; best_it = eit; Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2]; }
       if ((float)res < a.stall_factor * best_res) { best_res = (float)res; res_it = eit; }
@@ -772,9 +773,12 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // the iteration budget: the iterate just evaluated was the last one (a step nobody evaluates is not taken)
       if (!done && !restart_now && eit + 1 >= a.max_iter) done = true;
     }
+    handed_over = false;
     if constexpr (CAPPED) {
       // the cap: a group still iterating after cap_iter iterations hands its iterate over to the resume launch.  (The
-      // iterate has just been evaluated; the resume launch evaluates it again -- the bookkeeping above is idempotent.)
+      // iterate has just been evaluated, its bookkeeping -- best iterate, stall marks, the second chance -- goes along;
+      // the resume launch forms the Newton step of its first pass without evaluating the iterate a second time: a
+      // second evaluation of a solve whose second chance was granted on this very iterate would end it.)
       // Who hands over: a group that is the only one of its wavefront still iterating after cap_iter iterations (the
       // wavefront would run at a third of its width for it), and any group still iterating cap_hi iterations in (a long
       // runner belongs at the front of a launch, not wherever the batch order put it).

@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+#include <sched.h>
+
 #include "btrapz_device.h"
 #include "corridor.hpp"
 
@@ -50,15 +52,18 @@ struct Caller {
 // What btrapz_find_traj_last_iterations / _last_status report: per thread, and no reason to create a context.
 struct LastCall { int iters = -1; int status = 0; double viol[4] = {0.0, 0.0, 0.0, 0.0}; };
 thread_local LastCall t_last;
-std::mutex g_callers_mutex;
-std::vector<Caller *> g_idle_callers;   // sets whose thread has exited
+// The pool of sets whose thread has exited, and its lock: heap objects that are never destroyed -- a worker thread may
+// exit (and hand its set back) during or after the destruction of this library's static objects at process exit.
+struct CallerPool { std::mutex mutex; std::vector<Caller *> idle; };
+CallerPool &caller_pool() { static CallerPool *p = new CallerPool(); return *p; }
 
 struct CallerHolder {
   Caller *c = nullptr;
   ~CallerHolder() {
     if (!c) return;
-    std::lock_guard<std::mutex> lk(g_callers_mutex);
-    g_idle_callers.push_back(c);
+    CallerPool &pool = caller_pool();
+    std::lock_guard<std::mutex> lk(pool.mutex);
+    pool.idle.push_back(c);
   }
 };
 
@@ -68,15 +73,23 @@ Caller *this_caller() {
     const char *dev = getenv("BTRAPZ_DEVICE");
     const int device = dev ? atoi(dev) : 0;
     {
-      std::lock_guard<std::mutex> lk(g_callers_mutex);
-      for (size_t i = 0; i < g_idle_callers.size(); i++)
-        if (g_idle_callers[i]->device == device) {
-          me.c = g_idle_callers[i];
-          g_idle_callers.erase(g_idle_callers.begin() + (long)i);
+      CallerPool &pool = caller_pool();
+      std::lock_guard<std::mutex> lk(pool.mutex);
+      for (size_t i = 0; i < pool.idle.size(); i++)
+        if (pool.idle[i]->device == device) {
+          me.c = pool.idle[i];
+          pool.idle.erase(pool.idle.begin() + (long)i);
           break;
         }
     }
-    if (me.c) { btrapz_single_forget(me.c->ctx); return me.c; }   // (the previous owner's warm-start state is not ours)
+    if (me.c) {
+      // the previous owner may have returned from its last call on the completion word alone (wait_for_results): its
+      // last launch must have retired before this thread rewrites the pinned block; its warm-start state is not ours
+      (void)hipSetDevice(device);
+      (void)hipStreamSynchronize(me.c->stream);
+      btrapz_single_forget(me.c->ctx);
+      return me.c;
+    }
     Caller *c = new Caller();
     c->device = device;
     if (btrapz_create(&c->ctx, device) != BTRAPZ_OK) { delete c; return nullptr; }
@@ -90,18 +103,25 @@ bool verbose() { const char *v = getenv("BTRAPZ_VERBOSE"); return v && *v && *v 
 // BTRAPZ_VERBOSE=2: where a call's time goes (host stages and the launch), on stderr
 bool timing() { const char *v = getenv("BTRAPZ_VERBOSE"); return v && *v == '2'; }
 double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-// The single launch writes its results through the mapping and sets a completion word last (system-scope release):
-// polling that word sees the results a few microseconds before hipStreamSynchronize returns (end-of-kernel cache
-// release, completion signal, the runtime's wake-up).  The poll gives up after 2 ms -- a solve of 256 segments and 200
-// iterations takes longer, a faulted kernel never answers -- and the stream wait takes over.  BTRAPZ_SPIN=0: wait only.
-bool wait_for_results(const double *h_out, hipStream_t stream) {
+// The single launch writes its results through the mapping (a coherent, fine-grained pinned block: visible to the host
+// before the kernel ends) and sets a completion word last (system-scope release): polling that word sees the results a
+// few microseconds before hipStreamSynchronize returns (end-of-kernel cache release, completion signal, the runtime's
+// wake-up).  The poll burns the calling core for at most 300 us -- a usual solve answers within 200 -- then yields the
+// core between looks, and gives up after 2 ms (a long or faulted kernel): the stream wait takes over.  Solves of more
+// than 64 segments (slow: several wavefronts per problem) do not poll at all.  BTRAPZ_SPIN=0: wait only.
+bool wait_for_results(const double *h_out, hipStream_t stream, bool poll) {
   static const bool spin = [] { const char *v = getenv("BTRAPZ_SPIN"); return !(v && *v == '0'); }();
-  if (spin) {
+  if (spin && poll) {
     const volatile int *done = reinterpret_cast<const volatile int *>(h_out + 2) + 1;
     const double t0 = now_us();
+    bool yielding = false;
     for (int i = 0; !*done; ++i) {
-      __builtin_ia32_pause();
-      if ((i & 255) == 255 && now_us() - t0 > 2000.0) break;
+      if (yielding) sched_yield(); else __builtin_ia32_pause();
+      if (yielding || (i & 255) == 255) {
+        const double dt = now_us() - t0;
+        if (dt > 2000.0) break;
+        if (dt > 300.0) yielding = true;
+      }
     }
     if (*done) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return true; }
   }
@@ -275,7 +295,7 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
     if (me->pinned) (void)hipHostFree(me->pinned);
     me->pinned = nullptr; me->pinned_dev = nullptr; me->pinned_bytes = 0;
     const size_t want = (n_in + n_out) * 8 * 2;
-    if (hipHostMalloc(&me->pinned, want, hipHostMallocMapped) != hipSuccess) return FAIL;
+    if (hipHostMalloc(&me->pinned, want, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return FAIL;
     if (hipHostGetDevicePointer(&me->pinned_dev, me->pinned, 0) != hipSuccess) { (void)hipHostFree(me->pinned); me->pinned = nullptr; return FAIL; }
     me->pinned_bytes = want;
   }
@@ -301,7 +321,9 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   const double t_launch = tm ? now_us() : 0.0;
   btrapz_options opt1;
   btrapz_options_init(&opt1);
-  if (const char *mi = getenv("BTRAPZ_MAX_ITER")) opt1.max_iter = atoi(mi);   // (experiments: cost per iteration)
+#ifdef BTRAPZ_EXPERIMENTS
+  if (const char *mi = getenv("BTRAPZ_MAX_ITER")) opt1.max_iter = atoi(mi);   // (cost per iteration)
+#endif
   // BTRAPZ_EPS: the solve's tolerance (btrapz_options.eps; default 1e-9, control points within ~2e-6 of x*).  The
   // reference's OSQP runs at 1e-5; 1e-6 saves about one iteration per call ("Tolerance").
   if (const char *ep = getenv("BTRAPZ_EPS")) { const double v = atof(ep); if (v > 0.0 && v < 1e-2) opt1.eps = v; }
@@ -309,7 +331,7 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
     h_status[0] = BTRAPZ_MAX_ITER_REACHED;   // (nothing solved yet: the block below does it, without the rescue rows)
   } else
   if (btrapz_launch_single(ctx, &sh, &opt1, S, d_in, d_out, max_points, warm_on ? 1 : 0, me->stream) != BTRAPZ_OK ||
-      !wait_for_results(h_out, me->stream)) {
+      !wait_for_results(h_out, me->stream, S <= BTRAPZ_MAX_SEGMENTS)) {
     fprintf(stderr, "btrapz: %s\n", btrapz_last_error(ctx));
     btrapz_single_forget(ctx);   // (whatever the failed launch left is no start for the next call)
     return FAIL;
@@ -448,7 +470,13 @@ BTRAPZ_EXPORT int btrapz_find_traj_last_status(double *viol) {
 // arrays, the trajectory goes out in full precision.
 BTRAPZ_EXPORT double btrapz_find_traj_mem(int variant, const btrapz_traj_input *ti, const Params *p, int cap, double *traj,
                                        int *n_points, double *ctrl, int *n_segments) {
+  return btrapz_find_traj_mem_cap(variant, ti, p, cap, traj, n_points, ctrl, ctrl ? 12 * BTRAPZ_MAX_SEGMENTS : 0, n_segments);
+}
+
+BTRAPZ_EXPORT double btrapz_find_traj_mem_cap(int variant, const btrapz_traj_input *ti, const Params *p, int cap, double *traj,
+                                           int *n_points, double *ctrl, int ctrl_cap, int *n_segments) {
   const double FAIL = BTRAPZ_FAIL_SENTINEL;
+  if (ctrl_cap < 0 || (ctrl_cap > 0 && !ctrl)) return FAIL;
   if (n_points) *n_points = 0;
   if (n_segments) *n_segments = 0;
   if (!ti || !p || variant < 0 || variant > 1 || ti->N < 3 || ti->N > 100000 || ti->num_obs < 0 || ti->num_obs > 1000 ||
@@ -480,6 +508,9 @@ BTRAPZ_EXPORT double btrapz_find_traj_mem(int variant, const btrapz_traj_input *
     traj[i] = i * in.delta;
     for (int c = 0; c < 6; c++) traj[(size_t)(c + 1) * cap + i] = res.out[(size_t)src_row[c] * res.np + i];
   }
-  if (ctrl) for (size_t i = 0; i < res.ctrl.size(); i++) ctrl[i] = res.ctrl[i];
+  if (ctrl) {   // s axis then l axis, 6 S each; a buffer too small for 12 S receives the first ctrl_cap of them
+    const size_t n_ctrl = res.ctrl.size() < (size_t)ctrl_cap ? res.ctrl.size() : (size_t)ctrl_cap;
+    for (size_t i = 0; i < n_ctrl; i++) ctrl[i] = res.ctrl[i];
+  }
   return cost;
 }

@@ -7,8 +7,43 @@ all_gather (RCCL has no MINLOC) followed by a local min; ties go to the lowest g
 so every rank picks the same winner.  Backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in
 the CPU tests.
 """
+import datetime
+import os
+
 import torch
 import torch.distributed as dist
+
+# A collective that does not complete within this time fails instead of hanging (a rank that died, a link that does not
+# come up): the failing rank exits non-zero and the launcher (torch.distributed.run) ends the others.
+COLLECTIVE_TIMEOUT_S = 60
+
+
+def init_process_group(backend, local_rank=0, timeout_s=COLLECTIVE_TIMEOUT_S):
+    """torch.distributed.init_process_group for one process per GPU (rendezvous from the launcher's environment:
+    RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) with a finite timeout on every collective.  backend "nccl" is RCCL on
+    ROCm: the communicator is bound to this rank's device at once (device_id), so a first-contact problem -- no xGMI
+    peer access, IPC handles refused -- shows here, before the first timed step, not inside it.
+    HSA_ENABLE_IPC_MODE_LEGACY=0 is kept in the environment of every rank (set if absent): this pool's host driver
+    supports dmabuf IPC only, and RCCL's peer buffers fail with `hipIpcGetMemHandle: invalid argument` without it (the
+    image exports it; a launcher that scrubs the environment would lose it)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    timeout = datetime.timedelta(seconds=timeout_s)
+    if backend == "nccl":
+        dist.init_process_group("nccl", timeout=timeout, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend, timeout=timeout)
+
+
+def _all_gather_records(rec, group=None):
+    """rec [n][w] int64 of every rank -> [world][n][w], by ONE all_gather_into_tensor on a preallocated buffer on rec's
+    device (no Python list of tensors, no torch.stack; under nccl no host hop).  gloo dry runs of device tensors go
+    through the host, as gloo has no device transport here."""
+    world = dist.get_world_size(group)
+    dev = rec.device
+    src = rec.cpu() if (dist.get_backend(group) == "gloo" and rec.is_cuda) else rec
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src.contiguous(), group=group)     # raises on a size mismatch: same n on every rank
+    return out.view((world,) + tuple(src.shape)).to(dev)
 
 
 def shard_bounds(B, world, rank):
@@ -38,11 +73,7 @@ def global_argmin(best_cost, best_idx, group=None, ctx=None):
     assert best_cost.shape == best_idx.shape and best_cost.dim() == 1
     pair = torch.stack([best_cost.to(torch.float64).view(torch.int64), best_idx.to(torch.int64)], dim=-1).contiguous()
     dev = pair.device
-    if dist.get_backend(group) == "gloo" and pair.is_cuda:   # CPU dry runs of the multi-rank flow
-        pair = pair.cpu()
-    gathered = [torch.empty_like(pair) for _ in range(world)]
-    dist.all_gather(gathered, pair, group=group)             # raises on a size mismatch: same n on every rank
-    allp = torch.stack(gathered).to(dev)                     # [world, n, 2] int64
+    allp = _all_gather_records(pair, group)                  # [world, n, 2] int64
     if ctx is not None and allp.is_cuda:
         n = allp.shape[1]
         out_c = torch.empty(n, dtype=torch.float64, device=dev); out_i = torch.empty(n, dtype=torch.int64, device=dev)
@@ -83,11 +114,7 @@ def global_argmin_with_winner(best_cost, best_idx, local_ctrl, group=None, ctx=N
     rec = torch.cat([best_cost.to(torch.float64).view(torch.int64)[:, None], best_idx.to(torch.int64)[:, None],
                      local_ctrl.to(torch.float64).contiguous().view(torch.int64)], dim=1).contiguous()   # [n][2 + P] int64
     dev = rec.device
-    if dist.get_backend(group) == "gloo" and rec.is_cuda:
-        rec = rec.cpu()
-    gathered = [torch.empty_like(rec) for _ in range(world)]
-    dist.all_gather(gathered, rec, group=group)
-    allr = torch.stack(gathered).to(dev)                                  # [world][n][2 + P]
+    allr = _all_gather_records(rec, group)                                # [world][n][2 + P]
     pairs = allr[..., :2].contiguous()
     if ctx is not None and pairs.is_cuda:
         out_c = torch.empty(n, dtype=torch.float64, device=dev); out_i = torch.empty(n, dtype=torch.int64, device=dev)

@@ -105,7 +105,7 @@ EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "bt
            "btrapz_device_count", "btrapz_solve_batch_device", "btrapz_argmin_device",
            "btrapz_sample_device", "btrapz_solve_batch_host", "btrapz_solve_ragged_device",
            "btrapz_corridor_batch_device", "btrapz_sample_ragged_device", "btrapz_solve_warm_device",
-           "btrapz_eval_states_device", "btrapz_find_traj_mem", "btrapz_prism_bounds_device",
+           "btrapz_eval_states_device", "btrapz_find_traj_mem", "btrapz_find_traj_mem_cap", "btrapz_prism_bounds_device",
            "btrapz_prism_corridor_batch_device",
            "btrapz_find_traj_last_iterations", "btrapz_argmin_pairs_device", "btrapz_options_init",
            "btrapz_rescue_violations_device", "btrapz_find_traj_last_status", "btrapz_debug_mqm_tables",
@@ -166,6 +166,9 @@ def lib():
         l.btrapz_find_traj_mem.argtypes = [C.c_int, C.POINTER(CTrajInput), C.POINTER(CParams), C.c_int, C.c_void_p,
                                            C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int)]
         l.btrapz_find_traj_mem.restype = C.c_double
+        l.btrapz_find_traj_mem_cap.argtypes = [C.c_int, C.POINTER(CTrajInput), C.POINTER(CParams), C.c_int, C.c_void_p,
+                                               C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        l.btrapz_find_traj_mem_cap.restype = C.c_double
         l.btrapz_corridor_from_file.argtypes = [C.c_int, C.c_char_p, C.POINTER(CSegment), C.c_int]
         l.btrapz_corridor_from_file.restype = C.c_int
         l.btrapz_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
@@ -411,9 +414,9 @@ class TrajCall:
         self.cap = int(cap if cap is not None else 4 * kb.N + 16)
         self.traj = np.zeros((7, self.cap)); self.ctrl = np.zeros(12 * 256)
         self.n, self.S = C.c_int(0), C.c_int(0)
-        self._fn = lib().btrapz_find_traj_mem
+        self._fn = lib().btrapz_find_traj_mem_cap      # (control points of up to 256 segments: the buffer's size goes along)
         self._args = (self.variant, C.byref(self.ti), C.byref(self.cp), self.cap, self.traj.ctypes.data, C.byref(self.n),
-                      self.ctrl.ctypes.data, C.byref(self.S))
+                      self.ctrl.ctypes.data, self.ctrl.size, C.byref(self.S))
 
     def __call__(self, copy=True):
         """(cost, traj [7][n] rows t s l ds dl dds ddl, ctrl [12 S]); cost == 1e11 on failure (traj, ctrl None).

@@ -98,3 +98,16 @@ def test_config5_sharded_by_agent_replans_every_agent_as_one_gpu_does():
     assert "no collective" in two["parallelism"]
     three = run_mpc("--cold", "--gpus", "3", "--backend", "gloo", "--share-device")    # 6 agents over 3 ranks
     assert three["last_winners"] == one["last_winners"]
+
+
+def test_two_gpus_over_rccl():
+    """The N > 1 flow on real hardware: bench.py --gpus 2 with backend nccl (= RCCL over xGMI), one process per GPU.
+    Needs two devices; the 1-GPU box of the GPU tier skips it (the gloo flows above cover the code path, not the
+    transport).  Strong scaling: the winner is the 1-rank winner of the same batch."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices (RCCL has not run anywhere yet: SCALE_r0x skipped for want of a node)")
+    one = run("--gpus", "1", "--scaling", "strong")
+    two = run("--gpus", "2", "--scaling", "strong", "--backend", "nccl")
+    assert two["n_gpus"] == 2 and "rccl" in two["config"]["collective"]
+    assert two["winner"] == one["winner"]

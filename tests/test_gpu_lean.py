@@ -140,3 +140,21 @@ def test_lean_on_ragged_batches(solver):
         assert (np.abs(l["ctrl"][ok] - p["ctrl"][ok]) <= 1e-6 * scale).all()
         assert np.array_equal(l["status"], l2["status"]) and np.array_equal(l["iters"], l2["iters"]) and np.array_equal(l["cost"], l2["cost"])
         assert np.array_equal(l["ctrl"][ok], l2["ctrl"][ok])
+
+
+@pytest.mark.parametrize("lean", [-1, 1])
+def test_hand_over_at_any_iteration_changes_nothing(solver, lean):
+    """the iterate a group hands over has been evaluated by the first launch (best iterate, stall marks, the
+    second chance of a solve whose complementarity is stuck); the second launch must not evaluate it again -- a solve
+    granted its second chance on the very iterate it hands over would otherwise end there.  Caps from 3 to 22 put the
+    hand-over on every iteration a solve of these batches (16 % stalling candidates, second-chance candidates among
+    them) goes through: statuses, iteration counts, costs and control points are the one-launch solve's, bit for bit."""
+    for make in (lambda: synth.make_scenario1_batch(8192, 20, 1), lambda: synth.make_scenario1_batch(8192, 20, 0)):
+        batch, sh = make()
+        one, _ = run(solver, batch, sh, lean=lean, cap_iter=-1)
+        ok = one["status"] > 0
+        for cap in range(3, 23):
+            two, form = run(solver, batch, sh, lean=lean, cap_iter=cap)
+            assert form == (11 if lean > 0 else 3)
+            assert np.array_equal(one["status"], two["status"]) and np.array_equal(one["iters"], two["iters"]), cap
+            assert np.array_equal(one["cost"], two["cost"]) and np.array_equal(one["ctrl"][ok], two["ctrl"][ok]), cap

@@ -83,6 +83,29 @@ def test_find_traj_on_a_long_horizon():
     assert np.abs(traj[1] - smp[0]).max() <= 1e-4 * max(1.0, np.abs(smp[0]).max())      # s column against x*'s samples
 
 
+def test_control_point_buffer_of_the_64_segment_contract_is_not_overrun():
+    """btrapz_find_traj_mem's ctrl argument is [12 * 64] (its contract before horizons beyond 64 segments were solved): on
+    a longer horizon the first 12 * 64 values are written, S is reported, and nothing behind the buffer is touched;
+    btrapz_find_traj_mem_cap with the buffer's size returns them all."""
+    import ctypes as C
+    kb = synth.scenario1_knots(1, 80)
+    params = native.CParams(*[float(v) for v in synth.REFERENCE_WEIGHTS], 1)
+    call = native.TrajCall(0, params, kb, cap=4096)
+    cost, traj, full = call()
+    S = len(full) // 12
+    assert cost < 1e10 and S > 64
+    buf = np.full(12 * 64 + 64, -7.0)                       # 64 guard values behind the contract's size
+    n, ns = C.c_int(0), C.c_int(0)
+    t = np.zeros((7, 4096))
+    c2 = native.lib().btrapz_find_traj_mem(0, C.byref(call.ti), C.byref(call.cp), 4096, t.ctypes.data, C.byref(n), buf.ctypes.data, C.byref(ns))
+    assert c2 == cost and ns.value == S
+    assert np.array_equal(buf[:12 * 64], full[:12 * 64]) and (buf[12 * 64:] == -7.0).all()
+    small = np.full(100 + 8, -7.0)
+    c3 = native.lib().btrapz_find_traj_mem_cap(0, C.byref(call.ti), C.byref(call.cp), 4096, t.ctypes.data, C.byref(n), small.ctypes.data, 100, C.byref(ns))
+    assert c3 == cost and np.array_equal(small[:100], full[:100]) and (small[100:] == -7.0).all()
+    assert native.lib().btrapz_find_traj_mem_cap(0, C.byref(call.ti), C.byref(call.cp), 4096, t.ctypes.data, C.byref(n), None, 5, C.byref(ns)) == 100000000000.0
+
+
 @pytest.mark.parametrize("case,variant", [("s712_it11_v1", 1), ("s755_it2486_v1", 1)])
 def test_rescue_pass_of_the_long_form(case, variant):
     """Two corridors of 76 and 65 segments the round-3 fuzz campaign found (tests/fuzz/cases/): no feasible trajectory,

@@ -176,3 +176,27 @@ def test_bench_refuses_more_ranks_than_devices():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 3 and "HIP device" in p.stderr and p.stdout.strip() == ""
+
+
+def _launch(env_extra, timeout):
+    import subprocess, sys, time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank_fail_worker.py")],
+                       capture_output=True, text=True, env=env, timeout=timeout)
+    return p, time.time() - t0
+
+
+def test_a_failing_rank_ends_the_launch():
+    """First-contact hardening: process groups are created with a finite timeout
+    (spectral_amd.dist.init_process_group); a rank that dies before its first collective makes the launcher return
+    non-zero -- it ends the rank that is waiting in the all-gather -- instead of hanging.  The healthy launch of the same
+    worker returns 0 and both ranks agree on the winner."""
+    ok, _ = _launch({"FAIL_RANK": "-1"}, 240)
+    assert ok.returncode == 0, ok.stderr[-1500:]
+    assert "rank 0 winner 0" in ok.stdout and "rank 1 winner 0" in ok.stdout
+    bad, dt = _launch({"FAIL_RANK": "1", "COLLECTIVE_TIMEOUT_S": "20"}, 240)
+    assert bad.returncode != 0 and dt < 120, (bad.returncode, dt)
+    assert "fails before its first collective" in bad.stderr

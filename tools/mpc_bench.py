@@ -98,10 +98,8 @@ def main(argv=None):
             sys.stdout.flush()
             saved_fd = os.dup(1); os.dup2(2, 1)     # (gloo announces its connections on the C-level stdout)
             try:
-                if a.backend == "nccl":
-                    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-                else:
-                    dist.init_process_group(a.backend)
+                from spectral_amd.dist import init_process_group
+                init_process_group(a.backend, local_rank)
             finally:
                 os.dup2(saved_fd, 1); os.close(saved_fd)
             own_pg = True
