@@ -153,6 +153,21 @@ bool read_traj_input(const std::string &path, TrajInput &in) {
   return true;
 }
 
+bool write_trajectory_file(const std::string &path, int np, double delta, const double *s, const double *l, const double *ds,
+                           const double *dl, const double *dds, const double *ddl) {
+  FILE *f = fopen(path.c_str(), "w");
+  if (!f) return false;
+  std::string text;
+  text.reserve((size_t)(np > 0 ? np : 0) * 64);
+  char num[FORMAT_3_MAX + 1];
+  for (int i = 0; i < np; i++) {
+    const double row[7] = {i * delta, s[i], l[i], ds[i], dl[i], dds[i], ddl[i]};
+    for (int c = 0; c < 7; c++) { int n = format_3(num, row[c]); num[n++] = c < 6 ? ' ' : '\n'; text.append(num, (size_t)n); }
+  }
+  const bool ok = fwrite(text.data(), 1, text.size(), f) == text.size();
+  return fclose(f) == 0 && ok;
+}
+
 // ---- per-obstacle extraction and selection: thin std::vector wrappers over corridor_core.h ----------
 static Segment to_segment(const Seg &c) {
   Segment s;

@@ -48,6 +48,10 @@ bool read_traj_input(const std::string &path, TrajInput &in);
 double parse_double(const char *p, const char **end);
 enum { FORMAT_3_MAX = 336 };         // "-" + 309 digits + ".000" + NUL of the largest double
 int format_3(char *out, double v);   // out: FORMAT_3_MAX bytes
+// The reference's trajectory file (trp_wrapper.cpp:288-301 / cub_wrapper.cpp:268-279): one row per sample, fixed, 3
+// decimals: i*delta s l ds dl dds ddl.  false when the file cannot be written.
+bool write_trajectory_file(const std::string &path, int np, double delta, const double *s, const double *l, const double *ds,
+                           const double *dl, const double *dds, const double *ddl);
 
 // CorridorGeneration + CorridorSplit for one obstacle's bounds.
 std::vector<Segment> extract_segments(int variant, int N, double delta, const Bounds &sb, const Bounds &lb);

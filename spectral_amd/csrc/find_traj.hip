@@ -22,6 +22,7 @@
 
 #include "btrapz_device.h"
 #include "corridor.hpp"
+#include "traj_cost.h"
 
 using namespace btrapz;
 
@@ -136,58 +137,6 @@ ElasticEnv elastic_env() {
   ElasticEnv r = {!(e && *e == '0'), 0.0};
   if (t) { const double v = atof(t); if (v > 0) r.tol = v; }
   return r;
-}
-
-int clampi(int i, int hi) { return i < 0 ? 0 : (i > hi ? hi : i); }
-
-// a_cost of trp_wrapper.cpp:207-286 / cub_wrapper.cpp:201-262.  Reads of x_ref[i] past N
-// and of l[N-1] past the sampled length (undefined in the reference) are clamped.
-double trajectory_cost(int variant, const Params &p, const TrajInput &in, int np, const double *s, const double *ds,
-                       const double *dds, const double *l, const double *dl, const double *ddl) {
-  const double dt = in.delta;
-  const int N = in.N;
-  double s_cost = 0.0, l_cost = 0.0, max_a = 0.0;
-  for (int i = 0; i < np; ++i) {
-    const double jerk = (i == 0) ? (dds[np > 1 ? 1 : 0] - dds[0]) / dt : (dds[i] - dds[i - 1]) / dt;
-    const double e = s[i] - in.s_ref[clampi(i, N - 1)];
-    if (variant == BTRAPZ_TRAPEZOID) {
-      s_cost += p.weight_s_ref * e * e * dt;
-      s_cost += p.weight_ds_ref * ds[i] * ds[i] * dt;
-      s_cost += p.s_acc_weight * dds[i] * dds[i] * dt;
-      s_cost += p.s_jerk_weight * jerk * jerk * dt;
-    } else {
-      s_cost += e * e * dt;
-      s_cost += ds[i] * ds[i] * dt;
-      s_cost += dds[i] * dds[i] * dds[i] * dds[i] * dt;
-      s_cost += jerk * jerk * jerk * jerk * dt;
-    }
-    max_a = std::fmax(max_a, std::fabs(dds[i]));
-  }
-  if (variant == BTRAPZ_CUBOID) s_cost += max_a * max_a * max_a * max_a;
-  max_a = 0.0;
-  for (int i = 0; i < np; ++i) {
-    const double jerk = (i == 0) ? (ddl[np > 1 ? 1 : 0] - ddl[0]) / dt : (ddl[i] - ddl[i - 1]) / dt;
-    const double e = l[i] - in.l_ref[clampi(i, N - 1)];
-    if (variant == BTRAPZ_TRAPEZOID) {
-      l_cost += p.weight_l_ref * e * e * dt;
-      l_cost += p.weight_dl_ref * dl[i] * dl[i] * dt;
-      l_cost += p.l_acc_weight * ddl[i] * ddl[i] * dt;
-      l_cost += p.l_jerk_weight * jerk * jerk * dt;
-    } else {
-      l_cost += e * e * dt;
-      l_cost += dl[i] * dl[i] * dt;
-      l_cost += ddl[i] * ddl[i] * dt;
-      l_cost += jerk * jerk * dt;
-    }
-    max_a = std::fmax(max_a, std::fabs(ddl[i]));
-  }
-  if (variant == BTRAPZ_TRAPEZOID) {
-    const double e = l[clampi(N - 1, np - 1)] - in.l_ref[N - 1];
-    l_cost += p.weight_end_l * e * e * dt;
-  } else {
-    l_cost += max_a * max_a;
-  }
-  return s_cost + l_cost;
 }
 
 }  // namespace
@@ -434,19 +383,8 @@ BTRAPZ_EXPORT double btrapz_find_traj(int variant, const char *input_path, const
   const double *l = &res.out[(size_t)3 * max_points], *dl = &res.out[(size_t)4 * max_points], *ddl = &res.out[(size_t)5 * max_points];
 
   // trajectory file: trp_wrapper.cpp:288-301 (fixed, 3 decimals)
-  if (FILE *f = fopen(out_path.c_str(), "w")) {
-    std::string text;
-    text.reserve((size_t)max_points * 64);
-    char num[FORMAT_3_MAX + 1];
-    for (int i = 0; i < max_points; i++) {
-      const double row[7] = {i * in.delta, s[i], l[i], ds[i], dl[i], dds[i], ddl[i]};
-      for (int c = 0; c < 7; c++) { int n = format_3(num, row[c]); num[n++] = c < 6 ? ' ' : '\n'; text.append(num, (size_t)n); }
-    }
-    fwrite(text.data(), 1, text.size(), f);
-    fclose(f);
-  } else if (verbose()) {
+  if (!write_trajectory_file(out_path, max_points, in.delta, s, l, ds, dl, dds, ddl) && verbose())
     fprintf(stderr, "btrapz: cannot write '%s'\n", out_path.c_str());
-  }
   return cost;
 }
 

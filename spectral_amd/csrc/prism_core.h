@@ -4,7 +4,11 @@
 // Reference: Car.getCar + get_bounds of the harness, src/cart_frenet.py:664-1030; lineFromPoints :818-830.
 #ifndef BTRAPZ_PRISM_CORE_H
 #define BTRAPZ_PRISM_CORE_H
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#endif
+// (a host compiler -- the sanitizer build, host_check/ -- brings its own definitions of __device__, double2,
+//  __syncthreads and __ballot: one thread per lane, a real barrier)
 
 #include "btrapz_device.h"
 
