@@ -339,28 +339,51 @@ def main():
                        # every rank holds the winner's control points after the step; their checksum and first values
                        "ctrl_sum": float(wctrl[0].sum().item()), "ctrl_head": [float(v) for v in wctrl[0, :4].tolist()]},
         }
-        # second figure: the other workload family, same shape, a short run (not the headline)
-        if world == 1 and not a.no_secondary:
-            other = "generic" if a.workload == "scenario1" else "scenario1"
-            b2, sh2 = make_workload(other, B, S, a.variant, 0)
+        # The other BASELINE configurations and the other workload family, in the same (driver-timed) run: a short timed
+        # loop each, with the figures of the headline -- kernel time of the whole solve call by HIP events, roofline of
+        # the algorithmic bytes, useful FP64 rate -- and, where not every candidate has a solution (scenario_1's late slow
+        # obstacle; the cuboid variant's empty inscribed intervals, which end before the first iteration), the rate of
+        # the SOLVED candidates beside the rate of all.
+        def timed_config(label, generator, b2, sh2, variant2):
             d2 = solver.upload(b2)
             for _ in range(2):
-                solver.solve(d2, sh2)
+                solver.solve(d2, sh2, lean=a.lean)
             torch.cuda.synchronize(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = max(3, min(10, a.steps))
             e0.record()
             for _ in range(reps):
-                o2 = solver.solve(d2, sh2)
+                o2 = solver.solve(d2, sh2, lean=a.lean)
             e1.record()
             torch.cuda.synchronize(dev)
             ms2 = e0.elapsed_time(e1) / reps
+            form2 = solver.ctx.last_solve_form()
             st2 = o2["status"].cpu().numpy()
-            out["secondary"] = {"workload": workload_label(other, B, S, a.variant, 1, "weak"), "generator": other,
-                                "kernel_ms": ms2, "solves_per_s_kernel_only": B / (ms2 * 1e-3),
-                                "solved_fraction": float(np.mean((st2 == 1) | (st2 == 2))),
-                                "mean_ipm_iterations": float(np.mean(o2["iters"].cpu().numpy() + 1))}
-            del d2
+            ok2 = (st2 == 1) | (st2 == 2)
+            it2 = float(np.mean(o2["iters"].cpu().numpy() + 1))
+            B2, S2 = b2.B, b2.S
+            gbs = b2.algorithmic_bytes() * B2 / (ms2 * 1e-3) / 1e9
+            tfl = 2.0 * B2 * S2 * it2 * FLOPS_PER_SEGMENT_ITER / (ms2 * 1e-3) / 1e12
+            return {"workload": label, "generator": generator, "batch": B2, "segments": S2, "variant": variant2,
+                    "kernel": SOLVE_FORMS.get(form2, "btrapz::ipm_solve_kernel").split(" (")[0], "kernel_ms": ms2,
+                    "solves_per_s_kernel_only": B2 / (ms2 * 1e-3), "solved_fraction": float(ok2.mean()),
+                    "solved_solves_per_s_kernel_only": float(ok2.sum()) / (ms2 * 1e-3), "mean_ipm_iterations": it2,
+                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_solve": b2.algorithmic_bytes(),
+                                 "fp64_valu": {"achieved_tflops": tfl, "peak_tflops": FP64_VALU_PEAK_TFLOPS, "frac": tfl / FP64_VALU_PEAK_TFLOPS}}}
+        out["solved_solves_per_s"] = value * solved
+        if world == 1 and not a.no_secondary:
+            from spectral_amd import synth as _sy
+            other = "generic" if a.workload == "scenario1" else "scenario1"
+            b2, sh2 = make_workload(other, B, S, a.variant, 0)
+            out["secondary"] = timed_config(workload_label(other, B, S, a.variant, 1, "weak"), other, b2, sh2, a.variant)
+            if not (B == 4096 and S == 10 and a.variant == 0):
+                b2, sh2 = _sy.make_batch(4096, 10, config=2)
+                out["config2"] = timed_config("BASELINE config 2: " + workload_label("generic", 4096, 10, 0, 1, "weak"), "generic", b2, sh2, 0)
+            if not (a.variant == 1 and a.workload == "scenario1"):
+                b2, sh2 = make_workload("scenario1", B, S, 1, 0)
+                out["config4"] = timed_config("BASELINE config 4: " + workload_label("scenario1", B, S, 1, 1, "weak"), "scenario1", b2, sh2, 1)
+            del b2
         # the other named configurations, in the same (driver-timed) run: BASELINE config 5 (receding horizon, one GPU)
         # and the knot-level pipeline through the tools that profiles/ documents
         keep = lambda d, keys: {k: d[k] for k in keys if k in d}
@@ -374,11 +397,15 @@ def main():
                 out["config5_one_gpu"] = keep(m, ("workload", "achieved_hz", "target_hz", "p50_step_ms", "p99_step_ms",
                                                   "mean_ipm_iterations", "solved_fraction_mean", "candidates_per_s"))
                 pl = tool("pipeline_bench", ["--reps", "3"])
-                out["pipeline_knots_to_control_points"] = keep(pl, ("workload", "corridor_ms", "ragged_solve_ms",
+                out["pipeline_knots_to_control_points"] = keep(pl, ("workload", "corridor_ms", "ragged_solve_ms", "ragged_solve_form",
                                                                     "end_to_end_candidates_per_s", "solved_fraction", "corridor_roofline"))
+                if "solved_fraction" in pl and "end_to_end_candidates_per_s" in pl:
+                    out["pipeline_knots_to_control_points"]["end_to_end_solved_candidates_per_s"] = pl["end_to_end_candidates_per_s"] * pl["solved_fraction"]
                 pp = tool("pipeline_bench", ["--reps", "3", "--prisms"])
-                out["pipeline_prisms_to_control_points"] = keep(pp, ("workload", "prism_ms", "corridor_ms", "ragged_solve_ms",
-                                                                     "end_to_end_scenes_per_s", "prism_roofline", "corridor_roofline"))
+                out["pipeline_prisms_to_control_points"] = keep(pp, ("workload", "prism_ms", "corridor_ms", "ragged_solve_ms", "ragged_solve_form",
+                                                                     "end_to_end_scenes_per_s", "solved_fraction", "prism_roofline", "corridor_roofline"))
+                if "solved_fraction" in pp and "end_to_end_scenes_per_s" in pp:
+                    out["pipeline_prisms_to_control_points"]["end_to_end_solved_scenes_per_s"] = pp["end_to_end_scenes_per_s"] * pp["solved_fraction"]
             except Exception as e:                                  # the headline must not depend on the extras
                 out["extras_error"] = repr(e)[:200]
         # p50 latency of ONE solve (B = 1), inputs resident, including the sync
