@@ -56,13 +56,20 @@ def main():
             rec = {"input": name, "variant": v, "segments": int(S), "port_status": int(info.status), "port_iters": int(info.iter),
                    "port_accepts": bool(info.status in (1, 2)), "exact_status": None, "exact_iters": None,
                    "least_violation": None, "class_violation": None, "port_class_violation": None,
-                   "inconsistent_bounds": False}
+                   "inconsistent_bounds": False, "port_vs_xstar_rel": None, "port_vs_xstar_abs": None}
             inp = O.ParsedInput(path)
             n, cb = O.pipeline(v, inp)
             if n >= 1:
                 qp = O.AssembledQp(v, cb, p, inp)
                 x, y, ie = qp.solve_exact()
                 rec["exact_status"], rec["exact_iters"] = int(ie.status), int(ie.iter)
+                # how far the reference's OWN answer (the OSQP port's stopping point: eps 1e-5, no polish) is from the
+                # optimum it approximates, where both exist -- relative on the control points (north_star's measure) and
+                # in the control points' own unit
+                if info.status in (1, 2) and ie.status in (1, 2):
+                    xp = np.asarray(ctrl, dtype=float)
+                    rec["port_vs_xstar_rel"] = float(np.abs(xp - x).max() / np.abs(x).max())
+                    rec["port_vs_xstar_abs"] = float(np.abs(xp - x).max())
                 rec["inconsistent_bounds"] = bool((qp.l > qp.u + 1e-12).any())
                 if ie.status not in (1, 2) and not rec["inconsistent_bounds"]:
                     xe, _, _, viol = qp.solve_elastic()
@@ -78,12 +85,13 @@ def main():
     json.dump({"weights": [float(t) for t in w], "elastic_tol": ELASTIC_TOL, "rows": rows},
               open(os.path.join(HERE, "acceptance_table.json"), "w"), indent=1)
     if "--markdown" in sys.argv:
-        print("| input | variant | S | OSQP port: status (iterations) | reference returns | exact method | least violation / |g| (pos m, vel, acc, jerk) | product returns | |")
-        print("|---|---|---|---|---|---|---|---|---|")
+        print("| input | variant | S | OSQP port: status (iterations) | reference returns | port vs x*: rel (abs) | exact method | least violation / |g| (pos m, vel, acc, jerk) | product returns | |")
+        print("|---|---|---|---|---|---|---|---|---|---|")
         for r in rows:
-            print("| `%s.txt` | %s | %d | %d (%d) | %s | %s | %s | %s | %s |" % (
+            print("| `%s.txt` | %s | %d | %d (%d) | %s | %s | %s | %s | %s | %s |" % (
                 r["input"], "trapezoid" if r["variant"] == 0 else "cuboid", r["segments"], r["port_status"], r["port_iters"],
                 "trajectory" if r["port_accepts"] else "`1e11`",
+                "—" if r["port_vs_xstar_rel"] is None else "%.1e (%.2g)" % (r["port_vs_xstar_rel"], r["port_vs_xstar_abs"]),
                 "x* in %d iterations" % r["exact_iters"] if r["exact_status"] in (1, 2) else ("`l > u` rows" if r["inconsistent_bounds"] else "no solution"),
                 "—" if r["least_violation"] is None else "%.4f (%s)%s" % (
                     r["least_violation"], ", ".join("%.3g" % v for v in r["class_violation"]),

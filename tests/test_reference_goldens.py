@@ -148,3 +148,32 @@ def test_scenario1_lateral_columns_are_reproduced_by_fitted_weights(ref, name, v
     # the best starts of the fit ended at the same longitudinal residual: a floor, not a miss of the search
     r = fit["s"]["residuals_of_all_starts"]
     assert r[4] - r[0] <= 1e-3
+
+
+def test_distance_of_the_references_own_answer_from_the_optimum_is_tabulated():
+    """parity is held against the QP's optimum x*, not against OSQP's stopping point.  How far the two are
+    apart is a property of the reference (eps 1e-5, no polish, 5000 iterations), pinned here per bundled input by the
+    oracle's OSQP port: north_star's 1e-4 on control points holds against the reference's OUTPUT only where OSQP itself
+    converged that far -- scenario_1 (c1) -- and cannot hold on c3 (4e-3), c_road_s1_3 (5e-3) or c4 / c5, whose saved
+    reference trajectories are the unconverged iterate after 5000 iterations (0.34 control-point units off)."""
+    import json
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    table = json.load(open(os.path.join(gold, "acceptance_table.json")))
+    rows = {(r["input"], r["variant"]): r for r in table["rows"]}
+    w = np.loadtxt(os.path.join(gold, "inputs", "weights.txt"))
+    p = O.params_from_weights(w)
+    for key in (("c1", 0), ("c2", 1), ("c3", 0), ("c4", 0)):
+        path = os.path.join(gold, "inputs", key[0] + ".txt")
+        _, _, xp, _, info = O.find_traj(key[1], path, None, p)
+        inp = O.ParsedInput(path)
+        n, cubes = O.pipeline(key[1], inp)
+        x, _, ie = O.AssembledQp(key[1], cubes, p, inp).solve_exact()
+        assert ie.status in (1, 2) and info.status == rows[key]["port_status"]
+        rel = np.abs(np.asarray(xp) - x).max() / np.abs(x).max()
+        assert abs(rel - rows[key]["port_vs_xstar_rel"]) <= 1e-3 * rows[key]["port_vs_xstar_rel"] + 1e-9
+    both = [r for r in table["rows"] if r["port_vs_xstar_rel"] is not None]
+    assert len(both) == 13
+    assert rows[("c1", 0)]["port_vs_xstar_rel"] < 1e-5 and rows[("c1", 1)]["port_vs_xstar_rel"] < 1e-4
+    assert sum(r["port_vs_xstar_rel"] <= 1e-4 for r in both) == 2           # only scenario_1 meets 1e-4 against the reference's output
+    assert max(r["port_vs_xstar_rel"] for r in both if r["port_status"] == 1) < 5e-3
+    assert all(abs(r["port_vs_xstar_abs"] - 0.341) < 1e-3 for r in both if r["port_status"] == 2 and r["input"] in ("c4", "c5"))
