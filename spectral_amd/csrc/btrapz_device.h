@@ -125,6 +125,7 @@ __global__ void ipm_solve_lean_ordered_kernel(const KernelArgs a, const double *
 __global__ void ipm_solve_lean_capped_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void ipm_solve_lean_capped_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void ipm_solve_lean_resume_kernel(const KernelArgs a, const double *__restrict__ mqm);
+__global__ void ipm_solve_lean_resume_ragged_kernel(const KernelArgs a, const double *__restrict__ mqm);
 #define BTRAPZ_SUSPENDED (-7)   // internal: an axis problem the capped launch handed over (never leaves the library)
 __global__ void ipm_solve_long_kernel(const KernelArgs a, const double *__restrict__ mqm);          // 65..256 segments: one axis problem per workgroup
 __global__ void ipm_solve_long_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm);  // rescue pass of the long form (<= 192 segments)

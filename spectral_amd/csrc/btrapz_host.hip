@@ -437,7 +437,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     // Two wavefronts per SIMD (btrapz_options.lean / BTRAPZ_LEAN; btrapz_lean.hip): cold solves of at most 64 segments
     static const int lean_env = [] { const char *q = experiment_env("BTRAPZ_LEAN"); return q ? (*q == '0' ? -1 : 1) : 0; }();
     const int lean_opt = lean_env ? lean_env : (opt ? opt->lean : 0);
-    const bool lean_ok = !warm_kernel && !long_form && !split_on && !queue_on && S <= BTRAPZ_MAX_SEGMENTS && a.unc_start == 0;
+    const bool lean_ok = !warm_kernel && !long_form && !split_on && !queue_on && (S >= 3 || a.order) && S <= BTRAPZ_MAX_SEGMENTS && a.unc_start == 0;   // (uniform batches of one or two segments: the packed form -- only the list-reading lean kernels carry the end-lane fix-up)
     // Automatic: batches that give every SIMD its two wavefronts several times over.  Measured (tools/lean_bench.py,
     // scenario_1 x 20, packed -> lean, one launch): 512 candidates 0.375 -> 0.435 ms, 2 048 0.447 -> 0.517, 8 192 1.117 ->
     // 1.032, 16 384 1.964 -> 1.733, 65 536 7.05 -> 5.61: a lone wavefront per SIMD runs the packed form's shorter
@@ -516,7 +516,8 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       p2.bucket_S = ragged ? 0 : S;
       // (ragged: no candidate has more than min(S, 64) segments, so no wavefront holds fewer groups than that allows)
       const unsigned rblocks = 2u * (unsigned)(slots / (size_t)(64 / (S < 64 ? S : 64)) + 65);
-      if (lean_on) hipLaunchKernelGGL(ipm_solve_lean_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
+      if (lean_on && ragged) hipLaunchKernelGGL(ipm_solve_lean_resume_ragged_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
+      else if (lean_on) hipLaunchKernelGGL(ipm_solve_lean_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
       else hipLaunchKernelGGL(ipm_solve_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
       c->last_form = lean_on ? 11 : 3;
     } else if (long_form) {

@@ -29,7 +29,7 @@ namespace btrapz {
 enum { LN_LL = 0, LN_LU = 15, LN_RED = 30, LN_XB = 34, LN_XI = 37, LN_ROWS = 40 };
 enum { LEAN_SUSP_FIELDS = 3 + 4 * 15 + 3 + 8 };   // == SUSP_FIELDS of the packed form (the host sizes one workspace)
 
-template <bool ORDERED, bool CAPPED, bool RESUME>
+template <bool ORDERED, bool CAPPED, bool RESUME, bool SMALL_S>
 __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const double *__restrict__ mqm, double (*lds)[64],
                                                 const int wave_id, const int lane) {
   static_assert(!(CAPPED && RESUME), "one launch is the first or the second");
@@ -37,6 +37,12 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   constexpr bool FULL = false;
   constexpr int NR = 15;
   constexpr bool PERAXIS = RESUME;
+  // SMALL_S -- one or two segments: the root of the two-sided elimination is an end lane, and the neighbour it lacks is
+  // another group's lane: a fix-up in the sequential loops (wave-uniform branch; the two DPP directions kept apart until
+  // it: +2 % on every solve, measured).  Only the instantiations that serve ragged batches carry it -- a ragged batch may
+  // hold buckets of one or two segments; a uniform batch of fewer than three takes the packed form (btrapz_host.hip).
+  // (A template parameter of its own, not a function of ORDERED: the resume launch of a uniform batch reads lists too,
+  //  and it must run the arithmetic of the capped launch it carries on, instruction for instruction.)
   const int axis = __builtin_amdgcn_readfirstlane(wave_id & 1);
   int S, pair = wave_id >> 1, ncand = a.B, cand0 = 0;
   if constexpr (ORDERED) {
@@ -394,7 +400,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         // any group after cap_hi)
         const int nact = __popcll(__ballot(first && lane_in_group && valid && !done));
         const bool want = !done && valid && ((eit >= a.cap_iter && nact <= a.cap_alone) || eit >= a.cap_hi);
-        if (__any(want)) {
+        if (__builtin_expect(__any(want), 0)) {   // (rare: at most once per group)
           UNIFORM_BLOCK;
           wave_lds_sync();
           if (want && first) lds[LN_RED][lane] = (double)atomicAdd(a.susp_count, 1);
@@ -485,17 +491,20 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       UNROLL for (int i = 0; i < 6; i++) TF[i] = T[i];
       for (int step = 0; step <= m; ++step) {
         double zin[6], win[3];
-        {
+        if constexpr (SMALL_S) {
           double pz[6], nz[6], pw[3], nw[3];
           UNROLL for (int i = 0; i < 6; i++) { pz[i] = from_prev(Z[i]); nz[i] = from_next(Z[i]); }
           UNROLL for (int i = 0; i < 3; i++) { pw[i] = from_prev(wp[i]); nw[i] = from_next(wp[i]); }
-          if (S <= 2) {   // the root is an end lane: its missing neighbour is another group's lane (ragged batches: buckets of 1 or 2 segments)
+          if (S <= 2) {
             UNIFORM_BLOCK;
             UNROLL for (int i = 0; i < 6; i++) { pz[i] = first ? 0.0 : pz[i]; nz[i] = last ? 0.0 : nz[i]; }
             UNROLL for (int i = 0; i < 3; i++) { pw[i] = first ? 0.0 : pw[i]; nw[i] = last ? 0.0 : nw[i]; }
           }
           UNROLL for (int i = 0; i < 6; i++) zin[i] = pz[i] + nz[i];
           UNROLL for (int i = 0; i < 3; i++) win[i] = pw[i] + nw[i];
+        } else {   // (the unwanted neighbour still holds 0 when a lane's step comes: see the packed form)
+          UNROLL for (int i = 0; i < 6; i++) { const double p = from_prev(Z[i]), n = from_next(Z[i]); zin[i] = p + n; }
+          UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(wp[i]), n = from_next(wp[i]); win[i] = p + n; }
         }
         if (step == my_step) {
           double Sk[6], F[6];
@@ -539,11 +548,13 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       double w[3] = {0.0, 0.0, 0.0};
       for (int step = 0; step <= m; ++step) {
         double win[3];
-        {
+        if constexpr (SMALL_S) {
           double pw[3], nw[3];
           UNROLL for (int i = 0; i < 3; i++) { pw[i] = from_prev(w[i]); nw[i] = from_next(w[i]); }
           if (S <= 2) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) { pw[i] = first ? 0.0 : pw[i]; nw[i] = last ? 0.0 : nw[i]; } }
           UNROLL for (int i = 0; i < 3; i++) win[i] = pw[i] + nw[i];
+        } else {
+          UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(w[i]), n = from_next(w[i]); win[i] = p + n; }
         }
         if (step == my_step) {
           UNROLL for (int i = 0; i < 3; i++) u[i] -= win[i];
@@ -561,11 +572,13 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       UNROLL for (int i = 0; i < 3; i++) y[i] = mid ? dX[i] : 0.0;
       for (int step = m - 1; step >= 0; --step) {
         double xin[3];
-        {
+        if constexpr (SMALL_S) {
           double py[3], ny[3];
           UNROLL for (int i = 0; i < 3; i++) { py[i] = from_prev(y[i]); ny[i] = from_next(y[i]); }
           if (S <= 2) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) { py[i] = first ? 0.0 : py[i]; ny[i] = last ? 0.0 : ny[i]; } }
           UNROLL for (int i = 0; i < 3; i++) xin[i] = py[i] + ny[i];
+        } else {
+          UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(y[i]), n = from_next(y[i]); xin[i] = p + n; }
         }
         if (step == my_step) {
           UNROLL for (int i = 0; i < 3; i++) {
@@ -761,23 +774,27 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 #define LEAN_KERNEL __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 LEAN_KERNEL void ipm_solve_lean_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[LN_ROWS][64];
-  lean_solve_body<false, false, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
+  lean_solve_body<false, false, false, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 LEAN_KERNEL void ipm_solve_lean_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[LN_ROWS][64];
-  lean_solve_body<true, false, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
+  lean_solve_body<true, false, false, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 LEAN_KERNEL void ipm_solve_lean_capped_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[LN_ROWS][64];
-  lean_solve_body<false, true, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
+  lean_solve_body<false, true, false, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 LEAN_KERNEL void ipm_solve_lean_capped_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[LN_ROWS][64];
-  lean_solve_body<true, true, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
+  lean_solve_body<true, true, false, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
-LEAN_KERNEL void ipm_solve_lean_resume_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+LEAN_KERNEL void ipm_solve_lean_resume_kernel(const KernelArgs a, const double *__restrict__ mqm) {   // of a uniform batch
   __shared__ double lds[LN_ROWS][64];
-  lean_solve_body<true, false, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
+  lean_solve_body<true, false, true, false>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
+}
+LEAN_KERNEL void ipm_solve_lean_resume_ragged_kernel(const KernelArgs a, const double *__restrict__ mqm) {
+  __shared__ double lds[LN_ROWS][64];
+  lean_solve_body<true, false, true, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 }  // namespace btrapz

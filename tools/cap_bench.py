@@ -23,6 +23,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--caps", default="4,5,6,7,8,10")
+    ap.add_argument("--lean", type=int, default=0, help="btrapz_options.lean (0 automatic, 1 the two-wavefronts-per-SIMD form, -1 the packed form)")
     a = ap.parse_args(argv)
     caps = [int(c) for c in a.caps.split(",")]
     solver = BatchSolver(0)
@@ -39,15 +40,18 @@ def main(argv=None):
         ref = None
         for cap in [-1] + caps:       # -1: the one-launch solve (0 would be the library's automatic choice)
             for _ in range(2):
-                o = solver.solve(db, sh, split=-1, cap_iter=cap)
+                o = solver.solve(db, sh, split=-1, cap_iter=cap, lean=a.lean)
             torch.cuda.synchronize(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                o = solver.solve(db, sh, split=-1, cap_iter=cap)
+                o = solver.solve(db, sh, split=-1, cap_iter=cap, lean=a.lean)
             e1.record(); torch.cuda.synchronize(dev)
             res = {k: o[k].cpu().numpy().copy() for k in ("ctrl", "cost", "status", "iters")}
-            r = {"solve_ms": e0.elapsed_time(e1) / 5}
+            r = {"solve_ms": e0.elapsed_time(e1) / 5, "form": solver.ctx.last_solve_form()}
+            if cap > 0:
+                keys = solver.ctx.debug_resume_keys(a.batch)
+                r["handed_over_fraction"] = float((keys > 0).mean())
             if cap == -1:
                 ref = res
                 r["mean_iterations"] = float(res["iters"].mean() + 1)
