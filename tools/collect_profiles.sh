@@ -100,6 +100,15 @@ if [ "$QUICK" != "quick" ]; then
     step "corridor_pmc$i" "$OUT/corridor_pmc$i.json" rocprofv3 --pmc $group --output-format csv -d "$OUT/corridor_pmc$i" -- python3 "$ROOT/tools/pipeline_bench.py" --reps 2
   done
   step mpc_2rank "$OUT/mpc_warm_2rank_gloo.json" python3 "$ROOT/tools/mpc_bench.py" --gpus 2 --backend gloo --share-device
+  # round 4: the two-wavefronts-per-SIMD form against the packed one (one and two launches, small batches), its
+  # hand-over sweep, the sibling warm start, and the counters of both forms' kernels on the scenario_1 batch
+  step lean_bench "$OUT/lean_bench.json" python3 "$ROOT/tools/lean_bench.py" --oracle 64
+  for B in 512 2048 8192 16384; do
+    step lean_bench_$B "$OUT/lean_bench_B$B.json" python3 "$ROOT/tools/lean_bench.py" --batch $B --oracle 0 --reps 10 --cases 0,3
+  done
+  step cap_bench_lean "$OUT/cap_bench_lean.json" python3 "$ROOT/tools/cap_bench.py" --lean 1 --caps 5,6,7,8,10
+  step sibling_bench "$OUT/sibling_bench.json" python3 "$ROOT/tools/sibling_bench.py"
+  bash "$ROOT/tools/lean_pmc.sh" "$TAG/lean_pmc" 0 > "$OUT/lean_pmc.log" 2>&1 || echo "FAILED: lean_pmc" >> "$OUT/failed.txt"
 fi
 # keep only the CSVs (the merge-back limit is 64 MiB)
 find "$OUT" -name "*.db" -delete 2>/dev/null

@@ -97,7 +97,8 @@ def main():
             shutil.copy(max(pstats, key=os.path.getmtime), os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
     for name in ("mpc_warm", "mpc_cold", "mpc_warm_minfirst05", "mpc_cold_minfirst05", "pipeline", "pipeline_scenario1", "pipeline_prisms",
                  "pipeline_cap8", "pipeline_scenario1_cap8", "pipeline_prisms_cap8", "cap_bench",
-                 "bench_config2", "bench_config4", "bench_generic", "bench_2rank_gloo_strong", "split_bench", "mpc_warm_2rank_gloo"):
+                 "bench_config2", "bench_config4", "bench_generic", "bench_2rank_gloo_strong", "split_bench", "mpc_warm_2rank_gloo",
+                 "lean_bench", "lean_bench_B512", "lean_bench_B2048", "lean_bench_B8192", "lean_bench_B16384", "cap_bench_lean", "sibling_bench"):
         if os.path.exists(os.path.join(src, name + ".json")):
             # the tools print ONE JSON line; libraries may print before it (gloo announces its ranks on stdout)
             lines = [l for l in open(os.path.join(src, name + ".json")).read().splitlines() if l.lstrip().startswith("{")]
