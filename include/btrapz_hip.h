@@ -237,7 +237,8 @@ typedef struct btrapz_options {
    * multipliers in LDS, everything else recomputed: btrapz_lean.hip).  Same problem, same method, same termination rules;
    * results agree with the one-wavefront form to rounding.  0 -> automatic (batches of at least three wavefronts per
    * SIMD: below that the one-wavefront form's shorter instruction stream is faster); 1 -> whenever the solve qualifies;
-   * -1 -> never.  (Warm starts, the rescue pass, start = 1 and the candidate queue always run the one-wavefront form.) */
+   * -1 -> never.  (The rescue pass, start = 1 and the candidate queue always run the one-wavefront form; warm starts --
+   * btrapz_solve_warm_device -- have their instantiation of this form too, in one launch.) */
   int lean;
 } btrapz_options;
 /* Zeroes *opt (every field: "use the default") and sets struct_size.  Call it before filling the struct in. */

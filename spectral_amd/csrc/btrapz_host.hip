@@ -437,7 +437,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     // Two wavefronts per SIMD (btrapz_options.lean / BTRAPZ_LEAN; btrapz_lean.hip): cold solves of at most 64 segments
     static const int lean_env = [] { const char *q = experiment_env("BTRAPZ_LEAN"); return q ? (*q == '0' ? -1 : 1) : 0; }();
     const int lean_opt = lean_env ? lean_env : (opt ? opt->lean : 0);
-    const bool lean_ok = !warm_kernel && !long_form && !split_on && !queue_on && (S >= 3 || a.order) && S <= BTRAPZ_MAX_SEGMENTS && a.unc_start == 0;   // (uniform batches of one or two segments: the packed form -- only the list-reading lean kernels carry the end-lane fix-up)
+    const bool lean_ok = !long_form && !split_on && !queue_on && (S >= 3 || seg_count) && S <= BTRAPZ_MAX_SEGMENTS && a.unc_start == 0;   // (uniform batches of one or two segments: the packed form -- only the lean kernels of ragged batches carry the end-lane fix-up)
     // Automatic: batches that give every SIMD its two wavefronts several times over.  Measured (tools/lean_bench.py,
     // scenario_1 x 20, packed -> lean, one launch): 512 candidates 0.375 -> 0.435 ms, 2 048 0.447 -> 0.517, 8 192 1.117 ->
     // 1.032, 16 384 1.964 -> 1.733, 65 536 7.05 -> 5.61: a lone wavefront per SIMD runs the packed form's shorter
@@ -494,7 +494,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       p1.cap_iter = cap_iter; p1.cap_alone = BTRAPZ_CAP_ALONE; p1.cap_hi = cap_iter + BTRAPZ_CAP_HI; p1.susp_cap = (int)slots; p1.susp_state = c->d_susp_state; p1.susp_count = count;
       p1.susp_slot = slot_of; p1.susp_key = keys;
       if (lean_on) {
-        if (ragged) hipLaunchKernelGGL(ipm_solve_lean_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+        if (ragged) hipLaunchKernelGGL(ipm_solve_lean_capped_ragged_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
         else hipLaunchKernelGGL(ipm_solve_lean_capped_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
       } else {
         if (ragged) hipLaunchKernelGGL(ipm_solve_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
@@ -534,8 +534,10 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
                          (const double *)c->d_mqm);
     } else if (lean_on) {
       c->last_form = 8;
-      if (a.order) hipLaunchKernelGGL(ipm_solve_lean_ordered_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
-      else hipLaunchKernelGGL(ipm_solve_lean_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
+      const bool ragged_batch = seg_count != nullptr;   // (a.order without it: hint classes of a uniform batch)
+      auto lean_kernel = warm_kernel ? (ragged_batch ? ipm_solve_lean_warm_ragged_kernel : a.order ? ipm_solve_lean_warm_hint_kernel : ipm_solve_lean_warm_kernel)
+                                     : (ragged_batch ? ipm_solve_lean_ragged_kernel : a.order ? ipm_solve_lean_hint_kernel : ipm_solve_lean_kernel);
+      hipLaunchKernelGGL(lean_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
     } else {
       c->last_form = 0;
       hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);

@@ -125,7 +125,7 @@ def kernel_source_hash():
     the solve kernel's code (profiles/*.json carry it; bench.py refuses profiles of other kernel sources)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("btrapz_kernels.hip", "btrapz_lean.hip", "btrapz_ipm.h", "btrapz_device.h", "Makefile",
+    for f in ("btrapz_kernels.hip", "btrapz_lean.hip", "btrapz_lean_warm.hip", "btrapz_lean_body.h", "btrapz_ipm.h", "btrapz_device.h", "Makefile",
               os.path.join("..", "..", "include", "btrapz_hip.h")):
         with open(os.path.join(CSRC_DIR, f), "rb") as fh:
             h.update(fh.read())
@@ -286,9 +286,9 @@ class Context:
 
     def solve_warm_device(self, B, seg_stride, shared, seg, seg_count, init, ref_end, dl_bounds, ctrl, cost, status,
                           iters=None, x0=None, lam0=None, lam_out=None, mu0=0.0, smin=0.0, stream=None, max_iter=0,
-                          eps=0.0, hint=None, elastic=0, elastic_tol=0.0):
+                          eps=0.0, hint=None, elastic=0, elastic_tol=0.0, lean=0):
         """btrapz_solve_warm_device: seg_count None = uniform batch; x0 / lam0 / lam_out optional."""
-        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol)
+        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol, lean=lean)
         raw = lambda t: t.data_ptr() if t is not None else None
         warm = CWarm(raw(x0), raw(lam0), raw(lam_out), float(mu0), float(smin), raw(hint))
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
@@ -298,7 +298,7 @@ class Context:
                                                    C.c_void_p(stream or 0)), "btrapz_solve_warm_device")
 
     def last_solve_form(self):
-        """btrapz_last_solve_form: 0 packed, 1 split, 2 long, 3 capped + resume, 4 queue."""
+        """btrapz_last_solve_form: 0 packed, 1 split, 2 long, 3 capped + resume, 4 queue; + 8: the two-wavefronts-per-SIMD form."""
         return int(lib().btrapz_last_solve_form(self._h))
 
     def rescue_violations_device(self, B, viol, stream=None):

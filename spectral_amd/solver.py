@@ -76,7 +76,7 @@ class BatchSolver:
                                    dbatch.dl_bounds, o["ctrl"], o["cost"], o["status"], o["iters"], x0=x0, lam0=lam0,
                                    lam_out=lam_out, mu0=warm.get("mu0", 0.0), smin=warm.get("smin", 0.0),
                                    stream=stream, max_iter=max_iter, eps=eps, hint=hint, elastic=elastic,
-                                   elastic_tol=elastic_tol)
+                                   elastic_tol=elastic_tol, lean=lean)
         return o
 
     def prepare(self, dbatch, shared, out=None, **options):

@@ -160,3 +160,129 @@ def test_hand_over_at_any_iteration_changes_nothing(solver, lean):
             assert form == (11 if lean > 0 else 3)
             assert np.array_equal(one["status"], two["status"]) and np.array_equal(one["iters"], two["iters"]), cap
             assert np.array_equal(one["cost"], two["cost"]) and np.array_equal(one["ctrl"][ok], two["ctrl"][ok]), cap
+
+
+# ---- warm starts in the lean form (btrapz_solve_warm_device with btrapz_options.lean; btrapz_lean_warm.hip) ----------
+
+def _joint_times(batch, shift=0.0):
+    import torch
+    from spectral_amd import layout as L
+    return torch.from_numpy(np.cumsum(batch.seg[L.F_T], axis=1) + shift)
+
+
+@pytest.mark.parametrize("config,S,variant", [(2, 10, 0), (3, 20, 0), (4, 20, 1)])
+def test_lean_warm_start_same_problem_fewer_iterations_same_optimum(solver, config, S, variant):
+    import torch
+    batch, sh = synth.make_batch(768, S, config=config, variant=variant)
+    db = solver.upload(batch)
+    cold = solver.solve(db, sh, keep_multipliers=True, lean=1)
+    assert solver.ctx.last_solve_form() == 8
+    c_ctrl = cold["ctrl"].clone(); c_it = cold["iters"].cpu().numpy().copy(); c_st = cold["status"].cpu().numpy().copy()
+    c_cost = cold["cost"].cpu().numpy().copy()
+    x0 = solver.eval_states(db, c_ctrl, _joint_times(batch))
+    warm = solver.solve(db, sh, warm=dict(x0=x0, lam=cold["lam"]), lean=1)
+    torch.cuda.synchronize()
+    assert solver.ctx.last_solve_form() == 8
+    w_ctrl = warm["ctrl"].cpu().numpy(); w_it = warm["iters"].cpu().numpy(); w_st = warm["status"].cpu().numpy()
+    ok = c_st > 0
+    assert ok.mean() > 0.99 and (w_st[ok] > 0).all()
+    xs, obj, st, _ = O.batch_solve(batch, sh, 0, 48, exact=True)
+    good = (st == 1) & ok[:48]
+    rel = lambda a_, b_: np.abs(a_ - b_).max(axis=1) / np.abs(b_).max(axis=1)
+    assert rel(w_ctrl[:48][good], xs[good]).max() <= RTOL and rel(c_ctrl.cpu().numpy()[:48][good], xs[good]).max() <= RTOL
+    assert rel(w_ctrl[ok], c_ctrl.cpu().numpy()[ok]).max() <= RTOL
+    assert np.abs(warm["cost"].cpu().numpy()[ok] - c_cost[ok]).max() <= 1e-6 * (1 + np.abs(c_cost[ok]).max())
+    assert w_it[ok].mean() <= c_it[ok].mean() - 3.0, (w_it[ok].mean(), c_it[ok].mean())
+    # the packed warm-start kernel from the same start: same optimum, iteration counts within one
+    pw = solver.solve(db, sh, warm=dict(x0=x0, lam=cold["lam"]), lean=-1)
+    torch.cuda.synchronize()
+    assert solver.ctx.last_solve_form() == 0
+    assert rel(pw["ctrl"].cpu().numpy()[ok], w_ctrl[ok]).max() <= RTOL
+    assert abs(pw["iters"].cpu().numpy()[ok].mean() - w_it[ok].mean()) <= 0.5
+
+
+def test_lean_warm_start_garbage_and_restart(solver):
+    """NaN / inf / negative / absurd warm-start data: sanitised lane by lane, and a group whose guess does not pay off
+    restarts cold inside the kernel -- the result is the cold solve's."""
+    import torch
+    B, S = 192, 20
+    batch, sh = synth.make_batch(B, S, config=3)
+    db = solver.upload(batch)
+    cold = solver.solve(db, sh, lean=1)
+    c_ctrl = cold["ctrl"].cpu().numpy().copy(); c_st = cold["status"].cpu().numpy().copy()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x0 = torch.randn((B, 2, S, 3), generator=g, dtype=torch.float64) * 50.0
+    x0[::3, 0, 4] = float("nan"); x0[1::3, 1, 7, 2] = float("inf")
+    lam = torch.rand((2, 36, B, S), generator=g, dtype=torch.float64) * 10.0
+    lam[0, 5, ::2] = float("nan"); lam[1, 20, 1::2] = -3.0; lam[0, 30, ::5] = float("inf")
+    warm = solver.solve(db, sh, warm=dict(x0=x0.to(solver.device), lam=lam.to(solver.device)), lean=1)
+    torch.cuda.synchronize()
+    assert solver.ctx.last_solve_form() == 8
+    w_ctrl = warm["ctrl"].cpu().numpy(); w_st = warm["status"].cpu().numpy()
+    ok = c_st > 0
+    assert ok.mean() > 0.95 and (w_st[ok] > 0).all()
+    assert (np.abs(w_ctrl[ok] - c_ctrl[ok]).max(axis=1) <= RTOL * np.abs(c_ctrl[ok]).max(axis=1)).all()
+
+
+def test_lean_scheduling_hint_changes_nothing_but_the_schedule(solver):
+    """btrapz_warm.hint in the lean form: the hint kernels are the instantiations of the plain ones that read a.order --
+    same arithmetic, so results are bit-identical whatever the hint says, cold and warm."""
+    import torch
+    B, S = 4099, 20
+    batch, sh = synth.make_batch(B, S, config=3)
+    db = solver.upload(batch)
+    ref = {k: v.clone() for k, v in solver.solve(db, sh, lean=1).items()}
+    g = torch.Generator().manual_seed(2)
+    hints = {"constant": torch.full((B,), 3, dtype=torch.int32), "own iterations": (ref["iters"] + 1).to(torch.int32).cpu(),
+             "random, out of range": torch.randint(-50, 200, (B,), generator=g, dtype=torch.int32)}
+    for name, h in hints.items():
+        o = solver.solve(db, sh, warm=dict(hint=h.to(solver.device).contiguous()), lean=1)
+        torch.cuda.synchronize()
+        assert solver.ctx.last_solve_form() == 8
+        assert torch.equal(o["ctrl"], ref["ctrl"]) and torch.equal(o["cost"], ref["cost"]), name
+        assert torch.equal(o["status"], ref["status"]) and torch.equal(o["iters"], ref["iters"]), name
+    k0 = {k: v.clone() for k, v in solver.solve(db, sh, keep_multipliers=True, lean=1).items()}
+    x0 = solver.eval_states(db, k0["ctrl"], _joint_times(batch))
+    w0 = {k: v.clone() for k, v in solver.solve(db, sh, warm=dict(x0=x0, lam=k0["lam"].clone()), lean=1).items()}
+    w1 = solver.solve(db, sh, warm=dict(x0=x0, lam=k0["lam"].clone(), hint=hints["random, out of range"].to(solver.device)), lean=1)
+    torch.cuda.synchronize()
+    assert torch.equal(w1["ctrl"], w0["ctrl"]) and torch.equal(w1["iters"], w0["iters"]) and torch.equal(w1["status"], w0["status"])
+
+
+def test_lean_warm_start_on_ragged_batch(solver):
+    """Warm start of a ragged batch (segment counts from 1) in the lean form, through the C entry point."""
+    import torch
+    from spectral_amd import knots
+    from spectral_amd import layout as L
+    kb = knots.jittered(knots.parse_corridor_file(os.path.join(GOLD, "inputs", "c_road_s1_3.txt")), 96, seed=5)
+    sh = synth.shared_params(variant=0)
+    sh.ds_ref, sh.dl_ref = kb.header["ds_ref"], kb.header["dl_ref"]
+    sh.dds, sh.ddds, sh.ddl, sh.dddl = kb.header["dds"], kb.header["ddds"], kb.header["ddl"], kb.header["dddl"]
+    rec = solver.corridor_batch(kb, variant=0, seg_stride=16)
+    cold = {k: v.clone() for k, v in solver.solve_ragged(rec, sh, lean=1, cap_iter=-1).items()}
+    B, st = rec["B"], rec["seg_stride"]
+    d = solver.device
+    lam = torch.zeros((2, 36, B, st), dtype=torch.float64, device=d)
+    o = dict(ctrl=torch.zeros((B, 12 * st), dtype=torch.float64, device=d), cost=torch.empty(B, dtype=torch.float64, device=d),
+             status=torch.empty(B, dtype=torch.int32, device=d), iters=torch.empty(B, dtype=torch.int32, device=d))
+    stream = torch.cuda.current_stream(d).cuda_stream
+    call = lambda x0, lam0, lam_out: solver.ctx.solve_warm_device(
+        B, st, sh, rec["seg"], rec["seg_count"], rec["init"], rec["ref_end"], rec["dl_bounds"], o["ctrl"], o["cost"],
+        o["status"], o["iters"], x0=x0, lam0=lam0, lam_out=lam_out, stream=stream, lean=1)
+    call(None, None, lam)                                   # cold through the warm entry point, multipliers kept
+    torch.cuda.synchronize()
+    assert solver.ctx.last_solve_form() == 8 and torch.equal(o["status"], cold["status"])
+    okc = (cold["status"] > 0).cpu().numpy()
+    a_, b_ = o["ctrl"].cpu().numpy()[okc], cold["ctrl"].cpu().numpy()[okc]
+    assert (np.abs(a_ - b_).max(axis=1) <= 1e-7 * np.abs(b_).max(axis=1)).all()
+    it_cold = o["iters"].cpu().numpy().copy(); ctrl_cold = o["ctrl"].cpu().numpy().copy(); st_cold = o["status"].cpu().numpy().copy()
+    times = torch.cumsum(rec["seg"][L.F_T], dim=1)
+    x0 = torch.empty((B, 2, st, 3), dtype=torch.float64, device=d)
+    solver.ctx.eval_states_device(B, st, rec["seg_count"], rec["seg"], o["ctrl"], st, times.contiguous(), x0, stream=stream)
+    call(x0, lam.clone(), None)
+    torch.cuda.synchronize()
+    stt = o["status"].cpu().numpy(); ok = st_cold > 0
+    assert ok.sum() >= 0.5 * B and (stt[ok] > 0).all() and (stt[~ok] == st_cold[~ok]).all()
+    w = o["ctrl"].cpu().numpy()
+    assert (np.abs(w[ok] - ctrl_cold[ok]).max(axis=1) <= RTOL * np.abs(ctrl_cold[ok]).max(axis=1)).all()
+    assert o["iters"].cpu().numpy()[ok].mean() <= it_cold[ok].mean() - 2.0
