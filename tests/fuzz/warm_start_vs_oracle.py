@@ -1,7 +1,7 @@
 """Warm-started solves against the oracle: four batch families, replanning shifts of 0.1 / 0.3 / 1.0 s, warm start from
 the previous solution (states + multipliers), with and without scheduling hints, and cold beside them.
 
-    python tests/fuzz/warm_start_vs_oracle.py [B=4096]
+    python tests/fuzz/warm_start_vs_oracle.py [B=4096] [LEAN=0]     # LEAN: btrapz_options.lean (1: the two-wavefronts-per-SIMD form)
 
 Round 2: 147 456 solves, 0 lost, one borderline candidate accepted that the oracle scores just above its limit.
 """
@@ -16,11 +16,12 @@ from spectral_amd.solver import BatchSolver
 from test_gpu_warm_start import joint_times
 solver=BatchSolver(0)
 B=int(sys.argv[1]) if len(sys.argv)>1 else 4096
+LEAN=int(sys.argv[2]) if len(sys.argv)>2 else 0
 tot_lost=tot_extra=0
 for tag,mk in (('scenario1 v0',lambda: synth.make_scenario1_batch(B,20,0)),('scenario1 v1',lambda: synth.make_scenario1_batch(B,20,1)),('generic',lambda: synth.make_batch(B,20,config=3)),('scenario1 S10',lambda: synth.make_scenario1_batch(B,10,0))):
     batch,sh=mk(); S=batch.S
     db=solver.upload(batch)
-    prev=solver.solve(db,sh,keep_multipliers=True)
+    prev=solver.solve(db,sh,keep_multipliers=True,lean=LEAN)
     p_ctrl=prev['ctrl'].clone(); lam=prev['lam'].clone(); p_it=prev['iters'].clone()
     for d in (0.1,0.3,1.0):
         x0=solver.eval_states(db,p_ctrl,joint_times(batch,d))
@@ -34,7 +35,7 @@ for tag,mk in (('scenario1 v0',lambda: synth.make_scenario1_batch(B,20,0)),('sce
         xs,obj,ost,_=O.batch_solve(nb,sh,0,B,exact=True,threads=16)
         for mode in ('warm','warm+hint','cold'):
             kw={} if mode=='cold' else dict(warm=dict(x0=x0,lam=lam,**({'hint':torch.clamp((p_it-4)//4+1,min=1).to(torch.int32)} if mode=='warm+hint' else {})))
-            o=solver.solve(ndb,sh,**kw); torch.cuda.synchronize()
+            o=solver.solve(ndb,sh,lean=LEAN,**kw); torch.cuda.synchronize()
             st=o['status'].cpu().numpy(); c=o['ctrl'].cpu().numpy(); it=o['iters'].cpu().numpy()
             ka,oa=st>0,ost>0
             both=ka&oa
