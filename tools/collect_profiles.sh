@@ -108,7 +108,7 @@ if [ "$QUICK" != "quick" ]; then
   done
   step cap_bench_lean "$OUT/cap_bench_lean.json" python3 "$ROOT/tools/cap_bench.py" --lean 1 --caps 5,6,7,8,10
   step sibling_bench "$OUT/sibling_bench.json" python3 "$ROOT/tools/sibling_bench.py"
-  bash "$ROOT/tools/lean_pmc.sh" "$TAG/lean_pmc" 0 > "$OUT/lean_pmc.log" 2>&1 || echo "FAILED: lean_pmc" >> "$OUT/failed.txt"
+  (cd "$ROOT" && bash tools/lean_pmc.sh "$TAG/lean_pmc" 0) > "$OUT/lean_pmc.log" 2>&1 || echo "FAILED: lean_pmc" >> "$OUT/failed.txt"
 fi
 # keep only the CSVs (the merge-back limit is 64 MiB)
 find "$OUT" -name "*.db" -delete 2>/dev/null
