@@ -15,7 +15,7 @@ import torch.distributed as dist
 
 # A collective that does not complete within this time fails instead of hanging (a rank that died, a link that does not
 # come up): the failing rank exits non-zero and the launcher (torch.distributed.run) ends the others.
-COLLECTIVE_TIMEOUT_S = 60
+COLLECTIVE_TIMEOUT_S = int(os.environ.get("BTRAPZ_COLLECTIVE_TIMEOUT_S", "60"))   # (a node whose RCCL bootstrap is slower than that can raise it)
 
 
 def init_process_group(backend, local_rank=0, timeout_s=COLLECTIVE_TIMEOUT_S):
