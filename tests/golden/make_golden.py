@@ -25,6 +25,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.environ.get("GOLDEN_OUT", HERE)   # (tests regenerate into a temporary directory and compare)
 sys.path.insert(0, ROOT)
 from oracle import oracle as O  # noqa: E402
 from spectral_amd import synth  # noqa: E402
@@ -56,8 +57,8 @@ def main():
                 rc, samp = O.sample(cubes, inp.delta, xs, inp.init_s, inp.init_l)
                 arrays[key + "/traj"] = np.stack(samp) if rc == 0 else np.zeros((6, 0))
     json.dump({"fields": [f for f, _ in O.Cube._fields_], "corridors": corr},
-              open(os.path.join(HERE, "corridors.json"), "w"), indent=0)
-    np.savez_compressed(os.path.join(HERE, "scenario_xstar.npz"), **arrays)
+              open(os.path.join(OUT, "corridors.json"), "w"), indent=0)
+    np.savez_compressed(os.path.join(OUT, "scenario_xstar.npz"), **arrays)
     syn = {}
     for cfg, S, variant, nb in [(2, 10, 0, 32), (3, 20, 0, 32), (4, 20, 1, 32), (9, 7, 0, 16), (8, 13, 1, 16)]:
         batch, sh = synth.make_batch(256, S, config=cfg, variant=variant)
@@ -66,7 +67,7 @@ def main():
         syn["cfg%d/obj" % cfg] = obj
         syn["cfg%d/status" % cfg] = st
         syn["cfg%d/meta" % cfg] = np.array([256, S, variant, nb])
-    np.savez_compressed(os.path.join(HERE, "synthetic_xstar.npz"), **syn)
+    np.savez_compressed(os.path.join(OUT, "synthetic_xstar.npz"), **syn)
     print("wrote corridors.json, scenario_xstar.npz, synthetic_xstar.npz")
     scenario1()
 
@@ -80,7 +81,7 @@ def scenario1():
         key = "S%d_v%d" % (S, variant)
         s1[key + "/xstar"] = ctrl; s1[key + "/obj"] = obj; s1[key + "/status"] = st
         s1[key + "/meta"] = np.array([256, S, variant, nb])
-    np.savez_compressed(os.path.join(HERE, "scenario1_xstar.npz"), **s1)
+    np.savez_compressed(os.path.join(OUT, "scenario1_xstar.npz"), **s1)
     print("wrote scenario1_xstar.npz")
 
 

@@ -177,3 +177,20 @@ def test_distance_of_the_references_own_answer_from_the_optimum_is_tabulated():
     assert sum(r["port_vs_xstar_rel"] <= 1e-4 for r in both) == 2           # only scenario_1 meets 1e-4 against the reference's output
     assert max(r["port_vs_xstar_rel"] for r in both if r["port_status"] == 1) < 5e-3
     assert all(abs(r["port_vs_xstar_abs"] - 0.341) < 1e-3 for r in both if r["port_status"] == 2 and r["input"] in ("c4", "c5"))
+
+
+def test_committed_xstar_fixtures_are_what_the_generator_writes(tmp_path):
+    """The x* fixtures the GPU parity tests load (synthetic_xstar / scenario1_xstar / scenario_xstar .npz, corridors.json)
+    are products of the ORACLE's exact solver, not of the HIP solver: regenerating them with
+    tests/golden/make_golden.py gives the committed arrays bit for bit (round 4: regenerated, byte-identical)."""
+    import subprocess, sys
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    env = dict(os.environ, GOLDEN_OUT=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(gold, "make_golden.py")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    for f in ("scenario1_xstar.npz", "scenario_xstar.npz", "synthetic_xstar.npz"):
+        a, b = np.load(os.path.join(gold, f)), np.load(str(tmp_path / f))
+        assert sorted(a.files) == sorted(b.files)
+        for k in a.files:
+            assert np.array_equal(a[k], b[k], equal_nan=True), (f, k)
+    assert open(os.path.join(gold, "corridors.json")).read() == open(str(tmp_path / "corridors.json")).read()
