@@ -73,8 +73,12 @@ static inline const char *experiment_env(const char *name) {
 // BTRAPZ_SUSP_PERCENT of the axis problems, at most BTRAPZ_SUSP_BYTES_MAX of workspace.  (Tuned on the bench batches,
 // cap_alone 1 / 2 / 3: 6.39 / 6.47 / 6.58 ms; cap_hi 2 / 4 / 8: 6.44 / 6.39 / 6.41; 12-21 % of the problems
 // hand over.)  Compile-time constants: a stray environment variable must not change what a drop-in library does.
+#ifndef BTRAPZ_CAP_ALONE
 #define BTRAPZ_CAP_ALONE 1
+#endif
+#ifndef BTRAPZ_CAP_HI
 #define BTRAPZ_CAP_HI 4
+#endif
 #define BTRAPZ_SUSP_PERCENT 25
 #define BTRAPZ_SUSP_BYTES_MAX (1ull << 30)
 
