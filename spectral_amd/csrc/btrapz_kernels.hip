@@ -28,6 +28,9 @@
 // of every segment spread over three lanes, state in registers only, one scalar per row and phase exchanged through LDS.
 // Long form (65..256 segments; MULTI): one axis problem per workgroup of up to four wavefronts.  Large cold batches run
 // as two launches (CAPPED / RESUME): groups left alone in their wavefront hand their iterate over and are re-packed.
+// Batches of three and more wavefronts per SIMD (cold or warm-started, up to 64 segments) run the LEAN form of the same
+// iteration instead -- btrapz_lean_body.h: two wavefronts per SIMD on half the per-lane state; this file's packed form
+// serves the smaller batches, the rescue pass, the candidate queue and btrapz_options.start = 1.
 #include <hip/hip_runtime.h>
 #include "btrapz_ipm.h"
 

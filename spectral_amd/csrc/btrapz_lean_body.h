@@ -136,6 +136,12 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   // LDS reads of all fifteen rows at the top of a pass (latency it cannot know the second wavefront hides) and the
   // register allocator pays with scratch.
 #define ROW_SEP() __builtin_amdgcn_sched_barrier(0)
+// (a barrier in front of every second row: pairs of rows give the scheduler room at no extra scratch -- measured: every
+//  row 5.77 ms, every second 5.65, every third 5.76 with 8-16 B more scratch)
+#ifndef LEAN_ROW_GROUP
+#define LEAN_ROW_GROUP 2
+#endif
+#define ROW_SEP_R(r) do { if constexpr (SI(r) % LEAN_ROW_GROUP == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
   // Reciprocal slacks of the passes that form the step (Newton block, corrector, ratios, update).  The bare v_rcp_f64
   // seed (5e-8 relative) perturbs the Newton direction by as much -- an inexact Newton step; the iterate is EVALUATED
   // (residuals, complementarity, score: pass A1) without any reciprocal, so what the solve converges to and when it
@@ -379,7 +385,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       {
         ROW_LIMITS();
         FOR_ROWS(r)
-          ROW_SEP();
+          ROW_SEP_R(r);
           const double ll = LL(r), lu = LU(r);
           const double gcr = row_dot<r>(c, t);
           const double s_l = sl[SI(r)], s_u = su[SI(r)];
@@ -492,7 +498,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         ROW_LIMITS();
         const double t2 = t * t;
         FOR_ROWS(r)
-          ROW_SEP();
+          ROW_SEP_R(r);
           const double ll = LL(r), lu = LU(r);
           const double gcr = row_dot<r>(c, t);
           const double s_l = sl[SI(r)], s_u = su[SI(r)];
@@ -657,7 +663,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     // ---- C. predictor (sigma = 0): statistics of the affine step ----
     // per row: multipliers from the lane's LDS column; slack, residuals and reciprocals recomputed
 #define LROW(r, RCP)                                                                                 \
-      ROW_SEP();                                                                                      \
+      ROW_SEP_R(r);                                                                                   \
       const double ll = LL(r), lu = LU(r);                                                            \
       const double s_l = sl[SI(r)], s_u = su[SI(r)];                                                  \
       const double gcr = row_dot<r>(c, t);                                                            \
