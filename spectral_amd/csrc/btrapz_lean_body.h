@@ -138,6 +138,20 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 #define ROW_SEP() __builtin_amdgcn_sched_barrier(0)
 // (a barrier in front of every second row: pairs of rows give the scheduler room at no extra scratch -- measured: every
 //  row 5.77 ms, every second 5.65, every third 5.76 with 8-16 B more scratch)
+// LEAN_PRIO: wave priority raised inside the sequential loops (dependent chains: few instructions, each waiting for the
+// last) so that the SIMD's other wavefront -- in a row pass, say, with instructions to spare -- fills the gaps instead of
+// getting in front.
+// (measured, 65 536 x 20: scenario_1 two launches 5.35 -> 5.27 ms, one launch 5.63 -> 5.60; generic +-0)
+#ifndef LEAN_PRIO
+#define LEAN_PRIO 3
+#endif
+#if LEAN_PRIO
+#define SEQ_BEGIN() __builtin_amdgcn_s_setprio(LEAN_PRIO)
+#define SEQ_END() __builtin_amdgcn_s_setprio(0)
+#else
+#define SEQ_BEGIN()
+#define SEQ_END()
+#endif
 #ifndef LEAN_ROW_GROUP
 #define LEAN_ROW_GROUP 2
 #endif
@@ -555,6 +569,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           MK[i * 3 + j] = top ? nM : M01[j * 3 + i];
         }
       UNROLL for (int i = 0; i < 6; i++) TF[i] = T[i];
+      SEQ_BEGIN();
       for (int step = 0; step <= m; ++step) {
         double zin[6], win[3];
         if constexpr (SMALL_S) {
@@ -608,10 +623,12 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           }
         }
       }
+      SEQ_END();
     }
     // One solve with the factor: u (reduced to the joint states) -> dX by the sweeps -> dc.
     auto forward_u = [&](double (&u)[3]) {
       double w[3] = {0.0, 0.0, 0.0};
+      SEQ_BEGIN();
       for (int step = 0; step <= m; ++step) {
         double win[3];
         if constexpr (SMALL_S) {
@@ -631,11 +648,13 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           }
         }
       }
+      SEQ_END();
     };
     auto backward_u = [&](const double (&u)[3], double (&dX)[3], double (&dc)[6]) {
       ldl3_solve(TF, u[0], u[1], u[2], dX[0], dX[1], dX[2]);
       double y[3];
       UNROLL for (int i = 0; i < 3; i++) y[i] = mid ? dX[i] : 0.0;
+      SEQ_BEGIN();
       for (int step = m - 1; step >= 0; --step) {
         double xin[3];
         if constexpr (SMALL_S) {
@@ -653,6 +672,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           }
         }
       }
+      SEQ_END();
       const NullMap nm = {it, t * 0.05};
       double dXp[3];
       UNROLL for (int i = 0; i < 3; i++) { const double vv = from_prev(dX[i]); dXp[i] = first ? 0.0 : vv; }
