@@ -203,6 +203,30 @@ __device__ __forceinline__ Red4 group_reduce(double (*red)[64], int lane, int gb
   return r;
 }
 
+// Two values instead of four (the step ratios of the lean form: half the LDS traffic and combining operations).
+template <int O0, int O1>
+__device__ __forceinline__ Red4 group_reduce2(double (*red)[64], int lane, int gbase, int k, int S, double v0, double v1) {
+  const bool has_next = k + 1 < S;
+  v0 = pair_op<O0>(v0, has_next); v1 = pair_op<O1>(v1, has_next);
+  wave_lds_sync();
+  red[0][lane] = v0; red[1][lane] = v1;
+  wave_lds_sync();
+  Red4 r = {red_init<O0>(), red_init<O1>(), 0.0, 0.0};
+  const int n2 = (S + 1) >> 1;
+  for (int j0 = 0; j0 < n2; j0 += RB) {
+    double a[RB], b[RB];
+    UNROLL for (int u = 0; u < RB; u++) {
+      const int j = gbase + 2 * (j0 + u < n2 ? j0 + u : n2 - 1);
+      a[u] = red[0][j]; b[u] = red[1][j];
+    }
+    UNROLL for (int u = 0; u < RB; u++) {
+      const bool in = j0 + u < n2;
+      r.a = red_op<O0>(r.a, a[u], in); r.b = red_op<O1>(r.b, b[u], in);
+    }
+  }
+  return r;
+}
+
 // The same reduction with the maxima and minima through LDS atomics (ds_max_f64 / ds_min_f64 on the group's own entry:
 // order-independent, so the result is the one of the ordered loop, bit for bit) and only the sums through the ordered
 // reads -- a sum's rounding depends on its order.  OPn: 0 sum, 1 max, 2 min, -1 unused (returns 0).  Lanes outside

@@ -155,6 +155,14 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 #ifndef LEAN_ROW_GROUP
 #define LEAN_ROW_GROUP 2
 #endif
+#ifndef LEAN_PROJ_SEP
+#define LEAN_PROJ_SEP 1
+#endif
+#if LEAN_PROJ_SEP
+#define PROJ_SEP() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PROJ_SEP()
+#endif
 #define ROW_SEP_R(r) do { if constexpr (SI(r) % LEAN_ROW_GROUP == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
   // Reciprocal slacks of the passes that form the step (Newton block, corrector, ratios, update).  The bare v_rcp_f64
   // seed (5e-8 relative) perturbs the Newton direction by as much -- an inexact Newton step; the iterate is EVALUATED
@@ -539,7 +547,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       UT_apply(nm, w0[0], w1[0], w2[0], col); M00[0] = col[0]; M00[1] = col[1]; M00[2] = col[2];
       UT_apply(nm, w0[1], w1[1], w2[1], col); M00[3] = col[1]; M00[4] = col[2];
       UT_apply(nm, w0[2], w1[2], w2[2], col); M00[5] = col[2];
-      ROW_SEP();
+      PROJ_SEP();
       VT_apply(nm, H[SYM(0, 3)], H[SYM(0, 4)], H[SYM(0, 5)], w0);
       VT_apply(nm, H[SYM(1, 3)], H[SYM(1, 4)], H[SYM(1, 5)], w1);
       VT_apply(nm, H[SYM(2, 3)], H[SYM(2, 4)], H[SYM(2, 5)], w2);
@@ -547,7 +555,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         UT_apply(nm, w0[j], w1[j], w2[j], col);
         M01[0 * 3 + j] = col[0]; M01[1 * 3 + j] = col[1]; M01[2 * 3 + j] = col[2];
       }
-      ROW_SEP();
+      PROJ_SEP();
       VT_apply(nm, H[SYM(3, 3)], H[SYM(3, 4)], H[SYM(3, 5)], w0);
       VT_apply(nm, H[SYM(3, 4)], H[SYM(4, 4)], H[SYM(4, 5)], w1);
       VT_apply(nm, H[SYM(3, 5)], H[SYM(4, 5)], H[SYM(5, 5)], w2);
@@ -774,7 +782,8 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         END_ROWS
       }
 #if LEAN_E_CACHE
-      const Red4 rs = group_reduce<0, 1, 1, 1>(lds + LN_RED, lane, gbase, k, S, 0.0, pr, dr, 0.0);
+      const Red4 rs2 = group_reduce2<1, 1>(lds + LN_RED, lane, gbase, k, S, pr, dr);
+      const Red4 rs = {0.0, rs2.a, rs2.b, 0.0};
 #else
       const Red4 rs = group_reduce_mixed<-1, 1, 1, -1>(lds + LN_RED, lane, gbase, k, S, lane_in_group, 0.0, pr, dr, 0.0);
 #endif
