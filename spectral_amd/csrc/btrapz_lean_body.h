@@ -75,7 +75,18 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   const int my_step = top ? k : (k > m ? S - 1 - k : m);
   const Shared &sh = a.sh;
   const int variant = sh.variant;
-  const double *__restrict__ mq = mqm + axis * 84;
+  // The kernel's arguments as the loop and the write-back see them: through a pointer into the kernarg segment that is
+  // laundered once per iteration -- scalar loads where the value is used.  Left to itself the optimiser loads every
+  // argument at the top of the kernel and carries ~100 SGPRs of them through the loop as spills in VGPR lanes
+  // (180 v_readlane per iteration and three VGPRs).  (KernelArgs is the kernel's first parameter: offset 0.)
+  typedef const KernelArgs __attribute__((address_space(4))) kargs_t;
+  kargs_t *ka = (kargs_t *)__builtin_amdgcn_kernarg_segment_ptr();
+#define KA_FENCE() asm volatile("" : "+s"(ka))
+
+  // (constant address space: the table is read through scalar loads INSIDE the loop -- the pointer is laundered there, or
+  //  the optimiser hoists all 168 dwords of it out of the loop and spills them to VGPR lanes: 180 v_readlane per iteration)
+  typedef const double __attribute__((address_space(4))) ctable_t;
+  ctable_t *mq = (ctable_t *)(mqm + axis * 84);
   const double inv_m = 1.0 / ((double)(2 * NR) * (double)S);
   auto from_prev = [&](double x) -> double { return dpp_prev(x); };
   auto from_next = [&](double x) -> double { return dpp_next(x); };
@@ -87,31 +98,68 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   const int b = ORDERED ? a.order[cand0 + (int)cand] : (int)cand;
 
   // ---- problem data kept for the whole solve ----
+  // LEAN_RELOAD: the position lines of rows 1..4 and the velocity intervals of rows 7..9 (10 doubles) are NOT kept: every
+  // row pass reads the record fields they come from again (L2 hits, 512 contiguous bytes per wave instruction) and forms
+  // them where its first rows use them -- the registers they held are what the allocator used to evict to scratch.
+#ifndef LEAN_RELOAD
+#define LEAN_RELOAD 0
+#endif
   double t, it;
+#if LEAN_RELOAD
+  double mplo, mphi, mvlo, mvhi;               // rows 5 and 10: the joint's common intervals
+  unsigned eo8;                                // byte offset of this lane's entry in a field plane of the record
+#else
   double plo0, dplo, phi0, dphi, mplo, mphi;   // position rows 1..4: plo0 + r dplo; row 5: the joint's common interval
   double vl[3], vh[3], mvlo, mvhi;             // velocity rows 7..9; row 10: the joint's common interval
+#endif
   double qA, qB, qend;                         // q_j = qB + qA (j + 1) - qC [j = 0] + qC [j = 5] + qend [j = 5]
   double iqn, ibn;                             // 1 / (1 + |q|), 1 / (1 + |bounds|)
   double sl[NR], su[NR], X[3];
   bool infeasible_bounds, no_solution;
   // acceleration / jerk rows: limits x t, x t^2 (solve_3d.cc:862-888, 1010-1037); the reference's reference-tracking
   // weights of this axis
-  const double acc_lo = axis == 0 ? sh.acc_s[0] : sh.acc_l[0], acc_hi = axis == 0 ? sh.acc_s[1] : sh.acc_l[1];
-  const double jerk_lo = axis == 0 ? sh.jerk_s[0] : sh.jerk_l[0], jerk_hi = axis == 0 ? sh.jerk_s[1] : sh.jerk_l[1];
   const double w_end = axis == 0 ? sh.weight_end_s : sh.weight_end_l;
   const double qC0 = -2.0 * (axis == 0 ? sh.w_s[1] : sh.w_l[1]) * (axis == 0 ? sh.ds_ref : sh.dl_ref);   // x t: the d_ref term of q
 #define LLO(r) ((r) < 5 ? plo0 + (double)(r) * dplo : (r) == 5 ? mplo : (r) < 10 ? vl[((r) >= 7 && (r) <= 9) ? (r) - 7 : 0] : (r) == 10 ? mvlo : (r) < 15 ? alo : jlo)
 #define LUP(r) ((r) < 5 ? phi0 + (double)(r) * dphi : (r) == 5 ? mphi : (r) < 10 ? vh[((r) >= 7 && (r) <= 9) ? (r) - 7 : 0] : (r) == 10 ? mvhi : (r) < 15 ? ahi : jhi)
-#define ROW_LIMITS() const double alo = acc_lo * t, ahi = acc_hi * t, jlo = jerk_lo * t * t, jhi = jerk_hi * t * t
+// (read where they are used, through the laundered kernarg pointer: four scalars less to carry through the loop)
+#define ROW_LIMITS_ACC()                                                                            \
+  const double __attribute__((address_space(4))) *lim_ = &ka->sh.acc_s[0] + 2 * axis;               \
+  asm volatile("" : "+s"(lim_));   /* (a copy: some passes run under a divergent condition) */      \
+  const double alo = lim_[0] * t, ahi = lim_[1] * t, jlo = lim_[4] * t * t, jhi = lim_[5] * t * t
+#if LEAN_RELOAD
+#define ROW_LIMITS()                                                                                \
+  ROW_LIMITS_ACC();                                                                                  \
+  double plo0, dplo, phi0, dphi, vl[3], vh[3];                                                       \
+  load_limits(plo0, dplo, phi0, dphi, vl, vh)
+#else
+#define ROW_LIMITS() ROW_LIMITS_ACC()
+#endif
 #define LL(r) lds[LN_LL + SI(r)][lane]
 #define LU(r) lds[LN_LU + SI(r)][lane]
 #define HSYM(H, i, j) ((i) <= (j) ? H[SYM(i, j)] : H[SYM(j, i)])
   // P block of the lane's segment (solve_3d.cc:159-171) from the scalar table
+#ifndef LEAN_P_CHUNK
+#define LEAN_P_CHUNK 4
+#endif
+#define LEAN_P_PART(H, i0_, n_)                                                                       \
+  {                                                                                                   \
+    ctable_t *q_ = mq;                                                                                \
+    asm volatile("" : "+s"(q_));                                                                      \
+    UNROLL for (int i_ = (i0_); i_ < (i0_) + (n_); i_++)                                              \
+      H[i_] = 2.0 * (t3_ * q_[i_] + t * q_[21 + i_] + it * q_[42 + i_] + it3_ * q_[63 + i_]);         \
+  }
+  // (in parts, each behind its own laundered pointer and a scheduling barrier: the scalar loads of one part are in
+  //  flight while the previous one is consumed, and no more than 2 x 4 x LEAN_P_CHUNK doubles of the table are in SGPRs)
 #define LEAN_LOAD_P(H)                                                                               \
   {                                                                                                   \
     const double t3_ = t * t * t, it3_ = it * it * it;                                                \
-    UNROLL for (int i_ = 0; i_ < 21; i_++)                                                            \
-      H[i_] = 2.0 * (t3_ * mq[i_] + t * mq[21 + i_] + it * mq[42 + i_] + it3_ * mq[63 + i_]);         \
+    static_for<(21 + LEAN_P_CHUNK - 1) / LEAN_P_CHUNK>([&](auto c_c) {                                \
+      constexpr int c0_ = decltype(c_c)::value * LEAN_P_CHUNK;                                        \
+      constexpr int cn_ = 21 - c0_ < LEAN_P_CHUNK ? 21 - c0_ : LEAN_P_CHUNK;                          \
+      LEAN_P_PART(H, c0_, cn_)                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                              \
+    });                                                                                               \
     H[SYM(5, 5)] += last ? 2.0 * w_end * (t * t) : 0.0;                                               \
   }
   // control points of the lane's segment from the joint states at its two ends
@@ -130,7 +178,11 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   //  invariants in the optimiser's eyes, which it would compute once, before the loop, and keep.)
   auto fence_slacks = [&]() {
     UNROLL for (int i = 0; i < NR; i++) { asm volatile("" : "+v"(sl[i])); asm volatile("" : "+v"(su[i])); }
+#if LEAN_RELOAD
+    asm volatile("" : "+v"(t), "+v"(it), "+v"(qA), "+v"(qB));
+#else
     asm volatile("" : "+v"(t), "+v"(it), "+v"(plo0), "+v"(dplo), "+v"(phi0), "+v"(dphi), "+v"(qA), "+v"(qB));
+#endif
   };
   // The scheduler may not move anything across the boundary between two rows: left alone it starts the reciprocals and
   // LDS reads of all fifteen rows at the top of a pass (latency it cannot know the second wavefront hides) and the
@@ -189,6 +241,40 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   [[maybe_unused]] bool warm_started = false, restarted = true;
   [[maybe_unused]] int it0 = 0;          // iteration at which the current start was made
   [[maybe_unused]] size_t lam_e = 0;
+#if LEAN_RELOAD
+  // position lines and velocity intervals from the record, as the set-up forms them (solve_3d.cc:827-859, 965-966,
+  // 1003-1004; cuboid_3d.cc:677-689, 826-827)
+  auto load_limits = [&](double &plo0, double &dplo, double &phi0, double &dphi, double (&vl)[3], double (&vh)[3]) {
+    kargs_t *kb = ka;
+    asm volatile("" : "+s"(kb));   // (copies: some passes run under a divergent condition)
+    unsigned eo = eo8;
+    asm volatile("" : "+v"(eo));
+    const char *sg = (const char *)kb->seg;
+    const size_t fs8 = (size_t)kb->B * (size_t)kb->seg_stride * 8;
+    auto fld = [&](int f) -> double { return *(const double *)(sg + (size_t)f * fs8 + eo); };
+    if (variant != BTRAPZ_CUBOID) {
+      const int f0 = axis == 0 ? (int)BTRAPZ_F_DOWN_BIAS : (int)BTRAPZ_F_L_DOWN_BIAS;
+      const double lb = fld(f0), ls = fld(f0 + 1), ub = fld(f0 + 2), us = fld(f0 + 3);
+      plo0 = lb; dplo = ls * 0.2 * t; phi0 = ub; dphi = us * 0.2 * t;
+    } else {
+      if (axis == 0) {
+        const double lb = fld(BTRAPZ_F_DOWN_BIAS), ls = fld(BTRAPZ_F_DOWN_SKEW), ub = fld(BTRAPZ_F_UPP_BIAS), us = fld(BTRAPZ_F_UPP_SKEW);
+        plo0 = fmax(0.0, fmax(ls * 0.0 + lb, lb + ls * t));
+        phi0 = fmin(100.0, fmin(us * 0.0 + ub, ub + us * t));
+      } else {
+        plo0 = fld(BTRAPZ_F_BEG_L); phi0 = fld(BTRAPZ_F_END_L);
+      }
+      dplo = 0.0; dphi = 0.0;
+    }
+    if (axis == 0) {
+      const double lo = fld(BTRAPZ_F_DS_LO), hi = fld(BTRAPZ_F_DS_HI);
+      UNROLL for (int i = 0; i < 3; i++) { vl[i] = lo; vh[i] = hi; }
+    } else {
+      const double *dl = (const double *)((const char *)kb->dl_bounds + (unsigned)b * 80u);
+      UNROLL for (int i = 0; i < 3; i++) { vl[i] = dl[2 * (i + 1)]; vh[i] = dl[2 * (i + 1) + 1]; }
+    }
+  };
+#endif
   // cold start at the current X: slacks max(gap, 1), multipliers 1
   auto cold_rows = [&]() {
     double c[6];
@@ -207,6 +293,10 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     const double *sg = a.seg;
     const size_t e_ = (size_t)b * a.seg_stride + k;
     t = sg[BTRAPZ_F_T * BS + e_];
+#if LEAN_RELOAD
+    double plo0, dplo, phi0, dphi, vl[3], vh[3];   // (this block's own: the passes form theirs)
+    eo8 = (unsigned)e_ * 8u;
+#endif
     double lb, ls, ub, us, begl = 0.0, endl = 0.0, rv[10];
     if (axis == 0) {
       lb = sg[BTRAPZ_F_DOWN_BIAS * BS + e_]; ls = sg[BTRAPZ_F_DOWN_SKEW * BS + e_];
@@ -244,7 +334,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     } else {
       UNROLL for (int i = 0; i < 5; i++) { vlo[i] = rv[2 * i]; vhi[i] = rv[2 * i + 1]; }
     }
-    ROW_LIMITS();
+    ROW_LIMITS_ACC();
     mplo = plo0 + 5.0 * dplo; mphi = phi0 + 5.0 * dphi; mvlo = vlo[4]; mvhi = vhi[4];
     // rows of the reference (all 18) for the consistency checks
 #define LO0(r) ((r) < 6 ? plo0 + (double)(r) * dplo : (r) < 11 ? vlo[((r) >= 6 && (r) < 11) ? (r) - 6 : 0] : (r) < 15 ? alo : jlo)
@@ -357,8 +447,8 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 
   // ---- capped / resume: a group's iterate in a.susp_state, slot-major, field i of lane k at [slot][i][k] ----------
   [[maybe_unused]] auto state_io = [&](const bool store, const long long slot) {
-    double *base = a.susp_state + (size_t)slot * LEAN_SUSP_FIELDS * a.seg_stride + k;
-    const size_t fs = a.seg_stride;
+    double *base = ka->susp_state + (size_t)slot * LEAN_SUSP_FIELDS * ka->seg_stride + k;
+    const size_t fs = ka->seg_stride;
     int f = 0;
     auto io = [&](double &v) { if (store) base[(size_t)f * fs] = v; else v = base[(size_t)f * fs]; ++f; };
     UNROLL for (int i = 0; i < 3; i++) io(X[i]);
@@ -379,12 +469,15 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   // resume: carry on where the capped launch stopped.  The iterate handed over has been evaluated there (best iterate,
   // stall marks, second chance): the first pass here forms its Newton step without evaluating it a second time.
   [[maybe_unused]] bool handed_over = false;
+  [[maybe_unused]] int susp_slot_ = -1;
+  [[maybe_unused]] float susp_score_ = 1.0f;
   if constexpr (RESUME) {
     if (valid) state_io(false, a.susp_slot[2LL * b + axis]);
     handed_over = true;
   }
 
   for (;;) {
+    KA_FENCE();
     // ---- A1. control points; gradient P c + q + G' (lambda_u - lambda_l), residuals, complementarity ----
     double rd[3];
     double mu_part = 0.0, rp_part = 0.0, dscale = 0.0, rd_part;
@@ -450,13 +543,13 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           best_score = score; best_it = eit;
           UNROLL for (int i = 0; i < 3; i++) lds[LN_XB + i][lane] = X[i];
         }
-        if ((float)res < a.stall_factor * best_res) { best_res = (float)res; res_it = eit; }
-        const bool stalled = (eit - it0 >= a.stall_start && eit - best_it >= a.stall_len && eit - res_it >= a.stall_len) ||
-                             (mu > (double)a.diverge_factor * best_score) || !(score < 1e299);
+        if ((float)res < ka->stall_factor * best_res) { best_res = (float)res; res_it = eit; }
+        const bool stalled = (eit - it0 >= ka->stall_start && eit - best_it >= ka->stall_len && eit - res_it >= ka->stall_len) ||
+                             (mu > (double)ka->diverge_factor * best_score) || !(score < 1e299);
         const int patience = (best_score < 1e-7 && mu_primal < 1e-2 * best_score) ? 1 : 3;
         const bool at_floor = best_score < (feasible_and_complementary ? 1e-4 : 1e-5) && eit - best_it >= patience;
         if (at_floor && feasible_and_complementary) res_it = -1;
-        if (score < a.eps || at_floor) done = true;
+        if (score < ka->eps || at_floor) done = true;
         // a warm-started group that stalls, or is still far from converged after 12 iterations (a useful guess needs
         // about 5, a cold start 8-14), or is still running after 24, restarts once from the cold start
         else if (WARM && !restarted && (stalled || (eit - it0 >= 12 && best_score > 1e-4) || eit - it0 >= 24)) restart_now = true;
@@ -464,28 +557,24 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           if (!plain && res < 1e-6 && score < 1e299) { plain = true; best_it = eit; res_it = eit; }
           else done = true;
         }
-        if (!done && !restart_now && eit + 1 >= a.max_iter) done = true;
+        if (!done && !restart_now && eit + 1 >= ka->max_iter) done = true;
       }
       handed_over = false;
       if constexpr (CAPPED) {
         // the cap: who hands over is the packed form's rule (a group alone in its wavefront after cap_iter iterations,
         // any group after cap_hi)
         const int nact = __popcll(__ballot(first && lane_in_group && valid && !done));
-        const bool want = !done && valid && ((eit >= a.cap_iter && nact <= a.cap_alone) || eit >= a.cap_hi);
+        const bool want = !done && valid && ((eit >= ka->cap_iter && nact <= ka->cap_alone) || eit >= ka->cap_hi);
         if (__builtin_expect(__any(want), 0)) {   // (rare: at most once per group)
           UNIFORM_BLOCK;
           wave_lds_sync();
-          if (want && first) lds[LN_RED][lane] = (double)atomicAdd(a.susp_count, 1);
+          if (want && first) lds[LN_RED][lane] = (double)atomicAdd(ka->susp_count, 1);
           wave_lds_sync();
           const long long slot = want ? (long long)lds[LN_RED][gbase] : -1;
-          if (want && slot < (long long)a.susp_cap) {   // (no room: the group simply goes on)
-            state_io(true, slot);
-            if (first) {
-              const double sc = fmax(fmin(score, 1e3), 1e-12);
-              int cls = 1 + (int)(4.0 * (log10(sc) + 12.0));
-              a.susp_slot[2LL * b + axis] = (int)slot;
-              a.susp_key[(size_t)axis * a.B + b] = (ORDERED && !a.bucket_S) ? S : (cls < 1 ? 1 : cls > 64 ? 64 : cls);
-            }
+          if (want && slot < (long long)ka->susp_cap) {   // (no room: the group simply goes on)
+            // The group is done as far as this launch goes: nothing of its iterate or bookkeeping changes any more, so
+            // the record is written after the loop (state_io in here costs the allocator 84 B of scratch per lane).
+            susp_slot_ = (int)slot; susp_score_ = (float)fmax(fmin(score, 1e3), 1e-12);
             suspended = true; done = true;
           }
         }
@@ -788,7 +877,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       const Red4 rs = group_reduce_mixed<-1, 1, 1, -1>(lds + LN_RED, lane, gbase, k, S, lane_in_group, 0.0, pr, dr, 0.0);
 #endif
       const double m_ = fmax(rs.b, rs.c);
-      const double tau = (m_ * a.tau_thr <= 1.0 && eit - it0 < a.tau_iters) ? a.tau : fmin(a.tau, 0.995);
+      const double tau = (m_ * ka->tau_thr <= 1.0 && eit - it0 < ka->tau_iters) ? ka->tau : fmin(ka->tau, 0.995);
       const double alpha = fmin(1.0, tau * rcp(fmax(m_, tau)));
       if (!done && alpha == alpha) {
         UNROLL for (int i = 0; i < 3; i++) X[i] += alpha * dX[i];
@@ -818,24 +907,31 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   }
 
   // ---- write back: control points of the best iterate, objective, status ----
+  KA_FENCE();
   if constexpr (CAPPED) {
     if (suspended) {
-      if (valid && first) { a.axis_status[2LL * b + axis] = BTRAPZ_SUSPENDED; a.axis_iters[2LL * b + axis] = iters; a.axis_obj[2LL * b + axis] = 0.0; }
+      state_io(true, susp_slot_);
+      if (first) {
+        const int cls = 1 + (int)(4.0f * (log10f(susp_score_) + 12.0f));   // how far from convergence: key of the resume lists
+        ka->susp_slot[2LL * b + axis] = susp_slot_;
+        ka->susp_key[(size_t)axis * ka->B + b] = (ORDERED && !ka->bucket_S) ? S : (cls < 1 ? 1 : cls > 64 ? 64 : cls);
+      }
+      if (valid && first) { ka->axis_status[2LL * b + axis] = BTRAPZ_SUSPENDED; ka->axis_iters[2LL * b + axis] = iters; ka->axis_obj[2LL * b + axis] = 0.0; }
     }
   }
   if constexpr (WARM) {   // multipliers and joint states of the returned iterate: lam0 / x0 of a later solve of a nearby problem
-    if (a.lam_out && valid) {
-      const size_t BS = (size_t)a.B * a.seg_stride;
+    if (ka->lam_out && valid) {
+      const size_t BS = (size_t)ka->B * ka->seg_stride;
       FOR_ROWS(r)
-        a.lam_out[lam_e + (size_t)r * BS] = LL(r); a.lam_out[lam_e + (size_t)(18 + r) * BS] = LU(r);
+        ka->lam_out[lam_e + (size_t)r * BS] = LL(r); ka->lam_out[lam_e + (size_t)(18 + r) * BS] = LU(r);
       END_ROWS
       UNROLL for (int r0 = 0; r0 < 3; r0++) {   // the rows this lane does not keep (their bounds live in the previous segment's last rows)
         const int rr_ = r0 == 0 ? 0 : r0 == 1 ? 6 : 11;
-        a.lam_out[lam_e + (size_t)rr_ * BS] = 0.0; a.lam_out[lam_e + (size_t)(18 + rr_) * BS] = 0.0;
+        ka->lam_out[lam_e + (size_t)rr_ * BS] = 0.0; ka->lam_out[lam_e + (size_t)(18 + rr_) * BS] = 0.0;
       }
     }
-    if (a.x_out && valid) {
-      double *xo = a.x_out + (((size_t)b * 2 + axis) * a.seg_stride + k) * 3;
+    if (ka->x_out && valid) {
+      double *xo = ka->x_out + (((size_t)b * 2 + axis) * ka->seg_stride + k) * 3;
       UNROLL for (int i = 0; i < 3; i++) xo[i] = lds[LN_XB + i][lane];
     }
   }
@@ -854,7 +950,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     }
     const Red4 ro = group_reduce_mixed<0, -1, -1, -1>(lds + LN_RED, lane, gbase, k, S, lane_in_group, obj, 0.0, 0.0, 0.0);
     if (valid && !(CAPPED && suspended)) {
-      double *dst = a.ctrl + (size_t)b * 12 * a.seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
+      double *dst = ka->ctrl + (size_t)b * 12 * ka->seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
       UNROLL for (int i = 0; i < 6; i++) dst[i] = c[i];
       if (first) {
         int st;
@@ -863,22 +959,25 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         else if (best_score < 1e-5 || (res_it < 0 && best_score < 1e-4)) st = BTRAPZ_SOLVED_INACCURATE;
         else st = BTRAPZ_MAX_ITER_REACHED;
         const long long prob = 2LL * b + axis;
-        a.axis_obj[prob] = ro.a;
-        a.axis_status[prob] = st;
-        a.axis_iters[prob] = iters;
+        ka->axis_obj[prob] = ro.a;
+        ka->axis_status[prob] = st;
+        ka->axis_iters[prob] = iters;
       }
     }
   }
+#undef KA_FENCE
 #undef ROW_SEP
 #undef LEAN_RCP
 #undef RCP_PAIR
 #undef LLO
 #undef LUP
 #undef ROW_LIMITS
+#undef ROW_LIMITS_ACC
 #undef LL
 #undef LU
 #undef HSYM
 #undef LEAN_LOAD_P
+#undef LEAN_P_PART
 }
 
 // 256 registers per lane, 20 KB of LDS per wavefront: two wavefronts per SIMD, eight per CU.
