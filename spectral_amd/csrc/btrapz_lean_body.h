@@ -140,7 +140,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 #define HSYM(H, i, j) ((i) <= (j) ? H[SYM(i, j)] : H[SYM(j, i)])
   // P block of the lane's segment (solve_3d.cc:159-171) from the scalar table
 #ifndef LEAN_P_CHUNK
-#define LEAN_P_CHUNK 4
+#define LEAN_P_CHUNK 2
 #endif
 #define LEAN_P_PART(H, i0_, n_)                                                                       \
   {                                                                                                   \
@@ -194,6 +194,12 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 // last) so that the SIMD's other wavefront -- in a row pass, say, with instructions to spare -- fills the gaps instead of
 // getting in front.
 // (measured, 65 536 x 20: scenario_1 two launches 5.35 -> 5.27 ms, one launch 5.63 -> 5.60; generic +-0)
+// -DLEAN_MARKS: the phases named in the ISA (tools: per-phase instruction counts of a -S build)
+#ifdef LEAN_MARKS
+#define LEAN_MARK(x) asm volatile("; ==PHASE " x)
+#else
+#define LEAN_MARK(x)
+#endif
 #ifndef LEAN_PRIO
 #define LEAN_PRIO 3
 #endif
@@ -478,6 +484,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 
   for (;;) {
     KA_FENCE();
+    LEAN_MARK("A1");
     // ---- A1. control points; gradient P c + q + G' (lambda_u - lambda_l), residuals, complementarity ----
     double rd[3];
     double mu_part = 0.0, rp_part = 0.0, dscale = 0.0, rd_part;
@@ -522,6 +529,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       UNROLL for (int i = 0; i < 3; i++) { const double v = from_next(un[i]); rd[i] += last ? 0.0 : v; }
       rd_part = fmax(fabs(rd[0]), fmax(fabs(rd[1]), fabs(rd[2])));
     }
+    LEAN_MARK("TERM");
     // a lane whose residuals are not finite must poison its group's score (fmax / fmin ignore NaN)
     if (!(mu_part == mu_part) || !(rd_part == rd_part) || !(rp_part == rp_part) || !(dscale == dscale) ||
         !(fabs(rd_part) < 1e300) || !(fabs(mu_part) < 1e300))
@@ -598,6 +606,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       }
     }
 
+    LEAN_MARK("A2");
     // ---- A2. Newton block H = P + G' W G and the predictor's right-hand side (rc = s lambda: tv = lambda_l (s_l +
     // rp_l) / s_l - lambda_u (s_u - rp_u) / s_u), then M = Phi' H Phi: block tridiagonal T, M01 ----
     double M01[9], T[6], up[3];
@@ -654,6 +663,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       UNROLL for (int i = 0; i < 6; i++) { const double v = from_next(M00[i]); T[i] += last ? 0.0 : v; }
     }
 
+    LEAN_MARK("B");
     // ---- B. two-sided block LDL^T (lanes s and S-1-s own the pivots of step s; block m = S/2 is the root); the
     // predictor's forward sweep rides along.  MK: M01 of the neighbour towards the root until the lane's step, then
     // K = S_k^{-1} Mc; TF: the diagonal block until then, then its factor ----
@@ -777,6 +787,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       V_apply(nm, dX, dc[3], dc[4], dc[5]);
     };
 
+    LEAN_MARK("C");
     // ---- C. predictor (sigma = 0): statistics of the affine step ----
     // per row: multipliers from the lane's LDS column; slack, residuals and reciprocals recomputed
 #define LROW(r, RCP)                                                                                 \
@@ -811,6 +822,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       sigma_mu = sr * sr * sr * mu;
       second_order = (plain && fmin(ap, ad) < 0.1) ? 0.0 : -1.0;   // (the second chance: see the packed form)
     }
+    LEAN_MARK("D");
     // ---- D. corrector: rc = s lambda + ds_aff dlambda_aff - sigma mu, dlambda_aff = -lambda (1 + ds_aff / s) ----
 #define LROW_CORR(r)                                                                              \
       const double ga = row_dot<r>(dca, t);                                                         \
@@ -818,7 +830,19 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       const double rcl = __builtin_fma(second_order, (ll * dsa) * (1.0 + dsa * isl), __builtin_fma(s_l, ll, -sigma_mu)); \
       const double rcu = __builtin_fma(second_order, (lu * dua) * (1.0 + dua * isu), __builtin_fma(s_u, lu, -sigma_mu)); \
       const double el = rcl * isl, eu = rcu * isu, wl = ll * isl, wu = lu * isu;
+    // LEAN_E_CACHE: the corrected complementarity targets rc / s, el and eu, are the same numbers in the corrector's
+    // right-hand side (pass D), the step ratios (E1) and the update (E2).  1 (default): formed in D and again in E1, kept
+    // from E1 to E2 in the 60 registers the factorisation's blocks have just left; 2: formed in D only and kept through
+    // the corrector's solve -- 210 vector instructions per iteration less and 108 B of scratch per lane more, of iterate
+    // state spilled inside the sequential sweeps: 4.94 -> 5.33 ms on the scenario_1 batch, measured, rejected; 0: formed
+    // in all three passes, the two maxima of E1 through LDS atomics.
+#ifndef LEAN_E_CACHE
+#define LEAN_E_CACHE 1
+#endif
     double dc[6];
+#if LEAN_E_CACHE == 2
+    double el_[NR], eu_[NR];
+#endif
     {
       double h[6], u[3];
       UNROLL for (int i = 0; i < 6; i++) h[i] = 0.0;
@@ -828,6 +852,9 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         FOR_ROWS(r)
           LROW(r, LEAN_RCP)
           LROW_CORR(r)
+#if LEAN_E_CACHE == 2
+          el_[SI(r)] = el; eu_[SI(r)] = eu;
+#endif
           row_scatter<r>((el - eu) + (wl * rpl + wu * rpu), t, h);
         END_ROWS
       }
@@ -841,25 +868,28 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       forward_u(u);
       backward_u(u, dX, dc);
     }
+    LEAN_MARK("E1");
     // ---- E. step to the boundary, then the step ----
-    // LEAN_E_CACHE: the corrected complementarity targets rc / s of the ratio pass kept for the update pass (60 registers
-    // the factorisation's blocks have just left) -- with the ordered reduction in between; without: recomputed there, and
-    // the two maxima go through LDS atomics.  (The register allocator does not survive both: measured)
-#ifndef LEAN_E_CACHE
-#define LEAN_E_CACHE 1
-#endif
     {
       double pr = 0.0, dr = 0.0;
-#if LEAN_E_CACHE
+#if LEAN_E_CACHE == 1
       double el_[NR], eu_[NR];
 #endif
+#if LEAN_E_CACHE == 2
+      PHASE_FENCE(opaque6(c); opaque6(dc); fence_slacks());
+#else
       PHASE_FENCE(opaque6(c); opaque6(dca); opaque6(dc); fence_slacks());
+#endif
       {
         ROW_LIMITS();
         FOR_ROWS(r)
           LROW(r, LEAN_RCP)
+#if LEAN_E_CACHE == 2
+          const double wl = ll * isl, wu = lu * isu, el = el_[SI(r)], eu = eu_[SI(r)];
+#else
           LROW_CORR(r)
-#if LEAN_E_CACHE
+#endif
+#if LEAN_E_CACHE == 1
           el_[SI(r)] = el; eu_[SI(r)] = eu;
 #endif
           const double gd = row_dot<r>(dc, t);
@@ -876,6 +906,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 #else
       const Red4 rs = group_reduce_mixed<-1, 1, 1, -1>(lds + LN_RED, lane, gbase, k, S, lane_in_group, 0.0, pr, dr, 0.0);
 #endif
+    LEAN_MARK("E2");
       const double m_ = fmax(rs.b, rs.c);
       const double tau = (m_ * ka->tau_thr <= 1.0 && eit - it0 < ka->tau_iters) ? ka->tau : fmin(ka->tau, 0.995);
       const double alpha = fmin(1.0, tau * rcp(fmax(m_, tau)));
@@ -903,6 +934,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     }
 #undef LROW
 #undef LROW_CORR
+    LEAN_MARK("END");
     if (!done) ++eit;
   }
 
