@@ -158,8 +158,12 @@ template <int OP> __device__ __forceinline__ double red_init() { return OP == 0 
 // canonicalisation the compiler cannot prove away, ~90 instructions per iteration.  Writing the instruction as inline
 // asm removes them and costs far more: the "v" constraints pin operands that now live in AGPRs and the allocator
 // answers with 476 B of scratch per lane, 5.57 -> 8.27 ms.  Measured, rejected.)
+// (Inline-asm v_max_f64 / v_min_f64 to get rid of the canonicalising v_max_f64 x, x, x in front of maxima of LDS / DPP
+//  values: tried in the lean form too, round 4 -- the allocator answers with 708 B of scratch per lane.  Rejected again.)
 template <int OP> __device__ __forceinline__ double red_op(double acc, double v, bool in_range) {
-  if constexpr (OP == 0) return acc + (in_range ? v : 0.0);   // padded slots repeat entry S-1: harmless for max/min
+  // (padded slots repeat entry S-1: harmless for max / min; a sum takes them with weight 0 -- one fused multiply-add with
+  //  a scalar 0 / 1 instead of a two-instruction select and an add; fma(v, 1, acc) rounds as acc + v does)
+  if constexpr (OP == 0) return __builtin_fma(v, in_range ? 1.0 : 0.0, acc);
   else if constexpr (OP == 1) return fmax(acc, v);
   else return fmin(acc, v);
 }

@@ -900,7 +900,10 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           dr = fmax(dr, fmax(-dll * (lu * rll_), -dlu * (ll * rll_)));
         END_ROWS
       }
-#if LEAN_E_CACHE
+#ifndef LEAN_E_ATOMIC
+#define LEAN_E_ATOMIC 0
+#endif
+#if LEAN_E_CACHE && !LEAN_E_ATOMIC
       const Red4 rs2 = group_reduce2<1, 1>(lds + LN_RED, lane, gbase, k, S, pr, dr);
       const Red4 rs = {0.0, rs2.a, rs2.b, 0.0};
 #else
