@@ -56,6 +56,7 @@ struct KernelArgs {
   int cap_iter;             // iterations after which a group of the capped launch may suspend (0: no cap) ...
   int cap_alone;            // ... when at most this many groups of its wavefront are still iterating,
   int cap_hi;               // and after which it suspends in any case
+  double cap_score;         // a lone group whose KKT score is already below this stays: it is one or two iterations from done
   int susp_cap;             // slots of susp_state
   double *susp_state;       // [susp_cap][SUSP_FIELDS][seg_stride]
   int *susp_count;          // [1] slots handed out

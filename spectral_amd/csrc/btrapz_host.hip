@@ -79,6 +79,15 @@ static inline const char *experiment_env(const char *name) {
 #ifndef BTRAPZ_CAP_HI
 #define BTRAPZ_CAP_HI 4
 #endif
+// BTRAPZ_CAP_SCORE > 0: a lone group whose score is already below it is NOT handed over (quadratic convergence: one or
+// two iterations left; half of what scenario_1 hands over and three quarters of the generic batch is below 1e-5).
+// Measured, round 4 (65 536 x 20, lean form): it halves the hand-over traffic and costs time -- scenario_1 4.85 ms without,
+// 4.94 / 4.99 / 5.01 / 5.05 with 1e-6 / 1e-5 / 1e-4 / 1e-3; generic 3.78 -> 3.90 ... 4.01: a group alone in its wavefront
+// runs its last iteration at a third of the machine's width, and that costs more than 74 doubles per segment out and
+// back.  Off.
+#ifndef BTRAPZ_CAP_SCORE
+#define BTRAPZ_CAP_SCORE 0.0
+#endif
 #define BTRAPZ_SUSP_PERCENT 25
 #define BTRAPZ_SUSP_BYTES_MAX (1ull << 30)
 
@@ -222,7 +231,7 @@ static void fill_parameters(KernelArgs &a, const btrapz_shared *sh, const btrapz
   a.elastic_delta = (opt && opt->elastic_delta > 0) ? opt->elastic_delta : BTRAPZ_DEFAULT_ELASTIC_DELTA;
   a.elastic_tol = (opt && opt->elastic_tol > 0) ? opt->elastic_tol : BTRAPZ_DEFAULT_ELASTIC_TOL;
   a.bucket_S = 0;
-  a.cap_iter = 0; a.cap_alone = 0; a.cap_hi = 0; a.susp_cap = 0; a.susp_state = nullptr; a.susp_count = nullptr; a.susp_slot = nullptr; a.susp_key = nullptr;
+  a.cap_iter = 0; a.cap_alone = 0; a.cap_hi = 0; a.cap_score = 0.0; a.susp_cap = 0; a.susp_state = nullptr; a.susp_count = nullptr; a.susp_slot = nullptr; a.susp_key = nullptr;
   static const int start_env = [] { const char *e = experiment_env("BTRAPZ_START"); return e ? atoi(e) : -1; }();
   a.unc_start = start_env >= 0 ? start_env : (opt ? opt->start : 0);
 }
@@ -495,7 +504,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       HIPCHK(c, hipMemsetAsync(keys, 0, sizeof(int) * 2 * (size_t)B, stream));
       HIPCHK(c, hipMemsetAsync(c->d_rescue_meta, 0, sizeof(int) * 2 * 198, stream));
       KernelArgs p1 = a;
-      p1.cap_iter = cap_iter; p1.cap_alone = BTRAPZ_CAP_ALONE; p1.cap_hi = cap_iter + BTRAPZ_CAP_HI; p1.susp_cap = (int)slots; p1.susp_state = c->d_susp_state; p1.susp_count = count;
+      p1.cap_iter = cap_iter; p1.cap_alone = BTRAPZ_CAP_ALONE; p1.cap_hi = cap_iter + BTRAPZ_CAP_HI; p1.cap_score = BTRAPZ_CAP_SCORE; p1.susp_cap = (int)slots; p1.susp_state = c->d_susp_state; p1.susp_count = count;
       p1.susp_slot = slot_of; p1.susp_key = keys;
       if (lean_on) {
         if (ragged) hipLaunchKernelGGL(ipm_solve_lean_capped_ragged_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);

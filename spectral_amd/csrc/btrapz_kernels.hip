@@ -786,7 +786,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // wavefront would run at a third of its width for it), and any group still iterating cap_hi iterations in (a long
       // runner belongs at the front of a launch, not wherever the batch order put it).
       const int nact = __popcll(__ballot(first && lane_in_group && valid && !done));
-      const bool want = !done && !unc_pass && valid && ((eit >= a.cap_iter && nact <= a.cap_alone) || eit >= a.cap_hi);
+      const bool want = !done && !unc_pass && valid && ((eit >= a.cap_iter && nact <= a.cap_alone && score >= a.cap_score) || eit >= a.cap_hi);
       if (__any(want)) {
         UNIFORM_BLOCK;
         wave_lds_sync();

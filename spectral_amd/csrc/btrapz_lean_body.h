@@ -572,7 +572,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         // the cap: who hands over is the packed form's rule (a group alone in its wavefront after cap_iter iterations,
         // any group after cap_hi)
         const int nact = __popcll(__ballot(first && lane_in_group && valid && !done));
-        const bool want = !done && valid && ((eit >= ka->cap_iter && nact <= ka->cap_alone) || eit >= ka->cap_hi);
+        const bool want = !done && valid && ((eit >= ka->cap_iter && nact <= ka->cap_alone && score >= ka->cap_score) || eit >= ka->cap_hi);
         if (__builtin_expect(__any(want), 0)) {   // (rare: at most once per group)
           UNIFORM_BLOCK;
           wave_lds_sync();
