@@ -461,7 +461,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     const bool cap_requested = cap_iter > 0;   // (by the caller; the automatic choice below falls back to one launch when the workspace cannot be had)
     if (cap_iter == 0 && !ragged && S >= 16 && blocks >= 8u * (unsigned)c->resident_waves) cap_iter = 6;
     const bool capped = cap_iter > 0 && !long_form && !split_on && (!a.order || ragged) && !warm_kernel && !queue_on && S <= BTRAPZ_MAX_SEGMENTS &&
-                        cap_iter < a.max_iter && elastic != 2;
+                        cap_iter < a.max_iter && cap_iter + BTRAPZ_CAP_HI < 4000 && elastic != 2;   // (4000: the lean record's 12-bit counters)
     // Workspace of the two launches: hand-over slots for a quarter of the axis problems (a group that finds none simply
     // goes on), 74 doubles per segment each -- 19 KB per slot at 64 segments, 388 MB for 65 536 candidates of 20 -- but
     // never more than BTRAPZ_SUSP_BYTES_MAX.  When the device cannot give it, a solve that chose the two launches by

@@ -30,7 +30,8 @@
 namespace btrapz {
 
 enum { LN_LL = 0, LN_LU = 15, LN_RED = 30, LN_XB = 34, LN_XI = 37, LN_ROWS = 40 };
-enum { LEAN_SUSP_FIELDS = 3 + 4 * 15 + 3 + 8 };   // == SUSP_FIELDS of the packed form (the host sizes one workspace)
+enum { LEAN_SUSP_FIELDS = 3 + 4 * 15 + 3 + 8 };   // slot stride: SUSP_FIELDS of the packed form (the host sizes one workspace);
+                                                  // the lean record itself is 69 doubles per lane (3 + 3 + 60 + 3 of bookkeeping)
 
 template <bool ORDERED, bool CAPPED, bool RESUME, bool SMALL_S, bool WARM = false>
 __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const double *__restrict__ mqm, double (*lds)[64],
@@ -465,11 +466,17 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       io(l_); io(u_);
       if (!store) { LL(r) = l_; LU(r) = u_; }
     END_ROWS
-    double g8[8] = {best_score, (double)best_it, (double)best_res, (double)res_it, plain ? 1.0 : 0.0, (double)eit, 0.0, (double)iters};
-    UNROLL for (int i = 0; i < 8; i++) io(g8[i]);
+    // the group's bookkeeping in three doubles: the four counters (12 bits each -- a hand-over happens within cap_hi
+    // iterations, and the host keeps that below 4000; res_it may be -1) and a flag share one, exactly
+    double g3[3] = {best_score, (double)best_res,
+                    (double)best_it + 4096.0 * (double)(res_it + 1) + 16777216.0 * (double)eit + 68719476736.0 * (double)iters +
+                        (plain ? 281474976710656.0 : 0.0)};
+    UNROLL for (int i = 0; i < 3; i++) io(g3[i]);
     if (!store) {
-      best_score = g8[0]; best_it = (int)g8[1]; best_res = (float)g8[2]; res_it = (int)g8[3]; plain = g8[4] != 0.0;
-      eit = (int)g8[5]; iters = (int)g8[7];
+      best_score = g3[0]; best_res = (float)g3[1];
+      const long long code = (long long)g3[2];
+      best_it = (int)(code & 4095); res_it = (int)((code >> 12) & 4095) - 1; eit = (int)((code >> 24) & 4095); iters = (int)((code >> 36) & 4095);
+      plain = ((code >> 48) & 1) != 0;
     }
   };
   // resume: carry on where the capped launch stopped.  The iterate handed over has been evaluated there (best iterate,
