@@ -1028,7 +1028,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 #define ROW_STEP(r, gd, b) (ELASTIC ? ((gd) - ED(r) * (b)) * rcp(1.0 + ED(r) * (ll * isl + lu * isu)) : (gd))
 
     double dca[6], dX[3];
-    double sigma_mu, second_order;   // second_order: -1, or 0 when the corrector leaves that term out (below)
+    double sigma_mu, second_order;   // second_order: minus the weight of the second-order term (second_order_factor, btrapz_ipm.h)
     if (__any(unc_pass)) {   // (the groups of a wavefront start together: a wave-uniform branch)
       UNIFORM_BLOCK;
       backward_u(up, dX, dca);
@@ -1072,7 +1072,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       const double mua = ((1.0 - ad) * rr.a + (ap - ad - ap * ad) * ra.a - ap * ad * ra.b) * inv_m;
       const double sr = mua / mu;
       sigma_mu = sr * sr * sr * mu;
-      second_order = (plain && fmin(ap, ad) < 0.1) ? 0.0 : -1.0;
+      second_order = second_order_factor(ap, ad, plain);
       // corrector
       double el5[5], eu5[5], h[6], dc[6];
       wave_lds_sync();
@@ -1145,9 +1145,9 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // 1e-11): 2 of the 262 144 candidates of the four bench batches ended that way where the oracle finds x*.
       // A solve that stalls that way (termination test above) gets a second chance in which the corrector leaves the
       // term out on blocked iterations (the factor of the fused multiply-add that subtracts it): both converge within
-      // ten more iterations.  Everywhere else the term stays: dropping it on every blocked step costs 0.5-2.5 % more
-      // iterations on average.
-      second_order = (plain && fmin(ap, ad) < 0.1) ? 0.0 : -1.0;
+      // ten more iterations.  (Dropping it on every blocked step costs 0.5-2.5 % more iterations on average; weighting
+      // it by how far the affine step gets -- second_order_factor, round 4 -- saves 5-9 %.)
+      second_order = second_order_factor(ap, ad, plain);
     }
     {
       // corrector.  rc = s*lambda + [ds_aff*dlambda_aff] - sigma*mu , dlambda_aff = -lambda (1 + ds_aff/s)

@@ -489,6 +489,9 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     handed_over = true;
   }
 
+#ifdef LEAN_TRACE   // (debug build: per-iteration score, primal / dual residual, mu, step, centring instead of the control points)
+  double tr_score = 0.0, tr_res = 0.0, tr_mu = 0.0, tr_sr = 0.0, tr_pr = 0.0, tr_dr = 0.0;
+#endif
   for (;;) {
     KA_FENCE();
     LEAN_MARK("A1");
@@ -550,6 +553,9 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       const double rprim = rr.c * ibn;
       const double res = fmax(rd_eff * iqn, rprim);
       const double score = fmax(res, mu);
+#ifdef LEAN_TRACE
+      tr_score = score; tr_res = rd_eff * iqn; tr_mu = mu; tr_pr = rprim;
+#endif
       const double mu_primal = fmax(mu, rprim);
       const bool feasible_and_complementary = mu_primal < 1e-7;
       if (!done && !(RESUME && handed_over)) {
@@ -826,8 +832,11 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       const double ap = rcp(fmax(-ra.d, 1.0)), ad = rcp(fmax(1.0 + ra.c, 1.0));
       const double mua = ((1.0 - ad) * rr.a + (ap - ad - ap * ad) * ra.a - ap * ad * ra.b) * inv_m;
       const double sr = mua * rcp(mu);
+#ifdef LEAN_TRACE
+      tr_sr = sr; tr_dr = fmin(ap, ad);
+#endif
       sigma_mu = sr * sr * sr * mu;
-      second_order = (plain && fmin(ap, ad) < 0.1) ? 0.0 : -1.0;   // (the second chance: see the packed form)
+      second_order = second_order_factor(ap, ad, plain);   // (weighted by how far the affine step gets; the second chance: btrapz_ipm.h)
     }
     LEAN_MARK("D");
     // ---- D. corrector: rc = s lambda + ds_aff dlambda_aff - sigma mu, dlambda_aff = -lambda (1 + ds_aff / s) ----
@@ -920,8 +929,16 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       const double m_ = fmax(rs.b, rs.c);
       const double tau = (m_ * ka->tau_thr <= 1.0 && eit - it0 < ka->tau_iters) ? ka->tau : fmin(ka->tau, 0.995);
       const double alpha = fmin(1.0, tau * rcp(fmax(m_, tau)));
+      const double alpha_p = alpha, alpha_d = alpha;
+#ifdef LEAN_TRACE
+      if (first && valid && !done && (eit + 1) * 4 <= 6 * S) {   // 4 values per iteration into the axis's 6 S control-point slots
+        double *tdst = ka->ctrl + (size_t)b * 12 * ka->seg_stride + (size_t)axis * 6 * S + (size_t)eit * 4;
+        tdst[0] = tr_score; tdst[1] = tr_mu; tdst[2] = rs.b > rs.c ? alpha_p : -alpha_d;   // (negative: the dual ratio limits the step)
+        tdst[3] = tr_pr > tr_res ? -tr_sr : tr_sr;                                     // (negative: the primal residual is the larger one)
+      }
+#endif
       if (!done && alpha == alpha) {
-        UNROLL for (int i = 0; i < 3; i++) X[i] += alpha * dX[i];
+        UNROLL for (int i = 0; i < 3; i++) X[i] += alpha_p * dX[i];
 #if LEAN_E_CACHE
         PHASE_FENCE(opaque6(c); opaque6(dc); fence_slacks());
 #else
@@ -937,8 +954,8 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 #endif
           const double gd = row_dot<r>(dc, t);
           const double dsl = gd + rpl, dsu = -gd - rpu;
-          sl[SI(r)] = s_l + alpha * dsl; su[SI(r)] = s_u + alpha * dsu;
-          LL(r) = ll + alpha * (-el - wl * dsl); LU(r) = lu + alpha * (-eu - wu * dsu);
+          sl[SI(r)] = s_l + alpha_p * dsl; su[SI(r)] = s_u + alpha_p * dsu;
+          LL(r) = ll + alpha_d * (-el - wl * dsl); LU(r) = lu + alpha_d * (-eu - wu * dsu);
         END_ROWS
       }
     }
@@ -993,7 +1010,11 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     const Red4 ro = group_reduce_mixed<0, -1, -1, -1>(lds + LN_RED, lane, gbase, k, S, lane_in_group, obj, 0.0, 0.0, 0.0);
     if (valid && !(CAPPED && suspended)) {
       double *dst = ka->ctrl + (size_t)b * 12 * ka->seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
+#ifndef LEAN_TRACE
       UNROLL for (int i = 0; i < 6; i++) dst[i] = c[i];
+#else
+      (void)dst;
+#endif
       if (first) {
         int st;
         if (infeasible_bounds) st = BTRAPZ_PRIMAL_INFEASIBLE;
