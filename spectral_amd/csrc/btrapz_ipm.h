@@ -126,6 +126,20 @@ __device__ __forceinline__ void VT_apply(const NullMap m, double h3, double h4, 
   o[0] = m.it * ((h3 + h4) + h5); o[1] = -0.4 * h3 - 0.2 * h4; o[2] = m.t20 * h3;
 }
 
+// Cold start (all forms): slacks max(gap, BTRAPZ_COLD_SLACK), multipliers BTRAPZ_COLD_LAMBDA at the initial state propagated
+// at constant velocity.  Rounds 1-3 had 1 and 1; with the weighted second-order term (below) a start further inside
+// pays: tools/ab_variants.py sweep, round 4, 65 536 x 20 two launches / jittered bundled files (sum of six sets' mean
+// iterations): (1, 1) 4.30 ms / 81.9; (1, 2) 4.18 / 75.1; (1, 3) 4.15 / 71.9; (2, 4) 4.08 / 72.2; (2, 5) 4.05 / 72.1;
+// (3, 4) 4.05 / 75.6; (3, 6) 4.01 / 73.0 -- a broad plateau; generic batch 3.69 -> 3.67, cuboid 4.39 -> 4.04, 10 segments
+// 1.59 -> 1.66.  Per-row centred starts (lambda = mu0 / s) and a multiplier from the group's mean slack: no gain.
+// (The rescue pass -- the relaxed problem, its own scaling -- keeps 1 and 1.)
+#ifndef BTRAPZ_COLD_SLACK
+#define BTRAPZ_COLD_SLACK 3.0
+#endif
+#ifndef BTRAPZ_COLD_LAMBDA
+#define BTRAPZ_COLD_LAMBDA 6.0
+#endif
+
 // Factor of Mehrotra's second-order term ds_aff * dlambda_aff in the corrector's complementarity target (it enters through
 // a fused multiply-add that subtracts it: the factor is minus its weight).  The term describes the affine step; where
 // that step is cut short by a bound it describes less, and taking it in full then pushes the corrected step against the

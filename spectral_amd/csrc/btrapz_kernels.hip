@@ -241,9 +241,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
 #define HSYM(H, i, j) ((i) <= (j) ? H[SYM(i, j)] : H[SYM(j, i)])
 #define LL(r) lds[L_LL + SI(r)][lane]
 #define LU(r) lds[L_LU + SI(r)][lane]
-  // cold start of this lane: slacks max(gap, 1), multipliers 1
-  // slacks max(gap, 1) and multipliers 1 at the current X
+  // cold start of this lane: slacks max(gap, BTRAPZ_COLD_SLACK), multipliers BTRAPZ_COLD_LAMBDA at the current X
+  // (btrapz_ipm.h; the rescue pass: 1 and 1)
   auto init_slacks = [&]() {
+    constexpr double smin0 = ELASTIC ? 1.0 : BTRAPZ_COLD_SLACK, lam0 = ELASTIC ? 1.0 : BTRAPZ_COLD_LAMBDA;
     double Xp[3], c[6];
     UNROLL for (int i = 0; i < 3; i++) { const double v = from_prev(X[i]); Xp[i] = first ? Xinit[i] : v; }
     U_apply(nm, Xp, c[0], c[1], c[2]);
@@ -252,14 +253,14 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       double v5[5];
       slot_vals(c, v5);
       UNROLL for (int i = 0; i < 5; i++) {
-        sl5[i] = fmax(v5[i] - lo5[i], 1.0); su5[i] = fmax(up5[i] - v5[i], 1.0);
-        ll5[i] = 1.0; lu5[i] = 1.0;
+        sl5[i] = fmax(v5[i] - lo5[i], smin0); su5[i] = fmax(up5[i] - v5[i], smin0);
+        ll5[i] = lam0; lu5[i] = lam0;
       }
     } else {
       FOR_ROWS(r)
         const double gc_r = row_dot<r>(c, t);
-        sl[SI(r)] = fmax(gc_r - LO(r), 1.0); su[SI(r)] = fmax(UP(r) - gc_r, 1.0);
-        LL(r) = 1.0; LU(r) = 1.0;
+        sl[SI(r)] = fmax(gc_r - LO(r), smin0); su[SI(r)] = fmax(UP(r) - gc_r, smin0);
+        LL(r) = lam0; LU(r) = lam0;
       END_ROWS
     }
   };

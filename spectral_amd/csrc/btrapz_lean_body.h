@@ -282,15 +282,15 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     }
   };
 #endif
-  // cold start at the current X: slacks max(gap, 1), multipliers 1
+  // cold start at the current X: slacks max(gap, BTRAPZ_COLD_SLACK), multipliers BTRAPZ_COLD_LAMBDA (btrapz_ipm.h)
   auto cold_rows = [&]() {
     double c[6];
     control_points(X, c);
     ROW_LIMITS();
     FOR_ROWS(r)
       const double gc_r = row_dot<r>(c, t);
-      sl[SI(r)] = fmax(gc_r - LLO(r), 1.0); su[SI(r)] = fmax(LUP(r) - gc_r, 1.0);
-      LL(r) = 1.0; LU(r) = 1.0;
+      sl[SI(r)] = fmax(gc_r - LLO(r), BTRAPZ_COLD_SLACK); su[SI(r)] = fmax(LUP(r) - gc_r, BTRAPZ_COLD_SLACK);
+      LL(r) = BTRAPZ_COLD_LAMBDA; LU(r) = BTRAPZ_COLD_LAMBDA;
     END_ROWS
   };
 
