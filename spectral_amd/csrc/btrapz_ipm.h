@@ -126,6 +126,15 @@ __device__ __forceinline__ void VT_apply(const NullMap m, double h3, double h4, 
   o[0] = m.it * ((h3 + h4) + h5); o[1] = -0.4 * h3 - 0.2 * h4; o[2] = m.t20 * h3;
 }
 
+// A solve whose step length stays below BTRAPZ_TINY_STEP for BTRAPZ_TINY_STEPS iterations in a row is going nowhere: the
+// iterate of a problem without a solution wedges itself against bounds that contradict each other and creeps on with
+// steps of 1e-5 and less, the score falling in its tenth digit -- which the "no better score for six iterations" rule
+// counts as progress.  (With the unweighted second-order term such iterates blew up within a few iterations and the
+// divergence rule caught them at 17 on average; weighted, they crept on to 30.  Solvable candidates: the smallest steps
+// seen on the slowest of them are 5e-3, never twice in a row.)
+#define BTRAPZ_TINY_STEP 1e-3
+#define BTRAPZ_TINY_STEPS 3
+
 // Cold start (all forms): slacks max(gap, BTRAPZ_COLD_SLACK), multipliers BTRAPZ_COLD_LAMBDA at the initial state propagated
 // at constant velocity.  Rounds 1-3 had 1 and 1; with the weighted second-order term (below) a start further inside
 // pays: tools/ab_variants.py sweep, round 4, 65 536 x 20 two launches / jittered bundled files (sum of six sets' mean

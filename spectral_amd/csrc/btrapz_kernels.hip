@@ -209,7 +209,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   bool warm_started = false, restarted = true;   // a warm-started group that stalls gets ONE cold restart
   int it0 = 0;                                   // iteration at which the current start was made
   double best_score = 1e300, Xb[3] = {0.0, 0.0, 0.0};
-  int best_it = 0, iters = 0;
+  int best_it = 0, iters = 0, tiny_steps = 0;   // tiny_steps: consecutive steps shorter than BTRAPZ_TINY_STEP (btrapz_ipm.h)
   float best_res = 3e38f;          // smallest residual part of the score so far and when (the stall test)
   int res_it = 0;
   bool plain = false;              // second chance of a solve whose complementarity is stuck: see the corrector
@@ -283,10 +283,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       io(l_); io(u_);
       if (!store) { LL(r) = l_; LU(r) = u_; }
     END_ROWS
-    double g8[8] = {best_score, (double)best_it, (double)best_res, (double)res_it, plain ? 1.0 : 0.0, (double)eit, (double)it0, (double)iters};
+    double g8[8] = {best_score, (double)best_it, (double)best_res, (double)res_it, (plain ? 1.0 : 0.0) + 2.0 * (double)tiny_steps, (double)eit, (double)it0, (double)iters};
     UNROLL for (int i = 0; i < 8; i++) io(g8[i]);
     if (!store) {
-      best_score = g8[0]; best_it = (int)g8[1]; best_res = (float)g8[2]; res_it = (int)g8[3]; plain = g8[4] != 0.0;
+      best_score = g8[0]; best_it = (int)g8[1]; best_res = (float)g8[2]; res_it = (int)g8[3]; plain = ((int)g8[4] & 1) != 0; tiny_steps = (int)g8[4] >> 1;
       eit = (int)g8[5]; it0 = (int)g8[6]; iters = (int)g8[7];
     }
   };
@@ -750,7 +750,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // after 24, is restarted once from the cold start: a bad guess must neither turn a solvable candidate
       // into a failure nor cost more than a bounded number of iterations.
       const bool stalled = (eit - it0 >= a.stall_start && eit - best_it >= a.stall_len && eit - res_it >= a.stall_len) ||
-                           (!ELASTIC && mu > (double)a.diverge_factor * best_score) || !(score < 1e299);
+                           (!ELASTIC && mu > (double)a.diverge_factor * best_score) || !(score < 1e299) ||
+                           (!ELASTIC && tiny_steps >= BTRAPZ_TINY_STEPS);
       // (the dual floor: feasible to 1e-7 and complementary to 1e-7, the dual residual alone stuck between 1e-5 and
       //  1e-4 for three iterations -- the accuracy of the block elimination on a badly scaled corridor (a 0.1 s segment
       //  among 1 s ones), not of the iterate's position: "solved inaccurate", instead of iterating on until the slacks
@@ -814,7 +815,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // restarts as a whole (the score is group-uniform), so the DPP reads inside cold_start stay in the group.
       if (restart_now) {
         cold_start();
-        best_score = 1e300; best_it = eit + 1; it0 = eit + 1; restarted = true; best_res = 3e38f; res_it = eit + 1;
+        best_score = 1e300; best_it = eit + 1; it0 = eit + 1; restarted = true; best_res = 3e38f; res_it = eit + 1; tiny_steps = 0;
         Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2];
         ++eit;       // (the other groups did not take a step in this pass: their count stands)
       }
@@ -1108,6 +1109,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       const double m_ = fmax(rb.b, rb.c);
       const double tau = (m_ * a.tau_thr <= 1.0 && eit - it0 < a.tau_iters) ? a.tau : fmin(a.tau, 0.995);
       const double alpha = fmin(1.0, tau / fmax(m_, tau));
+      if (!done) tiny_steps = alpha < BTRAPZ_TINY_STEP ? (tiny_steps < 3 ? tiny_steps + 1 : 3) : 0;
       if (!done && alpha == alpha) {
         UNROLL for (int i = 0; i < 3; i++) X[i] += alpha * dX[i];
         UNROLL for (int i = 0; i < 5; i++) {
@@ -1189,6 +1191,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       const double m_ = fmax(ra.b, ra.c);
       const double tau = (m_ * a.tau_thr <= 1.0 && eit - it0 < a.tau_iters) ? a.tau : fmin(a.tau, 0.995);
       const double alpha = fmin(1.0, tau / fmax(m_, tau));
+      if (!done) tiny_steps = alpha < BTRAPZ_TINY_STEP ? (tiny_steps < 3 ? tiny_steps + 1 : 3) : 0;
       // a finished group keeps its state (a branch, not alpha = 0: 0 * inf would poison it); a step that is
       // not finite is not taken either -- the score of the unchanged iterate then stalls and the group stops
       if (!done && alpha == alpha) {

@@ -242,7 +242,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   // termination bookkeeping (group-uniform)
   double best_score = 1e300;
   float best_res = 3e38f;
-  int best_it = 0, res_it = 0, iters = 0, eit = 0;
+  int best_it = 0, res_it = 0, iters = 0, eit = 0, tiny_steps = 0;
   bool plain = false, done, suspended = false;
   // warm-start instantiations: a group whose guess does not pay off gets ONE cold restart (the packed form's rule)
   [[maybe_unused]] bool warm_started = false, restarted = true;
@@ -467,16 +467,16 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       if (!store) { LL(r) = l_; LU(r) = u_; }
     END_ROWS
     // the group's bookkeeping in three doubles: the four counters (12 bits each -- a hand-over happens within cap_hi
-    // iterations, and the host keeps that below 4000; res_it may be -1) and a flag share one, exactly
+    // iterations, and the host keeps that below 4000; res_it may be -1), a flag and the tiny-step count share one, exactly
     double g3[3] = {best_score, (double)best_res,
                     (double)best_it + 4096.0 * (double)(res_it + 1) + 16777216.0 * (double)eit + 68719476736.0 * (double)iters +
-                        (plain ? 281474976710656.0 : 0.0)};
+                        (plain ? 281474976710656.0 : 0.0) + 562949953421312.0 * (double)tiny_steps};
     UNROLL for (int i = 0; i < 3; i++) io(g3[i]);
     if (!store) {
       best_score = g3[0]; best_res = (float)g3[1];
       const long long code = (long long)g3[2];
       best_it = (int)(code & 4095); res_it = (int)((code >> 12) & 4095) - 1; eit = (int)((code >> 24) & 4095); iters = (int)((code >> 36) & 4095);
-      plain = ((code >> 48) & 1) != 0;
+      plain = ((code >> 48) & 1) != 0; tiny_steps = (int)((code >> 49) & 3);
     }
   };
   // resume: carry on where the capped launch stopped.  The iterate handed over has been evaluated there (best iterate,
@@ -566,7 +566,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         }
         if ((float)res < ka->stall_factor * best_res) { best_res = (float)res; res_it = eit; }
         const bool stalled = (eit - it0 >= ka->stall_start && eit - best_it >= ka->stall_len && eit - res_it >= ka->stall_len) ||
-                             (mu > (double)ka->diverge_factor * best_score) || !(score < 1e299);
+                             (mu > (double)ka->diverge_factor * best_score) || !(score < 1e299) || tiny_steps >= BTRAPZ_TINY_STEPS;
         const int patience = (best_score < 1e-7 && mu_primal < 1e-2 * best_score) ? 1 : 3;
         const bool at_floor = best_score < (feasible_and_complementary ? 1e-4 : 1e-5) && eit - best_it >= patience;
         if (at_floor && feasible_and_complementary) res_it = -1;
@@ -611,7 +611,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           const double xc = lds[LN_XI][lane], v0 = lds[LN_XI + 1][lane];
           X[0] = first ? xc + v0 * t : xc; X[1] = v0; X[2] = 0.0;     // (a first lane's row 0 is the initial position itself)
           cold_rows();
-          best_score = 1e300; best_it = eit + 1; it0 = eit + 1; restarted = true; best_res = 3e38f; res_it = eit + 1;
+          best_score = 1e300; best_it = eit + 1; it0 = eit + 1; restarted = true; best_res = 3e38f; res_it = eit + 1; tiny_steps = 0;
           UNROLL for (int i = 0; i < 3; i++) lds[LN_XB + i][lane] = X[i];
           ++eit;       // (the other groups did not take a step in this pass: their count stands)
         }
@@ -930,9 +930,10 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       const double tau = (m_ * ka->tau_thr <= 1.0 && eit - it0 < ka->tau_iters) ? ka->tau : fmin(ka->tau, 0.995);
       const double alpha = fmin(1.0, tau * rcp(fmax(m_, tau)));
       const double alpha_p = alpha, alpha_d = alpha;
+      if (!done) tiny_steps = alpha < BTRAPZ_TINY_STEP ? (tiny_steps < 3 ? tiny_steps + 1 : 3) : 0;   // (btrapz_ipm.h)
 #ifdef LEAN_TRACE
-      if (first && valid && !done && (eit + 1) * 4 <= 6 * S) {   // 4 values per iteration into the axis's 6 S control-point slots
-        double *tdst = ka->ctrl + (size_t)b * 12 * ka->seg_stride + (size_t)axis * 6 * S + (size_t)eit * 4;
+      if (first && valid && !done && (eit + 1) * 4 <= 6 * ka->seg_stride) {   // 4 values per iteration into the axis's half of the candidate's slot
+        double *tdst = ka->ctrl + (size_t)b * 12 * ka->seg_stride + (size_t)axis * 6 * ka->seg_stride + (size_t)eit * 4;
         tdst[0] = tr_score; tdst[1] = tr_mu; tdst[2] = rs.b > rs.c ? alpha_p : -alpha_d;   // (negative: the dual ratio limits the step)
         tdst[3] = tr_pr > tr_res ? -tr_sr : tr_sr;                                     // (negative: the primal residual is the larger one)
       }
