@@ -16,7 +16,12 @@ def main():
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     root = os.path.join(here, "gpurun_out", tag)
     acc = {}
+    newest = {}   # gpurun's merge keeps the files of earlier runs: the newest CSV of every pass counts
     for path in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+        group = os.path.relpath(path, root).split(os.sep)[0]
+        if group not in newest or os.path.getmtime(path) > os.path.getmtime(newest[group]):
+            newest[group] = path
+    for path in newest.values():
         for row in csv.DictReader(open(path, newline="")):
             name = row["Kernel_Name"].split("(")[0].split("::")[-1]
             if not (name.startswith("ipm_") or name.startswith("single_")):
