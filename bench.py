@@ -450,6 +450,22 @@ def main():
                 t1 = time.perf_counter(); cst, _, ctl = call1(); lat_f.append(time.perf_counter() - t1)
             out["p50_find_traj_mem_ms"] = float(np.percentile(np.array(lat_f[5:]) * 1e3, 50))
             out["find_traj_mem_segments"] = None if ctl is None else int(len(ctl) // 12)
+            # ... and on one of the reference's own bundled corridor files (src/c_road_s1_3.txt: N = 71 knots, 3 obstacles,
+            # 8 segments; tests/golden/inputs holds the reference's data files) with its weights.txt
+            try:
+                from spectral_amd import knots as _kn
+                gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "inputs")
+                kbr = _kn.parse_corridor_file(os.path.join(gdir, "c_road_s1_3.txt"))
+                prr = native.CParams(*[float(v) for v in np.loadtxt(os.path.join(gdir, "weights.txt"))], 0)
+                callr = native.TrajCall(0, prr, kbr)
+                lat_r = []
+                for i in range(max(30, a.latency_reps // 2)):
+                    t1 = time.perf_counter(); cr, _, ctr = callr(); lat_r.append(time.perf_counter() - t1)
+                out["p50_find_traj_mem_c_road_s1_3_ms"] = float(np.percentile(np.array(lat_r[5:]) * 1e3, 50))
+                out["find_traj_mem_c_road_s1_3"] = {"segments": None if ctr is None else int(len(ctr) // 12), "cost": float(cr),
+                                                    "iterations": int(native.lib().btrapz_find_traj_last_iterations())}
+            except OSError:
+                pass
             # ... and exactly as the reference's harness calls it: corridor text file in, trajectory text file out
             # (trp_wrapper.py:45-66 -> find_traj(Params*)); the files live in a temporary directory
             import ctypes as _C, tempfile as _tf
