@@ -286,3 +286,41 @@ def test_lean_warm_start_on_ragged_batch(solver):
     w = o["ctrl"].cpu().numpy()
     assert (np.abs(w[ok] - ctrl_cold[ok]).max(axis=1) <= RTOL * np.abs(ctrl_cold[ok]).max(axis=1)).all()
     assert o["iters"].cpu().numpy()[ok].mean() <= it_cold[ok].mean() - 2.0
+
+
+@pytest.mark.parametrize("lean", [1, -1])
+def test_iteration_counts_of_the_round4_method(solver, lean):
+    """The corrector's weighted second-order term and the cold start (csrc/btrapz_ipm.h: second_order_factor,
+    BTRAPZ_COLD_SLACK / _LAMBDA) are what the bench line's iteration count rests on: 8.3 iterations on the scenario_1
+    batch (9.7 with the unweighted term and the (1, 1) start), 8.0 on the generic one (8.2), nothing beyond 30.  Both
+    forms; a change that loses this shows here, not only in the bench."""
+    for make, bound in ((lambda: synth.make_scenario1_batch(8192, 20, 0), 8.6), (lambda: synth.make_batch(8192, 20, config=3), 8.3)):
+        batch, sh = make()
+        r, form = run(solver, batch, sh, lean=lean, cap_iter=-1)
+        ok = r["status"] > 0
+        assert ok.mean() > 0.98
+        its = r["iters"][ok] + 1
+        assert its.mean() < bound and its.max() <= 32, (lean, float(its.mean()), int(its.max()))
+
+
+def test_candidates_without_a_solution_are_given_up_early(solver):
+    """The tiny-step rule (csrc/btrapz_ipm.h: BTRAPZ_TINY_STEP): a candidate whose corridor has no solution creeps on
+    with steps of 1e-5 -- three of them in a row end the solve.  Jittered copies of src/c_road_s1_3.txt, a quarter
+    infeasible: those end after 14 iterations on average (30 without the rule), none after more than 24; the solvable
+    ones are the oracle's (test_gpu_corridor_pipeline.py holds that)."""
+    import torch
+    from spectral_amd import knots
+    W = np.loadtxt(os.path.join(GOLD, "inputs", "weights.txt"))
+    kb = knots.jittered(knots.parse_corridor_file(os.path.join(GOLD, "inputs", "c_road_s1_3.txt")), 8192, seed=3)
+    sh = synth.shared_params(0, weights=W)
+    sh.ds_ref, sh.dl_ref = kb.header["ds_ref"], kb.header["dl_ref"]
+    sh.dds, sh.ddds, sh.ddl, sh.dddl = kb.header["dds"], kb.header["ddds"], kb.header["ddl"], kb.header["dddl"]
+    rec = solver.corridor_batch(kb, 0, seg_stride=24)
+    for lean in (1, -1):
+        o = solver.solve_ragged(rec, sh, lean=lean)
+        torch.cuda.synchronize()
+        st, its = o["status"].cpu().numpy(), o["iters"].cpu().numpy() + 1
+        bad = st == -2
+        assert 0.15 < bad.mean() < 0.35 and (st[~bad] > 0).all()
+        assert its[bad].mean() < 17 and its[bad].max() <= 24, (lean, float(its[bad].mean()), int(its[bad].max()))
+        assert its[~bad].mean() < 10
