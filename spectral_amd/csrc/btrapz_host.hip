@@ -123,7 +123,7 @@ struct btrapz_ctx {
   int *d_queue = nullptr;           // [2] candidate counters of the persistent launch (ipm_solve_queue_kernel)
   // capped solve (btrapz_options.cap_iter): iterates of the suspended axis problems, their slots and list keys
   double *d_susp_state = nullptr; size_t susp_state_doubles = 0;
-  int *d_susp_ints = nullptr; size_t susp_ints = 0;      // [1 count (+pad)] [2B slots] [2B keys]
+  int *d_susp_ints = nullptr; size_t susp_ints = 0;      // [count, 3 pad] [bucket tables 2 x 198] [2B keys] [2B slots]
   int resident_waves = 1024;        // wavefronts the device holds at one per SIMD
   int last_form = -1;               // btrapz_last_solve_form
   int *d_istage = nullptr; size_t istage_cap = 0;
@@ -292,10 +292,10 @@ BTRAPZ_EXPORT int btrapz_debug_axis_records(btrapz_ctx *c, int B, int *iters, in
 }
 // ... and the keys [2][B] the last capped solve's resume launch was bucketed by (0: the axis problem was not handed over)
 BTRAPZ_EXPORT int btrapz_debug_resume_keys(btrapz_ctx *c, int B, int *keys) {
-  if (!c || B < 1 || !keys || c->susp_ints < 4 + 4 * (size_t)B) return BTRAPZ_EINVAL;
+  if (!c || B < 1 || !keys || c->susp_ints < 400 + 4 * (size_t)B) return BTRAPZ_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
-  HIPCHK(c, hipMemcpy(keys, c->d_susp_ints + 4 + 2 * (size_t)B, sizeof(int) * 2 * B, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(keys, c->d_susp_ints + 400, sizeof(int) * 2 * B, hipMemcpyDeviceToHost));
   return BTRAPZ_OK;
 }
 
@@ -474,7 +474,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       const size_t slots_max = (size_t)BTRAPZ_SUSP_BYTES_MAX / (sizeof(double) * 74 * (size_t)S);
       if (slots > slots_max) slots = slots_max;
       if (slots > (size_t)0x7fffffff) slots = (size_t)0x7fffffff;   // (susp_cap is an int)
-      const size_t need_state = slots * 74 * (size_t)S, need_ints = 4 + 4 * (size_t)B;
+      const size_t need_state = slots * 74 * (size_t)S, need_ints = 400 + 4 * (size_t)B;   // count[4] tables[2][198] keys[2][B] slots[2B]
       bool ok = slots >= 64;
       if (ok && need_state > c->susp_state_doubles) {
         (void)hipFree(c->d_susp_state); c->d_susp_state = nullptr; c->susp_state_doubles = 0;
@@ -499,10 +499,9 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       capped_ws = ok;
     }
     if (capped && capped_ws) {
-      int *count = c->d_susp_ints, *slot_of = c->d_susp_ints + 4, *keys = slot_of + 2 * (size_t)B;
-      HIPCHK(c, hipMemsetAsync(count, 0, sizeof(int) * 4, stream));
-      HIPCHK(c, hipMemsetAsync(keys, 0, sizeof(int) * 2 * (size_t)B, stream));
-      HIPCHK(c, hipMemsetAsync(c->d_rescue_meta, 0, sizeof(int) * 2 * 198, stream));
+      // (one workspace, one memset: the counter, the bucket tables of both axes and the keys are zeroed together)
+      int *count = c->d_susp_ints, *tables = count + 4, *keys = tables + 2 * 198, *slot_of = keys + 2 * (size_t)B;
+      HIPCHK(c, hipMemsetAsync(count, 0, sizeof(int) * (400 + 2 * (size_t)B), stream));
       KernelArgs p1 = a;
       p1.cap_iter = cap_iter; p1.cap_alone = BTRAPZ_CAP_ALONE; p1.cap_hi = cap_iter + BTRAPZ_CAP_HI; p1.cap_score = BTRAPZ_CAP_SCORE; p1.susp_cap = (int)slots; p1.susp_state = c->d_susp_state; p1.susp_count = count;
       p1.susp_slot = slot_of; p1.susp_key = keys;
@@ -516,16 +515,13 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       int *lists = c->d_rescue + 2 * (size_t)B;
       const unsigned nb = (unsigned)((B + 255) / 256);
       const int list_S = ragged ? 0 : -S;   // ragged: keys are segment counts; uniform: convergence classes, 0 = not listed
-      for (int ax = 0; ax < 2; ax++) {
-        int *meta = c->d_rescue_meta + ax * 198;
-        const int *k = keys + (size_t)ax * B;
-        hipLaunchKernelGGL(bucket_hist_kernel, dim3(nb), dim3(256), 0, stream, B, S, k, meta, list_S);
-        hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(64), 0, stream, meta, list_S);
-        hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nb), dim3(256), 0, stream, B, S, k, meta, lists + (size_t)ax * B,
-                           (double *)nullptr, (int *)nullptr, (int *)nullptr, list_S);
-      }
+      // both axes in one launch each (gridDim.y = 2: keys [2][B], tables [2][198], lists [2][B])
+      hipLaunchKernelGGL(bucket_hist_kernel, dim3(nb, 2), dim3(256), 0, stream, B, S, (const int *)keys, tables, list_S);
+      hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1, 2), dim3(64), 0, stream, tables, list_S);
+      hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nb, 2), dim3(256), 0, stream, B, S, (const int *)keys, tables, lists,
+                         (double *)nullptr, (int *)nullptr, (int *)nullptr, list_S);
       KernelArgs p2 = p1;
-      p2.cap_iter = 0; p2.order = lists; p2.seg_count = nullptr; p2.cand_prefix = c->d_rescue_meta; p2.wave_prefix = c->d_rescue_meta + 66;
+      p2.cap_iter = 0; p2.order = lists; p2.seg_count = nullptr; p2.cand_prefix = tables; p2.wave_prefix = tables + 66;
       p2.bucket_S = ragged ? 0 : S;
       // (ragged: no candidate has more than min(S, 64) segments, so no wavefront holds fewer groups than that allows)
       const unsigned rblocks = 2u * (unsigned)(slots / (size_t)(64 / (S < 64 ? S : 64)) + 65);

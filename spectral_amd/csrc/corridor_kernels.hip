@@ -581,7 +581,9 @@ __device__ __forceinline__ int hint_class(int v) { return v < 1 ? 1 : (v > 64 ? 
 __device__ __forceinline__ int bucket_key(int v, int fixed_S) {
   return fixed_S > 0 ? hint_class(v) : fixed_S < 0 ? (v < 1 ? 0 : hint_class(v)) : v;
 }
+// (A launch with gridDim.y = 2 builds the lists of both axes at once: keys [2][B], tables [2][198], lists [2][B].)
 __global__ void bucket_hist_kernel(int B, int seg_stride, const int *seg_count, int *meta, int fixed_S) {
+  seg_count += (size_t)blockIdx.y * B; meta += blockIdx.y * 198;
   __shared__ int h[65];
   for (int j = threadIdx.x; j < 65; j += blockDim.x) h[j] = 0;
   __syncthreads();
@@ -597,6 +599,7 @@ __global__ void bucket_hist_kernel(int B, int seg_stride, const int *seg_count, 
 // launched first, so the longest-running wavefronts do not start at the tail of the launch.
 __global__ void bucket_prefix_kernel(int *meta, int fixed_S) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  meta += blockIdx.y * 198;
   int cand = 0, wave = 0;
   meta[0] = 0; meta[66] = 0;
   for (int j = 1; j <= 64; j++) {
@@ -615,6 +618,7 @@ __global__ void bucket_prefix_kernel(int *meta, int fixed_S) {
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(int B, int seg_stride, const int *seg_count, int *meta,
                                                              int *order, double *axis_obj, int *axis_status,
                                                              int *axis_iters, int fixed_S) {
+  seg_count += (size_t)blockIdx.y * B; meta += blockIdx.y * 198; order += (size_t)blockIdx.y * B;
   __shared__ int wcount[4][65], base[65];
   for (int j = threadIdx.x; j < 4 * 65; j += blockDim.x) (&wcount[0][0])[j] = 0;
   __syncthreads();
