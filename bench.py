@@ -36,12 +36,12 @@ FLOPS_PER_SEGMENT_ITER = 1700.0
 # of ALL of these kernels; the rocprofv3 averages of the named ones add up to it.
 SOLVE_FORMS = {0: "btrapz::ipm_solve_kernel", 1: "btrapz::ipm_solve_split_kernel", 2: "btrapz::ipm_solve_long_kernel",
                3: "btrapz::ipm_solve_capped_kernel + btrapz::ipm_solve_resume_kernel (one solve = two launches: every candidate stops when "
-                  "left alone in its wavefront after 6 iterations, the second launch carries those on; + 6 bucketing launches of ~5 us)",
+                  "left alone in its wavefront after 6 iterations, the second launch carries those on; + 3 bucketing launches of 5-11 us)",
                4: "btrapz::ipm_solve_queue_kernel",
                8: "btrapz::ipm_solve_lean_kernel (two wavefronts per SIMD)",
                11: "btrapz::ipm_solve_lean_capped_kernel + btrapz::ipm_solve_lean_resume_kernel (two wavefronts per SIMD; one solve = two launches: "
-                   "every candidate stops when left alone in its wavefront after 6 iterations, the second launch carries those on; + 6 bucketing "
-                   "launches of ~5 us)"}
+                   "every candidate stops when left alone in its wavefront after 6 iterations, the second launch carries those on; + 3 bucketing "
+                   "launches of 5-11 us)"}
 
 
 def parse():
@@ -319,11 +319,11 @@ def main():
                          "algorithmic_bytes_per_solve": batch.algorithmic_bytes(),
                          "note": "on-chip solve: the binding resource is FP64 VALU issue + dependent sweeps, not HBM "
                                  "(SURVEY 8d); see fp64_valu" + ("; traffic above the algorithmic bytes is the iterate of the candidates the "
-                                 "first launch hands to the second (74 doubles per segment, written once and read once, for the ~11 % of "
+                                 "first launch hands to the second (69-74 doubles per segment, written once and read once, for the ~9 % of "
                                  "the axis problems that are handed over) and their records read a second time: not re-reads of a "
                                  "working set" if solve_form in (3, 11) else "") +
-                                 ("; the two-wavefronts-per-SIMD form also spills 17-27 doubles of read-mostly problem data per lane to "
-                                  "scratch (written once per solve at set-up, ~0.7 GB per launch pair, re-read from L2): DESIGN 3.3" if solve_form in (8, 11) else ""),
+                                 ("; the two-wavefronts-per-SIMD form also spills ~13 doubles of read-only problem data per lane to "
+                                  "scratch (written once per solve at set-up, ~0.35 GB per launch pair, re-read from L2): DESIGN 3.3" if solve_form in (8, 11) else ""),
                          "fp64_valu": {"achieved_tflops": flops / (kernel_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                                        "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                        "model": "%.0f useful flops per segment per iteration x %.2f mean iterations" %
