@@ -9,6 +9,8 @@
 #include <cstring>
 #include <string>
 
+#include <cstddef>
+#include <type_traits>
 #include "btrapz_device.h"
 #include "prism_core.h"
 
@@ -90,6 +92,13 @@ static inline const char *experiment_env(const char *name) {
 #endif
 #define BTRAPZ_SUSP_PERCENT 25
 #define BTRAPZ_SUSP_BYTES_MAX (1ull << 30)
+
+// Layout the lean kernels rely on (btrapz_lean_body.h reads the row limits of its axis as (&sh.acc_s[0])[2 axis + i],
+// (&sh.acc_s[0])[4 + 2 axis + i], and its arguments through the kernarg segment pointer: KernelArgs is the first parameter).
+static_assert(offsetof(btrapz::Shared, acc_l) == offsetof(btrapz::Shared, acc_s) + 2 * sizeof(double) &&
+              offsetof(btrapz::Shared, jerk_s) == offsetof(btrapz::Shared, acc_s) + 4 * sizeof(double) &&
+              offsetof(btrapz::Shared, jerk_l) == offsetof(btrapz::Shared, acc_s) + 6 * sizeof(double), "Shared: acc_s, acc_l, jerk_s, jerk_l contiguous");
+static_assert(std::is_trivially_copyable<btrapz::KernelArgs>::value && alignof(btrapz::KernelArgs) <= 8, "KernelArgs is passed by value at kernarg offset 0");
 
 struct btrapz_ctx {
   int device = 0;
