@@ -351,6 +351,10 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   const double *s = &out[0], *ds = &out[(size_t)max_points], *dds = &out[(size_t)2 * max_points];
   const double *l = &out[(size_t)3 * max_points], *dl = &out[(size_t)4 * max_points], *ddl = &out[(size_t)5 * max_points];
   const double cost = trajectory_cost(variant, *p, in, max_points, s, ds, dds, l, dl, ddl);
+  // A trajectory that is not finite is no trajectory (the reference refuses a solve whose objective is NaN,
+  // solve_3d.cc:1251-1253): a corridor with infinite bounds assembles to rows and an objective of inf / NaN, and the solve
+  // of such a problem may still end with a small score.  (Fuzzed: tests/fuzz/find_traj_vs_oracle.py, seeds 911 / 914.)
+  if (!std::isfinite(cost) || !std::isfinite(h_cost)) { t_last.status = BTRAPZ_MAX_ITER_REACHED; return FAIL; }
 
   res.S = S; res.np = max_points; res.out = std::move(out);
   res.ctrl.assign(h_out + 3, h_out + 3 + 12 * S);

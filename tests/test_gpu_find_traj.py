@@ -292,3 +292,27 @@ def test_inputs_the_round3_fuzz_campaign_found(case, variant, tol):
         assert cost < 1e10 and len(ctrl) == 12 * n, (case, split)
         assert native.find_traj_last_status()[0] in (1, 2), (case, split, native.find_traj_last_status())
         assert np.abs(ctrl - x).max() <= tol * np.abs(x).max(), (case, split, np.abs(ctrl - x).max() / np.abs(x).max())
+
+
+@pytest.mark.parametrize("case", ["s911_it1229_v0", "s914_it392_v0"])
+def test_corridors_with_infinite_bounds_are_refused(case):
+    """Two inputs of round 4's second fuzz campaign (tests/fuzz/cases/): three knots, one `inf` among the s bounds.  The
+    corridor assembles to rows and an objective of inf / NaN; the relaxed problem of the rescue pass can still end with a
+    small score, and until then find_traj returned NaN as the cost of an "accepted" trajectory.  A trajectory that is not
+    finite is refused (the reference refuses a solve whose objective is NaN, solve_3d.cc:1251-1253); so does the oracle's
+    exact solver.  (OSQP itself takes an infinite bound as no bound: the oracle's OSQP port returns a trajectory here --
+    one of the "port only" decisions the fuzz campaigns tally)  With and without the rescue pass, both
+    forms of the single-candidate kernel."""
+    from spectral_amd import knots
+    w = np.loadtxt(os.path.join(GOLD, "inputs", "weights.txt"))
+    path = os.path.join(os.path.dirname(__file__), "fuzz", "cases", case + ".txt")
+    params = native.CParams(*[float(v) for v in w], 3)
+    kb = knots.parse_corridor_file(path)
+    for split in ("1", "0"):
+        for elastic in ("1", "0"):
+            os.environ["BTRAPZ_SPLIT"] = split; os.environ["BTRAPZ_ELASTIC"] = elastic
+            try:
+                cost, traj, ctrl = native.find_traj_mem(0, params, kb)
+            finally:
+                del os.environ["BTRAPZ_SPLIT"], os.environ["BTRAPZ_ELASTIC"]
+            assert cost == 1e11 and native.find_traj_last_status()[0] < 0, (case, split, elastic, cost)
