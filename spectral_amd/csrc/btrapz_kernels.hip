@@ -594,6 +594,9 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
             // within the caller's tolerance -> the reference's "solved inaccurate"; beyond it -> infeasible
             if (st > 0 && ro.b > 1e-7 * (1.0 + bnorm)) st = ro.c <= a.elastic_tol ? BTRAPZ_SOLVED_INACCURATE : BTRAPZ_PRIMAL_INFEASIBLE;
           }
+          // an objective that is not finite is no solution, whatever the score says (a corridor with an infinite bound
+          // assembles to rows of inf / NaN; the reference refuses a solve whose objective is NaN, solve_3d.cc:1251-1253)
+          if (st > 0 && !(fabs(ro.a) < 1e300)) st = BTRAPZ_MAX_ITER_REACHED;
           const long long prob = 2LL * b + axis;
           if constexpr (ELASTIC) {
             if (a.axis_viol) {   // per class of rows, in the rows' own units (0 where the rows hold)

@@ -1022,6 +1022,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         else if (best_score < 1e-7) st = BTRAPZ_SOLVED;
         else if (best_score < 1e-5 || (res_it < 0 && best_score < 1e-4)) st = BTRAPZ_SOLVED_INACCURATE;
         else st = BTRAPZ_MAX_ITER_REACHED;
+        if (st > 0 && !(fabs(ro.a) < 1e300)) st = BTRAPZ_MAX_ITER_REACHED;   // (an objective that is not finite: see the packed form)
         const long long prob = 2LL * b + axis;
         ka->axis_obj[prob] = ro.a;
         ka->axis_status[prob] = st;

@@ -324,3 +324,21 @@ def test_candidates_without_a_solution_are_given_up_early(solver):
         assert 0.15 < bad.mean() < 0.35 and (st[~bad] > 0).all()
         assert its[bad].mean() < 17 and its[bad].max() <= 24, (lean, float(its[bad].mean()), int(its[bad].max()))
         assert its[~bad].mean() < 10
+
+
+@pytest.mark.parametrize("lean", [1, -1])
+def test_a_candidate_with_an_infinite_bound_is_not_reported_solved(solver, lean):
+    """An `inf` among a candidate's bounds makes rows and objective inf / NaN; whatever its solve (or the rescue pass)
+    ends with, an objective that is not finite is never status 1 or 2 -- and the other candidates of the batch are
+    untouched.  (Found as find_traj calls by round 4's second fuzz campaign: tests/fuzz/cases/s911_it1229_v0.txt.)"""
+    from spectral_amd import layout as L
+    batch, sh = synth.make_batch(512, 10, config=2)
+    clean, _ = run(solver, batch, sh, lean=lean, cap_iter=-1, elastic=1)
+    bad = [3, 200, 511]
+    batch.seg[L.F_UPP_BIAS, bad[0], 2] = np.inf
+    batch.seg[L.F_DOWN_BIAS, bad[1], 0] = -np.inf
+    batch.seg[L.F_L_UPP_BIAS, bad[2], 9] = np.inf
+    r, form = run(solver, batch, sh, lean=lean, cap_iter=-1, elastic=1)
+    assert (r["status"][bad] <= 0).all() and not np.isfinite(r["cost"][bad]).any(), r["status"][bad]
+    ok = np.ones(512, bool); ok[bad] = False
+    assert np.array_equal(r["status"][ok], clean["status"][ok]) and np.array_equal(r["ctrl"][ok], clean["ctrl"][ok])
