@@ -354,7 +354,11 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   // A trajectory that is not finite is no trajectory (the reference refuses a solve whose objective is NaN,
   // solve_3d.cc:1251-1253): a corridor with infinite bounds assembles to rows and an objective of inf / NaN, and the solve
   // of such a problem may still end with a small score.  (Fuzzed: tests/fuzz/find_traj_vs_oracle.py, seeds 911 / 914.)
-  if (!std::isfinite(cost) || !std::isfinite(h_cost)) { t_last.status = BTRAPZ_MAX_ITER_REACHED; return FAIL; }
+  // (The trajectory and the objective decide, not a_cost: with a reference line that is not finite a_cost is NaN for a
+  //  perfectly good trajectory, and the reference returns that NaN -- trp_wrapper.cpp:217-286.)
+  bool finite = std::isfinite(h_cost);
+  for (size_t i = 0; finite && i < out.size(); i++) finite = std::isfinite(out[i]);
+  if (!finite) { t_last.status = BTRAPZ_MAX_ITER_REACHED; return FAIL; }
 
   res.S = S; res.np = max_points; res.out = std::move(out);
   res.ctrl.assign(h_out + 3, h_out + 3 + 12 * S);
