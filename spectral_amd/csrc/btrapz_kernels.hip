@@ -213,6 +213,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   float best_res = 3e38f;          // smallest residual part of the score so far and when (the stall test)
   int res_it = 0;
   bool plain = false;              // second chance of a solve whose complementarity is stuck: see the corrector
+  [[maybe_unused]] bool lone_start = false;   // capped launch: the group was the only live one of its wavefront at the first iteration
   // btrapz_options.start = 1: before the first iteration one Newton step of the UNCONSTRAINED problem (all row weights
   // zero: the block system is Phi' P Phi, its solution the optimum without the inequality rows), slacks re-initialised
   // there.  The pass is the loop body up to the predictor's sweep; it is not counted as an iteration.
@@ -791,7 +792,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // wavefront would run at a third of its width for it), and any group still iterating cap_hi iterations in (a long
       // runner belongs at the front of a launch, not wherever the batch order put it).
       const int nact = __popcll(__ballot(first && lane_in_group && valid && !done));
-      const bool want = !done && !unc_pass && valid && ((eit >= a.cap_iter && nact <= a.cap_alone && score >= a.cap_score) || eit >= a.cap_hi);
+      if (eit == 0) lone_start = nact <= a.cap_alone;   // (alone from the start: hands over after its first iteration, see the lean form)
+      const bool want = !done && !unc_pass && valid && ((eit >= (lone_start ? 1 : a.cap_iter) && nact <= a.cap_alone && score >= a.cap_score) || eit >= a.cap_hi);
       if (__any(want)) {
         UNIFORM_BLOCK;
         wave_lds_sync();
