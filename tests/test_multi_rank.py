@@ -189,14 +189,23 @@ def _launch(env_extra, timeout):
     return p, time.time() - t0
 
 
-def test_a_failing_rank_ends_the_launch():
+def _rank_reports(d):
+    return {f: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d))}
+
+
+def test_a_failing_rank_ends_the_launch(tmp_path):
     """First-contact hardening: process groups are created with a finite timeout
     (spectral_amd.dist.init_process_group); a rank that dies before its first collective makes the launcher return
     non-zero -- it ends the rank that is waiting in the all-gather -- instead of hanging.  The healthy launch of the same
     worker returns 0 and both ranks agree on the winner."""
-    ok, _ = _launch({"FAIL_RANK": "-1"}, 240)
+    good_dir, bad_dir = tmp_path / "good", tmp_path / "bad"
+    good_dir.mkdir(); bad_dir.mkdir()
+    ok, _ = _launch({"FAIL_RANK": "-1", "RESULT_DIR": str(good_dir)}, 240)
     assert ok.returncode == 0, ok.stderr[-1500:]
-    assert "rank 0 winner 0" in ok.stdout and "rank 1 winner 0" in ok.stdout
-    bad, dt = _launch({"FAIL_RANK": "1", "COLLECTIVE_TIMEOUT_S": "20"}, 240)
+    # each rank reports into its own file (the shared stdout pipe interleaves the ranks' writes: ADVICE r4)
+    assert _rank_reports(str(good_dir)) == {"rank0.txt": "rank 0 winner 0\n", "rank1.txt": "rank 1 winner 0\n"}
+    bad, dt = _launch({"FAIL_RANK": "1", "COLLECTIVE_TIMEOUT_S": "20", "RESULT_DIR": str(bad_dir)}, 240)
     assert bad.returncode != 0 and dt < 120, (bad.returncode, dt)
-    assert "fails before its first collective" in bad.stderr
+    reports = _rank_reports(str(bad_dir))
+    assert reports.get("rank1.txt") == "rank 1 fails before its first collective\n"
+    assert "rank0.txt" not in reports            # rank 0 never got a winner: it was ended inside the all-gather
