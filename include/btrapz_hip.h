@@ -67,7 +67,9 @@ double btrapz_find_traj(int variant, const char *input_path, const char *output_
  *   ctrl [12*BTRAPZ_MAX_SEGMENTS] (may be NULL): control points, s axis (6 S) then l axis (6 S); *n_segments receives
  *                  S.  A horizon of more than 64 segments (solved since round 3, up to BTRAPZ_MAX_SEGMENTS_LONG) does
  *                  not fit this buffer: the first 12*64 values are written, S is reported, and the caller that wants
- *                  them all calls btrapz_find_traj_mem_cap with a buffer of 12 S (ctrl_cap: its size in doubles). */
+ *                  them all calls btrapz_find_traj_mem_cap with a buffer of 12 S (ctrl_cap: its size in doubles).
+ *                  CHECK *n_segments: 12 * S above the buffer's size means the block is truncated.  A call that passes
+ *                  ctrl but no n_segments cannot notice, so it FAILS (1e11) when the block does not fit. */
 typedef struct btrapz_traj_input {
   int N, num_obs;
   double delta;
@@ -295,6 +297,78 @@ int btrapz_argmin_device(btrapz_ctx *ctx, int B, int group, long long index_base
  * Device pointers.  (spectral_amd/dist.py packs, gathers and calls this.) */
 int btrapz_argmin_pairs_device(btrapz_ctx *ctx, int world, int n, const long long *pairs, double *best_cost,
                                long long *best_idx, void *stream);
+
+/* ---- the multi-GPU step (one host process, G devices) ------------------------------------------------------------
+ * north_star: "batches of candidate corridors shard embarrassingly across the 8 GPUs of one node with RCCL over xGMI
+ * only for the final arg-min reduction", the host staying C++ over this C-ABI.  The reference has no counterpart: one
+ * corridor per call inside a single-process replanning loop (src/cart_frenet.py:1516-1571, src/solve_3d.cc:1231-1414).
+ *
+ * A btrapz_multi owns, per entry of `devices`, a context, a stream and the buffers of that device's shard.  A step
+ * (btrapz_multi_solve_argmin) is, per device and all asynchronous: solve the shard (btrapz_solve_batch_device), arg-min
+ * over it (btrapz_argmin_device), pack the local winner's record -- (cost bits, global index, 12 S control points):
+ * 16 + 96 S bytes -- then ONE all-gather of the G records and the same deterministic lexicographic min (cost, then the
+ * lowest global index: the order of btrapz_argmin_pairs_device) on every device: each ends with the global winner's
+ * index, cost and control points.  No other data crosses devices.
+ *   transport   BTRAPZ_MULTI_RCCL: ncclAllGather inside ncclGroupStart / ncclGroupEnd, communicators from
+ *               ncclCommInitAll; librccl.so is resolved at run time (dlopen, next to the HIP runtime the process runs
+ *               on; BTRAPZ_RCCL_LIB overrides) -- the library has no link dependency on it;
+ *               BTRAPZ_MULTI_COPIES: stream-ordered peer copies (hipMemcpyPeerAsync), the fallback without RCCL;
+ *               BTRAPZ_MULTI_AUTO: RCCL when it can be had, else copies (btrapz_multi_last_error says why).
+ *   logical devices: an ordinal may repeat in `devices` -- every entry still gets its own context, stream, buffers and
+ *               shard, so the whole path runs on a box with one GPU (transport: copies).
+ * Shards are contiguous, ceil(B / G) candidates per device (spectral_amd/dist.py::shard_bounds; trailing devices may be
+ * short or empty).  With group > 0 (B % group == 0, BASELINE config 5: `group` candidates per ego agent) a shard is a
+ * whole number of arg-min groups, every group's winner is found on its own device and there is NO collective.
+ * Results do not depend on G as long as the form of the solve kernel does not (automatic selection goes by the shard's
+ * size: pin btrapz_options.lean / split / cap_iter to compare across G bit for bit).
+ * Not thread-safe; one step at a time per handle. */
+typedef struct btrapz_multi btrapz_multi;
+enum { BTRAPZ_MULTI_AUTO = 0, BTRAPZ_MULTI_COPIES = 1, BTRAPZ_MULTI_RCCL = 2 };
+int btrapz_multi_create(btrapz_multi **m, const int *devices, int G, int transport);
+int btrapz_multi_destroy(btrapz_multi *m);
+const char *btrapz_multi_last_error(const btrapz_multi *m);
+int btrapz_multi_transport(const btrapz_multi *m);               /* BTRAPZ_MULTI_COPIES or BTRAPZ_MULTI_RCCL */
+const char *btrapz_multi_transport_library(const btrapz_multi *m); /* the librccl.so in use ("" for copies) */
+int btrapz_multi_device_count(const btrapz_multi *m);
+/* [lo, hi) of device slot g (0 <= g < G) for B candidates; group as above (0: one arg-min group over the whole batch). */
+int btrapz_multi_shard_bounds(int B, int G, int g, int group, int *lo, int *hi);
+
+/* The batch, from HOST arrays of the whole batch (layout of btrapz_solve_batch_device): every device receives its shard
+ * and keeps it resident until the next upload.  Synchronous (the host arrays may be released on return). */
+int btrapz_multi_upload(btrapz_multi *m, int B, int S, int group, const double *seg, const double *init,
+                        const double *ref_end, const double *dl_bounds);
+/* ... or shards that are on the devices already (e.g. written there by btrapz_corridor_batch_device): shards [G], in
+ * device-slot order, contiguous in the global index, pointers valid on that slot's device (layout of
+ * btrapz_solve_batch_device with B = the shard's size).  The arrays stay the caller's. */
+typedef struct btrapz_multi_shard {
+  int B;                 /* candidates of this shard (0: none) */
+  long long index_base;  /* global index of its first candidate */
+  const double *seg, *init, *ref_end, *dl_bounds;
+} btrapz_multi_shard;
+int btrapz_multi_set_shards(btrapz_multi *m, int B, int S, int group, const btrapz_multi_shard *shards);
+
+/* One step over the current batch: returns when everything is enqueued. */
+int btrapz_multi_solve_argmin(btrapz_multi *m, const btrapz_shared *shared, const btrapz_options *opt);
+/* Waits for the step and copies the winner(s) to the host.  One arg-min group (group = 0): best_idx [1], best_cost [1],
+ * best_ctrl [12 S] (NaN when no candidate was solved: best_idx -1, best_cost +inf), read from device slot `device_slot`
+ * after waiting for that device only, or from slot 0 after waiting for all (-1).  group > 0: the winners of all B / group
+ * groups in group order.  Any output pointer may be NULL. */
+int btrapz_multi_result(btrapz_multi *m, int device_slot, long long *best_idx, double *best_cost, double *best_ctrl);
+int btrapz_multi_wait(btrapz_multi *m);
+/* What lives on device slot g after a step (device pointers; valid until the next upload / set_shards / step). */
+typedef struct btrapz_multi_view {
+  int device, B;
+  long long index_base;
+  void *stream;               /* the slot's hipStream_t: order further work on this device behind the step */
+  btrapz_ctx *ctx;            /* the slot's context (sampling, state evaluation ... on its shard) */
+  double *ctrl, *cost;        /* [B][12 S], [B] of the shard */
+  int *status, *iters;
+  long long *best_idx;        /* the global winner (group = 0: [1], the same on every device) or the shard's winners */
+  double *best_cost, *best_ctrl;
+} btrapz_multi_view;
+int btrapz_multi_shard_view(btrapz_multi *m, int device_slot, btrapz_multi_view *view);
+/* The whole batch's results to HOST arrays ctrl [B][12 S], cost [B], status [B], iters [B] (any may be NULL): tests. */
+int btrapz_multi_download(btrapz_multi *m, double *ctrl, double *cost, int *status, int *iters);
 
 /* Bernstein sampling (solve_3d.cc:1279-1392) of nsel selected candidates on device.
  *   sel [nsel] candidate indices; t taken from seg; out [nsel][6][max_points]

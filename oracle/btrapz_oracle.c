@@ -1363,6 +1363,7 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
   for (int j = 0; j < n; j++) for (orc_int p = qp->P_p[j]; p < qp->P_p[j + 1]; p++) { int i = (int)qp->P_i[p]; Pd[(size_t)i * n + j] = qp->P_x[p]; Pd[(size_t)j * n + i] = qp->P_x[p]; }
   int Nk = n + me;
   double *K = (double *)malloc(sizeof(double) * (size_t)Nk * Nk); int *piv = (int *)malloc(sizeof(int) * Nk);
+  double *K0 = (double *)malloc(sizeof(double) * (size_t)Nk * Nk), *rhs0 = (double *)malloc(sizeof(double) * Nk), *rres = (double *)malloc(sizeof(double) * Nk), *dsc = (double *)malloc(sizeof(double) * Nk);
   double *x = (double *)calloc(n, sizeof(double)), *nu = (double *)calloc(me + 1, sizeof(double));
   double *sl = (double *)malloc(sizeof(double) * (mi + 1)), *su = (double *)malloc(sizeof(double) * (mi + 1));
   double *ll = (double *)malloc(sizeof(double) * (mi + 1)), *lu_ = (double *)malloc(sizeof(double) * (mi + 1));
@@ -1377,7 +1378,8 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
   double qn = vnorm_inf(qp->q, n), bn = 0;
   for (int i = 0; i < m; i++) { bn = fmax(bn, fabs(qp->l[i])); bn = fmax(bn, fabs(qp->u[i])); }
   for (int i = 0; i < m; i++) if (!iseq[i]) { int r = rowpos[i]; sl[r] = fmax(0.0 - qp->l[i], 1.0); su[r] = fmax(qp->u[i] - 0.0, 1.0); ll[r] = 1.0; lu_[r] = 1.0; }
-  int best_it = 0;
+  int best_it = 0, safe = 0;
+  double score_hist[4] = {1e300, 1e300, 1e300, 1e300};
   for (iter = 0; iter < max_iter; iter++) {
     for (int i = 0; i < m; i++) { double s = 0; const double *a = Ad + (size_t)i * n; for (int j = 0; j < n; j++) s += a[j] * x[j]; Ax[i] = s; }
     for (int j = 0; j < n; j++) { double s = qp->q[j]; const double *pr = Pd + (size_t)j * n; for (int k = 0; k < n; k++) s += pr[k] * x[k]; rd[j] = s; }
@@ -1421,11 +1423,33 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
         for (int j = 0; j < n; j++) if (a[j] != 0) { double f = We * a[j]; for (int k = 0; k < n; k++) if (a[k] != 0) K[(size_t)j * Nk + k] += f * a[k]; }
       }
     }
+    /* Symmetric equilibration D K D before the factorisation: unit diagonal in the Hessian block, unit largest entry in
+     * every equality row.  Partial pivoting compares magnitudes across rows, and rows weighted by lambda / s = 1e15 next
+     * to equality rows of size one make it pick badly (same finding as the refinement below). */
+    for (int i = 0; i < n; i++) { const double d = K[(size_t)i * Nk + i]; dsc[i] = d > 0 ? 1.0 / sqrt(d) : 1.0; }
+    for (int r = 0; r < me; r++) {
+      double mx = 0; const double *kr = K + (size_t)(n + r) * Nk;
+      for (int j = 0; j < n; j++) mx = fmax(mx, fabs(kr[j]) * dsc[j]);
+      dsc[n + r] = mx > 0 ? 1.0 / mx : 1.0;
+    }
+    for (int i = 0; i < Nk; i++) { double *kr = K + (size_t)i * Nk; const double di = dsc[i]; for (int j = 0; j < Nk; j++) kr[j] *= di * dsc[j]; }
+    memcpy(K0, K, sizeof(double) * (size_t)Nk * Nk);   /* (for the refinement of the solves below) */
     if (lu_factor(K, piv, Nk) != 0) break;
+    /* Safeguard (round 5, found by the sweep over the reference's weight space): unsafeguarded Mehrotra steps can cycle --
+     * mu going round 2e-3, 1e-3, 2e-3, 6e-4 for ever with residuals at 1e-13 (seen on 4 of ~57 000 candidates under
+     * weight rows with a near-zero jerk weight or zero end weights; a cycle may still creep down in its fourth digit).
+     * Four iterations with less than a halving of the score switch the solve, for good, to plain centred path-following:
+     * no second-order term, sigma at least 0.2.  Linear but sure. */
+    /* (only where complementarity is all that is left -- residuals four digits below mu: a slow START, residuals and mu
+     *  falling together by 10 % per iteration as on src/c4.txt, is not a cycle and Mehrotra's steps get it going) */
+    if (fmax(vnorm_inf(rd, n) / (1 + qn), rpn / (1 + bn)) < 1e-4 * mu &&
+        iter >= 8 && score > 0.5 * score_hist[iter & 3]) safe = 1;   /* (less than a halving in four iterations) */
+    score_hist[iter & 3] = score;
     double sigma = 0, alpha = 1;
     for (int pass = 0; pass < 2; pass++) {
       for (int r = 0; r < mi; r++) {
         if (pass == 0) { rcl[r] = sl[r] * ll[r]; rcu[r] = su[r] * lu_[r]; }
+        else if (safe) { rcl[r] = sl[r] * ll[r] - sigma * mu; rcu[r] = su[r] * lu_[r] - sigma * mu; }
         else { rcl[r] = sl[r] * ll[r] - sigma * mu + dsl[r] * dll[r]; rcu[r] = su[r] * lu_[r] - sigma * mu + dsu[r] * dlu[r]; }
       }
       for (int j = 0; j < n; j++) rhs[j] = -rd[j];
@@ -1438,7 +1462,23 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
           const double *a = Ad + (size_t)i * n; for (int j = 0; j < n; j++) if (a[j] != 0) rhs[j] -= a[j] * t;
         }
       }
+      /* Solve with two steps of iterative refinement, residuals in long double: near the end the weights lambda / s span
+       * twenty orders of magnitude and a plain LU solve of the indefinite system loses the dual residual altogether (found
+       * by the round-5 sweep over the reference's weight space: src/c2.txt, cuboid, trial rows 5 and 36 of all_weights.txt
+       * -- the dual residual went from 4e-8 to 1e+11 within five iterations at mu = 1e-5). */
+      for (int i = 0; i < Nk; i++) rhs[i] *= dsc[i];
+      memcpy(rhs0, rhs, sizeof(double) * Nk);
       lu_solve(K, piv, rhs, Nk);
+      for (int refine = 0; refine < 2; refine++) {
+        for (int i = 0; i < Nk; i++) {
+          long double acc = rhs0[i]; const double *kr = K0 + (size_t)i * Nk;
+          for (int j = 0; j < Nk; j++) acc -= (long double)kr[j] * rhs[j];
+          rres[i] = (double)acc;
+        }
+        lu_solve(K, piv, rres, Nk);
+        for (int i = 0; i < Nk; i++) rhs[i] += rres[i];
+      }
+      for (int i = 0; i < Nk; i++) rhs[i] *= dsc[i];
       for (int i = 0; i < m; i++) { double s = 0; const double *a = Ad + (size_t)i * n; for (int j = 0; j < n; j++) s += a[j] * rhs[j]; Adx[i] = s; }
       double ap = 1, ad = 1;
       for (int i = 0; i < m; i++) if (!iseq[i]) {
@@ -1456,10 +1496,12 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
         for (int r = 0; r < mi; r++) mua += (sl[r] + ap * dsl[r]) * (ll[r] + ad * dll[r]) + (su[r] + ap * dsu[r]) * (lu_[r] + ad * dlu[r]);
         mua = mi ? mua / (2.0 * mi) : 0;
         sigma = mu > 0 ? pow(mua / mu, 3) : 0;
+        if (safe) sigma = fmax(sigma, 0.2);
       } else {
         alpha = fmin(1.0, 0.995 * fmin(ap, ad));
       }
     }
+    if (getenv("ORC_TRACE")) fprintf(stderr, "orc trace        step: safe %d sigma %.3e alpha %.6f\n", safe, sigma, alpha);
     for (int j = 0; j < n; j++) x[j] += alpha * rhs[j];
     for (int r = 0; r < me; r++) nu[r] += alpha * rhs[n + r];
     for (int r = 0; r < mi; r++) { sl[r] += alpha * dsl[r]; su[r] += alpha * dsu[r]; ll[r] += alpha * dll[r]; lu_[r] += alpha * dlu[r]; }
@@ -1468,6 +1510,7 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
   if (y_out) memcpy(y_out, by, sizeof(double) * m);
   status = best_score < 1e-7 ? 1 : (best_score < 1e-5 ? 2 : -2);
   for (int j = 0; j < n; j++) { double s = 0; const double *pr = Pd + (size_t)j * n; for (int k = 0; k < n; k++) s += pr[k] * bx[k]; obj += 0.5 * bx[j] * s + qp->q[j] * bx[j]; }
+  free(K0); free(rhs0); free(rres); free(dsc);
   free(Ad); free(Pd); free(K); free(piv); free(x); free(nu); free(sl); free(su); free(ll); free(lu_); free(Ax); free(rd);
   free(rpl); free(rpu); free(re); free(W); free(rhs); free(dsl); free(dsu); free(dll); free(dlu); free(rcl); free(rcu); free(Adx); free(tt); free(bx); free(by);
   }

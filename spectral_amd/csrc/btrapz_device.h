@@ -7,6 +7,14 @@
 // The library is built with -fvisibility=hidden: only the C-ABI of include/btrapz_hip.h is exported.
 #define BTRAPZ_EXPORT extern "C" __attribute__((visibility("default")))
 
+// Bounds that are no bounds (btrapz_ipm.h, "bounds that are no bounds"): a finite bound of at least BTRAPZ_FAR in
+// magnitude can never be active; the kernels move such row bounds to BTRAPZ_FAR_FACTOR (1 + the lane's largest real
+// bound), the host moves such header limits (acceleration, jerk) to +-BTRAPZ_FAR_LIMIT; neither enters |bounds|.
+#define BTRAPZ_FAR 1e9
+#define BTRAPZ_FAR_FACTOR 1048576.0
+#define BTRAPZ_FAR_LIMIT 1e6
+#define BTRAPZ_COLD_FAR 1e4
+
 namespace btrapz {
 
 // Device view of btrapz_shared: limits already in the form the rows use them.

@@ -17,8 +17,11 @@
 using namespace btrapz;
 
 // Environment overrides of btrapz_options for experiments (BTRAPZ_CAP, _QUEUE, _LEAN, _SPLIT, _START, _STALL_FACTOR: A/B
-// runs of tools/ without touching the caller).  Only in a -DBTRAPZ_EXPERIMENTS build: the shipped drop-in library takes
-// these choices from btrapz_options alone, so a stray variable in the harness's environment cannot change what it does.
+// runs of tools/ without touching the caller).  Only in a -DBTRAPZ_EXPERIMENTS build: in the shipped library this file
+// reads no environment variable at all -- the batched entry points and btrapz_launch_single take every choice from
+// btrapz_options.  (find_traj, whose only configuration channel IS the environment, translates its documented
+// variables -- BTRAPZ_EPS, _ELASTIC, _ELASTIC_TOL, _WARM, _SPLIT, _SPIN, _DEVICE, _INPUT, _OUTPUT_PREFIX, _VERBOSE --
+// into options in find_traj.hip; btrapz_multi.hip reads BTRAPZ_RCCL_LIB, a path.)
 static inline const char *experiment_env(const char *name) {
 #ifdef BTRAPZ_EXPERIMENTS
   return getenv(name);
@@ -220,10 +223,13 @@ static void fill_parameters(KernelArgs &a, const btrapz_shared *sh, const btrapz
   memcpy(a.sh.w_s, sh->w_s, sizeof(a.sh.w_s)); memcpy(a.sh.w_l, sh->w_l, sizeof(a.sh.w_l));
   a.sh.weight_end_s = sh->weight_end_s; a.sh.weight_end_l = sh->weight_end_l;
   a.sh.ds_ref = sh->ds_ref; a.sh.dl_ref = sh->dl_ref;
+  // a header limit left at the reference's default of +-1e10 (piecewise_jerk_problem.cc:9,25-35) is no limit: moved to
+  // +-BTRAPZ_FAR_LIMIT, where the kernels know it for one (an infinite or NaN limit stays a defect of the input)
+  auto limit = [](double v) { const double m = fabs(v); return (m >= BTRAPZ_FAR && m <= 1.7e308) ? copysign(BTRAPZ_FAR_LIMIT, v) : v; };
   a.sh.acc_s[0] = fmax(sh->dds[0], -1000.0); a.sh.acc_s[1] = fmin(sh->dds[1], 1000.0);  // solve_3d.cc:836,843-844
-  a.sh.acc_l[0] = sh->ddl[0]; a.sh.acc_l[1] = sh->ddl[1];
-  a.sh.jerk_s[0] = sh->ddds[0]; a.sh.jerk_s[1] = sh->ddds[1];
-  a.sh.jerk_l[0] = sh->dddl[0]; a.sh.jerk_l[1] = sh->dddl[1];
+  a.sh.acc_l[0] = limit(sh->ddl[0]); a.sh.acc_l[1] = limit(sh->ddl[1]);
+  a.sh.jerk_s[0] = limit(sh->ddds[0]); a.sh.jerk_s[1] = limit(sh->ddds[1]);
+  a.sh.jerk_l[0] = limit(sh->dddl[0]); a.sh.jerk_l[1] = limit(sh->dddl[1]);
   a.sh.variant = sh->variant;
   a.eps = (opt && opt->eps > 0) ? opt->eps : 1e-9;
   a.max_iter = (opt && opt->max_iter > 0) ? opt->max_iter : 60;
@@ -326,8 +332,7 @@ int btrapz_launch_single(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_op
   a.axis_obj = c->d_axis_obj; a.axis_status = c->d_axis_status; a.axis_iters = c->d_axis_iters;
   a.ctrl = c->d_single; a.queue = nullptr; a.x_out = nullptr; a.axis_viol = nullptr;
   // at most 21 segments: the split form (rows of a segment over three lanes), ~0.8 of the time per iteration
-  const char *split_e = getenv("BTRAPZ_SPLIT");   // (read per call: tests switch it)
-  const bool split_form = S <= 21 && !(split_e && *split_e == '0') && !(opt && opt->split < 0);
+  const bool split_form = S <= 21 && !(opt && opt->split < 0);   // (find_traj maps BTRAPZ_SPLIT onto opt->split)
   if (warm) {
     const size_t nx = 2 * 64 * 3, nl = 2 * 36 * 64, set = nx + nl;
     if (!c->d_single_warm) HIPCHK(c, hipMalloc(&c->d_single_warm, sizeof(double) * 2 * set));
@@ -468,7 +473,9 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     const bool lean_on = lean_ok && (lean_opt > 0 || (lean_opt == 0 && est_waves >= 3u * (unsigned)c->resident_waves));
     const bool ragged = seg_count != nullptr;
     const bool cap_requested = cap_iter > 0;   // (by the caller; the automatic choice below falls back to one launch when the workspace cannot be had)
-    if (cap_iter == 0 && !ragged && S >= 16 && blocks >= 8u * (unsigned)c->resident_waves) cap_iter = 6;
+    // (S <= 32: a wavefront that holds ONE group has nobody to wait for -- with 33..64 segments every group would be
+    //  "alone" at once and a quarter of the batch be written out and read back for nothing: ADVICE r4)
+    if (cap_iter == 0 && !ragged && S >= 16 && S <= 32 && blocks >= 8u * (unsigned)c->resident_waves) cap_iter = 6;
     const bool capped = cap_iter > 0 && !long_form && !split_on && (!a.order || ragged) && !warm_kernel && !queue_on && S <= BTRAPZ_MAX_SEGMENTS &&
                         cap_iter < a.max_iter && cap_iter + BTRAPZ_CAP_HI < 4000 && elastic != 2;   // (4000: the lean record's 12-bit counters)
     // Workspace of the two launches: hand-over slots for a quarter of the axis problems (a group that finds none simply

@@ -149,6 +149,43 @@ __device__ __forceinline__ void VT_apply(const NullMap m, double h3, double h4, 
 #define BTRAPZ_COLD_LAMBDA 6.0
 #endif
 
+// ---- bounds that are no bounds (round 5) ------------------------------------------------------------------------------
+// The reference's rows default to +-1e10 (src/piecewise_jerk_problem.cc:9,25-35) and a caller may leave them there: such
+// a row can never be active.  Taken literally it wrecks the solve twice over: a cold start with slack 1e10 and multiplier
+// 6 puts mu at 1e10 and the first centring step flings every other row after it (found by the round-5 sweep: a quarter
+// of the candidates of a batch with default dl bounds ended "stalled" after 4-9 iterations); and 1 / (1 + |bounds|)
+// scales the primal residual of every other row by 1e-10.  So:
+//   * a FINITE bound of magnitude >= BTRAPZ_FAR is moved to +-BTRAPZ_FAR_FACTOR (1 + the largest other bound of the
+//     lane's rows) when the record is read: 2^20 times further out than anything the problem's data says, still "never
+//     active", but near enough that (value + slack - bound) rounds at 1e-10 of the data's scale instead of at 1e-6;
+//     header limits (acceleration, jerk) beyond BTRAPZ_FAR are moved to +-BTRAPZ_FAR_LIMIT by the host;
+//   * such bounds do not enter |bounds|;
+//   * a cold start gives a row whose slack is above BTRAPZ_COLD_FAR the centred multiplier COLD_SLACK COLD_LAMBDA / s
+//     instead of COLD_LAMBDA (rows of ordinary size keep the start the bench batches were tuned on, bit for bit).
+// An INFINITE bound stays what it was: a defect of the input that ends in "no trajectory" (DESIGN section 6).
+// (BTRAPZ_FAR, _FAR_FACTOR, _FAR_LIMIT, _COLD_FAR: btrapz_device.h -- the host moves the header limits)
+__device__ __forceinline__ bool far_bound(double v) { const double a_ = fabs(v); return a_ >= BTRAPZ_FAR && a_ <= 1.7e308; }
+// largest |v| among bounds that are real ones
+__device__ __forceinline__ double near_norm(double acc, double v) { const double a_ = fabs(v); return a_ < BTRAPZ_FAR ? fmax(acc, a_) : acc; }
+__device__ __forceinline__ double cold_lambda(double slack, double slack0, double lambda0) {
+  return slack > BTRAPZ_COLD_FAR ? (slack0 * lambda0) * rcp_fast(slack) : lambda0;   // (a starting value: the seed will do)
+}
+// Position lines lo0 + i dlo (i = 0..5) and velocity intervals of a lane, far bounds moved in; returns the lane's `big`.
+__device__ __forceinline__ double move_far_bounds(double &plo0, double &dplo, double &phi0, double &dphi, double (&vlo)[5], double (&vhi)[5]) {
+  double fin = 0.0;
+  fin = near_norm(fin, plo0); fin = near_norm(fin, plo0 + 5.0 * dplo); fin = near_norm(fin, phi0); fin = near_norm(fin, phi0 + 5.0 * dphi);
+  UNROLL for (int i = 0; i < 5; i++) { fin = near_norm(fin, vlo[i]); fin = near_norm(fin, vhi[i]); }
+  const double big = BTRAPZ_FAR_FACTOR * (1.0 + fin);
+  const double plo5 = plo0 + 5.0 * dplo, phi5 = phi0 + 5.0 * dphi;
+  if (far_bound(plo0) || far_bound(plo5)) { plo0 = copysign(big, far_bound(plo0) ? plo0 : plo5); dplo = 0.0; }
+  if (far_bound(phi0) || far_bound(phi5)) { phi0 = copysign(big, far_bound(phi0) ? phi0 : phi5); dphi = 0.0; }
+  UNROLL for (int i = 0; i < 5; i++) {
+    if (far_bound(vlo[i])) vlo[i] = copysign(big, vlo[i]);
+    if (far_bound(vhi[i])) vhi[i] = copysign(big, vhi[i]);
+  }
+  return big;
+}
+
 // Factor of Mehrotra's second-order term ds_aff * dlambda_aff in the corrector's complementarity target (it enters through
 // a fused multiply-add that subtracts it: the factor is minus its weight).  The term describes the affine step; where
 // that step is cut short by a bound it describes less, and taking it in full then pushes the corrected step against the

@@ -214,6 +214,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
   int res_it = 0;
   bool plain = false;              // second chance of a solve whose complementarity is stuck: see the corrector
   [[maybe_unused]] bool lone_start = false;   // capped launch: the group was the only live one of its wavefront at the first iteration
+  [[maybe_unused]] bool slot_refused = false; // capped launch: the workspace had no hand-over slot left for this group
   // btrapz_options.start = 1: before the first iteration one Newton step of the UNCONSTRAINED problem (all row weights
   // zero: the block system is Phi' P Phi, its solution the optimum without the inequality rows), slacks re-initialised
   // there.  The pass is the loop body up to the predictor's sweep; it is not counted as an iteration.
@@ -257,12 +258,31 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
         sl5[i] = fmax(v5[i] - lo5[i], smin0); su5[i] = fmax(up5[i] - v5[i], smin0);
         ll5[i] = lam0; lu5[i] = lam0;
       }
+      // rows without a real bound (btrapz_ipm.h, "bounds that are no bounds"): the centred multiplier.  A pass of its own
+      // behind a wave-uniform branch that is all but never taken -- selects inside the loop above cost the warm-start
+      // instantiations, which call this from their restart path too, 36 B of scratch per lane.
+      bool far_row = false;
+      UNROLL for (int i = 0; i < 5; i++) far_row |= sl5[i] > BTRAPZ_COLD_FAR || su5[i] > BTRAPZ_COLD_FAR;
+      if (__any(far_row)) {
+        UNIFORM_BLOCK;
+        UNROLL for (int i = 0; i < 5; i++) { ll5[i] = cold_lambda(sl5[i], smin0, lam0); lu5[i] = cold_lambda(su5[i], smin0, lam0); }
+      }
     } else {
       FOR_ROWS(r)
         const double gc_r = row_dot<r>(c, t);
         sl[SI(r)] = fmax(gc_r - LO(r), smin0); su[SI(r)] = fmax(UP(r) - gc_r, smin0);
         LL(r) = lam0; LU(r) = lam0;
       END_ROWS
+      bool far_row = false;
+      FOR_ROWS(r)
+        far_row |= sl[SI(r)] > BTRAPZ_COLD_FAR || su[SI(r)] > BTRAPZ_COLD_FAR;
+      END_ROWS
+      if (__any(far_row)) {   // (as above)
+        UNIFORM_BLOCK;
+        FOR_ROWS(r)
+          LL(r) = cold_lambda(sl[SI(r)], smin0, lam0); LU(r) = cold_lambda(su[SI(r)], smin0, lam0);
+        END_ROWS
+      }
     }
   };
   auto cold_start = [&]() {
@@ -356,6 +376,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     // acceleration / jerk rows (solve_3d.cc:862-888, 1010-1037)
     alo = (axis == 0 ? sh.acc_s[0] : sh.acc_l[0]) * t; ahi = (axis == 0 ? sh.acc_s[1] : sh.acc_l[1]) * t;
     jlo = (axis == 0 ? sh.jerk_s[0] : sh.jerk_l[0]) * t * t; jhi = (axis == 0 ? sh.jerk_s[1] : sh.jerk_l[1]) * t * t;
+    const double far_cut = move_far_bounds(plo0, dplo, phi0, dphi, vlo, vhi);   // bounds that are none (btrapz_ipm.h)
     mplo = plo0 + 5.0 * dplo; mphi = phi0 + 5.0 * dphi; mvlo = vlo[4]; mvhi = vhi[4];
     bool joint_empty = false;
     if constexpr (!FULL) {
@@ -411,7 +432,10 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // upper bound exactly at a control point (0.4 + 0.5 * 0.6 against 0.7) gives l = 0.7000000000000004 >
       // u = 0.7000000000000001, an equality in all but the last bit (round-3 fuzz campaign: 1 call in 32 000 was refused
       // for it)
-      const double rb = fmax(fabs(LO0(r)), fabs(UP0(r)));
+      // |bounds|: the real ones (a moved bound sits at far_cut exactly; header limits at BTRAPZ_FAR_LIMIT x t, x t^2)
+      const double cut = r < 11 ? far_cut : r < 15 ? BTRAPZ_FAR_LIMIT * t : BTRAPZ_FAR_LIMIT * t * t;
+      const double al = fabs(LO0(r)), au = fabs(UP0(r));
+      const double rb = fmax(al < cut ? al : 0.0, au < cut ? au : 0.0);
       gapmin = fmin(gapmin, (UP0(r) - LO0(r)) + 1e-12);
       bnorm = fmax(bnorm, rb);
     });
@@ -730,7 +754,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     // relative to the bound scale, complementarity absolute.
     const double rd_eff = fmax(rr.b - 2e-13 * rr.d, 0.0);
     const double res = fmax(rd_eff / (1.0 + qn), rr.c / (1.0 + bnorm));
-    const double score = fmax(res, mu);
+    const double score = (mu == mu) ? fmax(res, mu) : 1e300;   // (fmax would drop a NaN mu: ADVICE r4)
     const double mu_primal = fmax(mu, rr.c / (1.0 + bnorm));
     const bool feasible_and_complementary = mu_primal < 1e-7;   // (only the dual residual is left: see the dual floor below)
 #ifdef BTRAPZ_TRACE   // debugging aid: one line per iteration and axis problem (tools: build with -DBTRAPZ_TRACE)
@@ -793,7 +817,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
       // runner belongs at the front of a launch, not wherever the batch order put it).
       const int nact = __popcll(__ballot(first && lane_in_group && valid && !done));
       if (eit == 0) lone_start = nact <= a.cap_alone;   // (alone from the start: hands over after its first iteration, see the lean form)
-      const bool want = !done && !unc_pass && valid && ((eit >= (lone_start ? 1 : a.cap_iter) && nact <= a.cap_alone && score >= a.cap_score) || eit >= a.cap_hi);
+      const bool want = !done && !unc_pass && valid && !slot_refused && ((eit >= (lone_start ? 1 : a.cap_iter) && nact <= a.cap_alone && score >= a.cap_score) || eit >= a.cap_hi);
       if (__any(want)) {
         UNIFORM_BLOCK;
         wave_lds_sync();
@@ -811,6 +835,8 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
             a.susp_key[(size_t)axis * a.B + b] = (ORDERED && !a.bucket_S) ? S : (cls < 1 ? 1 : cls > 64 ? 64 : cls);
           }
           suspended = true; done = true;
+        } else if (want) {
+          slot_refused = true;   // no room: the group goes on to the end, and does not ask again
         }
       }
     }

@@ -292,6 +292,18 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       sl[SI(r)] = fmax(gc_r - LLO(r), BTRAPZ_COLD_SLACK); su[SI(r)] = fmax(LUP(r) - gc_r, BTRAPZ_COLD_SLACK);
       LL(r) = BTRAPZ_COLD_LAMBDA; LU(r) = BTRAPZ_COLD_LAMBDA;
     END_ROWS
+    // rows without a real bound (btrapz_ipm.h, "bounds that are no bounds"): the centred multiplier, in a pass of its
+    // own behind a wave-uniform branch that is all but never taken (the packed form's arrangement)
+    bool far_row = false;
+    FOR_ROWS(r)
+      far_row |= sl[SI(r)] > BTRAPZ_COLD_FAR || su[SI(r)] > BTRAPZ_COLD_FAR;
+    END_ROWS
+    if (__any(far_row)) {
+      UNIFORM_BLOCK;
+      FOR_ROWS(r)
+        LL(r) = cold_lambda(sl[SI(r)], BTRAPZ_COLD_SLACK, BTRAPZ_COLD_LAMBDA); LU(r) = cold_lambda(su[SI(r)], BTRAPZ_COLD_SLACK, BTRAPZ_COLD_LAMBDA);
+      END_ROWS
+    }
   };
 
   // ---- set-up: the candidate's record, bounds, consistency, cold start ------------------------------------------
@@ -342,6 +354,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       UNROLL for (int i = 0; i < 5; i++) { vlo[i] = rv[2 * i]; vhi[i] = rv[2 * i + 1]; }
     }
     ROW_LIMITS_ACC();
+    const double far_cut = move_far_bounds(plo0, dplo, phi0, dphi, vlo, vhi);   // bounds that are none (btrapz_ipm.h)
     mplo = plo0 + 5.0 * dplo; mphi = phi0 + 5.0 * dphi; mvlo = vlo[4]; mvhi = vhi[4];
     // rows of the reference (all 18) for the consistency checks
 #define LO0(r) ((r) < 6 ? plo0 + (double)(r) * dplo : (r) < 11 ? vlo[((r) >= 6 && (r) < 11) ? (r) - 6 : 0] : (r) < 15 ? alo : jlo)
@@ -349,7 +362,10 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     double gapmin = 1e300, bnorm = 0.0;
     static_for<18>([&](auto r_c) {
       constexpr int r = decltype(r_c)::value;
-      const double rb = fmax(fabs(LO0(r)), fabs(UP0(r)));
+      // |bounds|: the real ones (a moved bound sits at far_cut exactly; header limits at BTRAPZ_FAR_LIMIT x t, x t^2)
+      const double cut = r < 11 ? far_cut : r < 15 ? BTRAPZ_FAR_LIMIT * t : BTRAPZ_FAR_LIMIT * t * t;
+      const double al = fabs(LO0(r)), au = fabs(UP0(r));
+      const double rb = fmax(al < cut ? al : 0.0, au < cut ? au : 0.0);
       gapmin = fmin(gapmin, (UP0(r) - LO0(r)) + 1e-12);   // (1e-12: the tolerance of the test suite's exact solver)
       bnorm = fmax(bnorm, rb);
     });
@@ -553,7 +569,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       const double rd_eff = fmax(rr.b - 2e-13 * rr.d, 0.0);
       const double rprim = rr.c * ibn;
       const double res = fmax(rd_eff * iqn, rprim);
-      const double score = fmax(res, mu);
+      const double score = (mu == mu) ? fmax(res, mu) : 1e300;   // (fmax would drop a NaN mu: ADVICE r4)
 #ifdef LEAN_TRACE
       tr_score = score; tr_res = rd_eff * iqn; tr_mu = mu; tr_pr = rprim;
 #endif
@@ -589,8 +605,8 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         // (a group that is alone from the first iteration on -- its neighbours have no solution, a quarter of the cuboid
         //  bench batch -- does not wait for cap_iter: it hands over after its first iteration; cuboid batch 4.08 -> 3.96 ms)
         if (eit == 0) lone_start = nact <= ka->cap_alone;
-        const bool want = !done && valid && ((eit >= (lone_start ? 1 : ka->cap_iter) && nact <= ka->cap_alone && score >= ka->cap_score) || eit >= ka->cap_hi);
-        if (__builtin_expect(__any(want), 0)) {   // (rare: at most once per group)
+        const bool want = !done && valid && susp_slot_ != -2 && ((eit >= (lone_start ? 1 : ka->cap_iter) && nact <= ka->cap_alone && score >= ka->cap_score) || eit >= ka->cap_hi);
+        if (__builtin_expect(__any(want), 0)) {   // (rare: at most once per group -- a group that finds no slot does not ask again)
           UNIFORM_BLOCK;
           wave_lds_sync();
           if (want && first) lds[LN_RED][lane] = (double)atomicAdd(ka->susp_count, 1);
@@ -601,6 +617,8 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
             // the record is written after the loop (state_io in here costs the allocator 84 B of scratch per lane).
             susp_slot_ = (int)slot; susp_score_ = (float)fmax(fmin(score, 1e3), 1e-12);
             suspended = true; done = true;
+          } else if (want) {
+            susp_slot_ = -2;   // no room: the group goes on to the end
           }
         }
       }

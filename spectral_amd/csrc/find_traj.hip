@@ -276,6 +276,9 @@ double run_find_traj(int variant, const TrajInput &in, const Params *p, TrajResu
   // BTRAPZ_EPS: the solve's tolerance (btrapz_options.eps; default 1e-9, control points within ~2e-6 of x*).  The
   // reference's OSQP runs at 1e-5; 1e-6 saves about one iteration per call ("Tolerance").
   if (const char *ep = getenv("BTRAPZ_EPS")) { const double v = atof(ep); if (v > 0.0 && v < 1e-2) opt1.eps = v; }
+  // BTRAPZ_SPLIT=0: the single launch in the three-candidates-per-wavefront form instead of the split one (find_traj's
+  // only configuration channel is the environment; the library below it reads btrapz_options alone)
+  if (const char *sp = getenv("BTRAPZ_SPLIT")) opt1.split = *sp == '0' ? -1 : 1;
   if (long_form) {
     h_status[0] = BTRAPZ_MAX_ITER_REACHED;   // (nothing solved yet: the block below does it, without the rescue rows)
   } else
@@ -446,6 +449,10 @@ BTRAPZ_EXPORT double btrapz_find_traj_mem_cap(int variant, const btrapz_traj_inp
   TrajResult res;
   const double cost = run_find_traj(variant, in, p, res);
   if (cost == FAIL) return FAIL;
+  // A control-point buffer too small for 12 S values is filled as far as it goes -- which the caller can only notice
+  // through *n_segments: without that pointer a truncated block would pass for the whole trajectory, so the
+  // call fails instead.
+  if (ctrl && (size_t)ctrl_cap < res.ctrl.size() && !n_segments) { t_last.status = BTRAPZ_EINVAL; return FAIL; }
   if (n_points) *n_points = res.np;
   if (n_segments) *n_segments = res.S;
   const int n = res.np < cap ? res.np : cap;

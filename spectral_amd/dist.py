@@ -13,6 +13,12 @@ import os
 import torch
 import torch.distributed as dist
 
+# Read once by ROCr when the HIP runtime comes up: set it here, at import, if the launcher did not (effective only when
+# nothing has initialised the GPU yet -- init_process_group warns otherwise; never re-exec a process to "fix" this).
+_IPC_MODE_WAS_SET = "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+_cuda_was_initialized_at_import = torch.cuda.is_initialized()
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 # A collective that does not complete within this time fails instead of hanging (a rank that died, a link that does not
 # come up): the failing rank exits non-zero and the launcher (torch.distributed.run) ends the others.
 COLLECTIVE_TIMEOUT_S = int(os.environ.get("BTRAPZ_COLLECTIVE_TIMEOUT_S", "60"))   # (a node whose RCCL bootstrap is slower than that can raise it)
@@ -23,10 +29,16 @@ def init_process_group(backend, local_rank=0, timeout_s=COLLECTIVE_TIMEOUT_S):
     RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) with a finite timeout on every collective.  backend "nccl" is RCCL on
     ROCm: the communicator is bound to this rank's device at once (device_id), so a first-contact problem -- no xGMI
     peer access, IPC handles refused -- shows here, before the first timed step, not inside it.
-    HSA_ENABLE_IPC_MODE_LEGACY=0 is kept in the environment of every rank (set if absent): this pool's host driver
-    supports dmabuf IPC only, and RCCL's peer buffers fail with `hipIpcGetMemHandle: invalid argument` without it (the
-    image exports it; a launcher that scrubs the environment would lose it)."""
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the rank's environment BEFORE the HIP runtime initialises (ROCr reads it
+    once): this pool's host driver supports dmabuf IPC only, and RCCL's peer buffers fail with `hipIpcGetMemHandle:
+    invalid argument` without it.  The image exports it; this module sets it at import when it is absent (below), which
+    helps only if nothing has touched the GPU yet -- so a process that arrives here with the runtime up and the
+    variable missing is told, instead of being left to fail inside its first collective."""
+    if backend == "nccl" and not _IPC_MODE_WAS_SET and torch.cuda.is_initialized() and _cuda_was_initialized_at_import:
+        import warnings
+        warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY was not in the environment when the HIP runtime initialised: on hosts whose "
+                      "driver supports dmabuf IPC only, RCCL's peer buffers will fail (hipIpcGetMemHandle: invalid argument). "
+                      "Export HSA_ENABLE_IPC_MODE_LEGACY=0 in the launcher.")
     timeout = datetime.timedelta(seconds=timeout_s)
     if backend == "nccl":
         dist.init_process_group("nccl", timeout=timeout, device_id=torch.device("cuda", local_rank))
@@ -53,7 +65,7 @@ def shard_bounds(B, world, rank):
     return lo, min(B, lo + per)
 
 
-def global_argmin(best_cost, best_idx, group=None, ctx=None):
+def global_argmin(best_cost, best_idx, group=None, ctx=None, force_collective=False):
     """best_cost [n] float64, best_idx [n] int64 (global candidate indices, -1 = none) of this rank.
     Returns (cost [n], idx [n]) of the winners over all ranks; identical on every rank.
 
@@ -68,7 +80,7 @@ def global_argmin(best_cost, best_idx, group=None, ctx=None):
     spectral_amd.native.Context) and device tensors the reduction over the ranks is one launch of the library
     (btrapz_argmin_pairs_device) on torch's current stream; otherwise a handful of torch ops with the same result."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):   # (force_collective: the first-contact test runs the collective at one rank)
         return best_cost, best_idx
     assert best_cost.shape == best_idx.shape and best_cost.dim() == 1
     pair = torch.stack([best_cost.to(torch.float64).view(torch.int64), best_idx.to(torch.int64)], dim=-1).contiguous()
@@ -92,7 +104,7 @@ def global_argmin(best_cost, best_idx, group=None, ctx=None):
     return out_c, out_i
 
 
-def global_argmin_with_winner(best_cost, best_idx, local_ctrl, group=None, ctx=None):
+def global_argmin_with_winner(best_cost, best_idx, local_ctrl, group=None, ctx=None, force_collective=False):
     """global_argmin that also brings the winners' control points to every rank ("only the winner's 1.9 KB
     is fetched from its owner"), in the SAME collective: every rank contributes, per arg-min group, its local winner's
     (cost, global index) pair followed by that candidate's control points -- 16 B + 12 S x 8 B = 1 936 B at 20 segments
@@ -106,7 +118,7 @@ def global_argmin_with_winner(best_cost, best_idx, local_ctrl, group=None, ctx=N
     ctrl [n][P]); ctrl rows of groups nobody solved are NaN.  Identical on every rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     assert best_cost.shape == best_idx.shape and best_cost.dim() == 1 and local_ctrl.dim() == 2 and local_ctrl.shape[0] == best_cost.shape[0]
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         out = local_ctrl.clone()
         out[best_idx < 0] = float("nan")
         return best_cost, best_idx, out

@@ -70,6 +70,22 @@ class CTrajInput(C.Structure):
                 ("dl_bounds", C.c_void_p), ("s_ref", C.c_void_p), ("l_ref", C.c_void_p)]
 
 
+class CMultiShard(C.Structure):
+    """btrapz_multi_shard: a shard that is on its device already."""
+    _fields_ = [("B", C.c_int), ("index_base", C.c_longlong), ("seg", C.c_void_p), ("init", C.c_void_p),
+                ("ref_end", C.c_void_p), ("dl_bounds", C.c_void_p)]
+
+
+class CMultiView(C.Structure):
+    """btrapz_multi_view: what lives on one device slot after a step (device pointers)."""
+    _fields_ = [("device", C.c_int), ("B", C.c_int), ("index_base", C.c_longlong), ("stream", C.c_void_p), ("ctx", C.c_void_p),
+                ("ctrl", C.c_void_p), ("cost", C.c_void_p), ("status", C.c_void_p), ("iters", C.c_void_p),
+                ("best_idx", C.c_void_p), ("best_cost", C.c_void_p), ("best_ctrl", C.c_void_p)]
+
+
+MULTI_AUTO, MULTI_COPIES, MULTI_RCCL = 0, 1, 2
+
+
 class CParams(C.Structure):
     """include/btrapz/py_cpp_.h:6-21 == trp_wrapper.py:19-32."""
     _fields_ = [("s_acc_weight", C.c_double), ("s_jerk_weight", C.c_double),
@@ -110,7 +126,11 @@ EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "bt
            "btrapz_find_traj_last_iterations", "btrapz_argmin_pairs_device", "btrapz_options_init",
            "btrapz_rescue_violations_device", "btrapz_find_traj_last_status", "btrapz_debug_mqm_tables",
            "btrapz_debug_axis_records", "btrapz_debug_resume_keys", "btrapz_debug_parse_double", "btrapz_debug_format_fixed",
-           "btrapz_last_solve_form")
+           "btrapz_last_solve_form",
+           "btrapz_multi_create", "btrapz_multi_destroy", "btrapz_multi_last_error", "btrapz_multi_transport",
+           "btrapz_multi_transport_library", "btrapz_multi_device_count", "btrapz_multi_shard_bounds", "btrapz_multi_upload",
+           "btrapz_multi_set_shards", "btrapz_multi_solve_argmin", "btrapz_multi_result", "btrapz_multi_wait",
+           "btrapz_multi_shard_view", "btrapz_multi_download")
 
 
 def build(verbose=False):
@@ -201,8 +221,125 @@ def lib():
         l.btrapz_prism_bounds_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(CRoad), dp, C.c_int, dp, dp, ip, vp]
         l.btrapz_prism_corridor_batch_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(CRoad), dp, C.c_int,
                                                          C.c_double, dp, dp, dp, dp, C.c_int, dp, ip, dp, dp, ip, vp]
+        l.btrapz_multi_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int]
+        l.btrapz_multi_destroy.argtypes = [vp]
+        l.btrapz_multi_last_error.argtypes = [vp]; l.btrapz_multi_last_error.restype = C.c_char_p
+        l.btrapz_multi_transport.argtypes = [vp]
+        l.btrapz_multi_transport_library.argtypes = [vp]; l.btrapz_multi_transport_library.restype = C.c_char_p
+        l.btrapz_multi_device_count.argtypes = [vp]
+        l.btrapz_multi_shard_bounds.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        l.btrapz_multi_upload.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp]
+        l.btrapz_multi_set_shards.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(CMultiShard)]
+        l.btrapz_multi_solve_argmin.argtypes = [vp, C.POINTER(CShared), C.POINTER(COptions)]
+        l.btrapz_multi_result.argtypes = [vp, C.c_int, llp, dp, dp]
+        l.btrapz_multi_wait.argtypes = [vp]
+        l.btrapz_multi_shard_view.argtypes = [vp, C.c_int, C.POINTER(CMultiView)]
+        l.btrapz_multi_download.argtypes = [vp, dp, dp, ip, ip]
         _lib = l
     return _lib
+
+
+def multi_shard_bounds(B, G, g, group=0):
+    """btrapz_multi_shard_bounds: [lo, hi) of device slot g."""
+    lo, hi = C.c_int(0), C.c_int(0)
+    rc = lib().btrapz_multi_shard_bounds(int(B), int(G), int(g), int(group), C.byref(lo), C.byref(hi))
+    if rc != 0:
+        raise BtrapzError("btrapz_multi_shard_bounds(%d, %d, %d, %d) -> %d" % (B, G, g, group, rc))
+    return lo.value, hi.value
+
+
+class MultiContext:
+    """btrapz_multi: one host process, one context + stream per entry of `devices` (an ordinal may repeat: logical
+    devices), candidates sharded contiguously, one gather of the local winners (include/btrapz_hip.h)."""
+
+    def __init__(self, devices, transport=MULTI_AUTO):
+        self._h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = lib().btrapz_multi_create(C.byref(self._h), devs, len(devices), int(transport))
+        if rc != 0:
+            raise BtrapzError("btrapz_multi_create(%s, transport=%d) failed with %d (no HIP device, or the transport "
+                              "cannot be had: see stderr)" % (list(devices), transport, rc))
+        self.G = len(devices); self.B = self.S = 0; self.group = 0
+
+    def close(self):
+        if self._h:
+            lib().btrapz_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise BtrapzError("%s failed (%d): %s" % (what, rc, lib().btrapz_multi_last_error(self._h).decode()))
+
+    def transport(self):
+        return int(lib().btrapz_multi_transport(self._h))
+
+    def transport_library(self):
+        return lib().btrapz_multi_transport_library(self._h).decode()
+
+    def fallback_reason(self):
+        return lib().btrapz_multi_last_error(self._h).decode()
+
+    def upload(self, batch, group=0):
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        seg, init, ref_end, dlb = f(batch.seg), f(batch.init), f(batch.ref_end), f(batch.dl_bounds)
+        assert seg.shape == (L.NUM_SEG_FIELDS, batch.B, batch.S)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(lib().btrapz_multi_upload(self._h, batch.B, batch.S, int(group), p(seg), p(init), p(ref_end), p(dlb)), "btrapz_multi_upload")
+        self.B, self.S, self.group = batch.B, batch.S, int(group)
+
+    def set_shards(self, B, S, shards, group=0):
+        """shards: list of (B_g, index_base, seg, init, ref_end, dl_bounds) with torch tensors on the slot's device (or
+        None for an empty shard); the tensors must stay alive while steps run."""
+        arr = (CMultiShard * self.G)()
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        for g, (Bg, base, seg, init, ref_end, dlb) in enumerate(shards):
+            arr[g] = CMultiShard(int(Bg), int(base), ptr(seg), ptr(init), ptr(ref_end), ptr(dlb))
+        self._check(lib().btrapz_multi_set_shards(self._h, int(B), int(S), int(group), arr), "btrapz_multi_set_shards")
+        self.B, self.S, self.group = int(B), int(S), int(group)
+        self._keep = shards
+
+    def solve_argmin(self, shared, **options):
+        sh = CShared.from_shared(shared)
+        opt = _options(options.pop("max_iter", 0), options.pop("eps", 0.0), options.pop("elastic", 0), options.pop("elastic_tol", 0.0), **options)
+        self._check(lib().btrapz_multi_solve_argmin(self._h, C.byref(sh), C.byref(opt)), "btrapz_multi_solve_argmin")
+
+    def prepared_step(self, shared, **options):
+        """solve_argmin with its argument structs built once: returns a function of no arguments (timing loops)."""
+        sh = CShared.from_shared(shared)
+        opt = _options(options.pop("max_iter", 0), options.pop("eps", 0.0), options.pop("elastic", 0), options.pop("elastic_tol", 0.0), **options)
+        fn, check, h = lib().btrapz_multi_solve_argmin, self._check, self._h
+        args = (h, C.byref(sh), C.byref(opt))
+
+        def call(_keep=(sh, opt)):
+            check(fn(*args), "btrapz_multi_solve_argmin")
+        return call
+
+    def result(self, device_slot=-1):
+        """(best_idx, best_cost, best_ctrl): scalars + [12 S] for one arg-min group, arrays [n], [n], [n, 12 S] for n groups."""
+        n = 1 if (self.group == 0 or self.group >= self.B) else self.B // self.group
+        idx = np.zeros(n, dtype=np.int64); cost = np.zeros(n); ctrl = np.zeros((n, 12 * self.S))
+        self._check(lib().btrapz_multi_result(self._h, int(device_slot), idx.ctypes.data, cost.ctypes.data, ctrl.ctypes.data), "btrapz_multi_result")
+        return (int(idx[0]), float(cost[0]), ctrl[0]) if n == 1 else (idx, cost, ctrl)
+
+    def wait(self):
+        self._check(lib().btrapz_multi_wait(self._h), "btrapz_multi_wait")
+
+    def view(self, device_slot):
+        v = CMultiView()
+        self._check(lib().btrapz_multi_shard_view(self._h, int(device_slot), C.byref(v)), "btrapz_multi_shard_view")
+        return v
+
+    def download(self):
+        ctrl = np.zeros((self.B, 12 * self.S)); cost = np.zeros(self.B)
+        status = np.zeros(self.B, dtype=np.int32); iters = np.zeros(self.B, dtype=np.int32)
+        self._check(lib().btrapz_multi_download(self._h, ctrl.ctypes.data, cost.ctypes.data, status.ctypes.data, iters.ctypes.data), "btrapz_multi_download")
+        return dict(ctrl=ctrl, cost=cost, status=status, iters=iters)
 
 
 class Context:

@@ -66,6 +66,25 @@ def test_shard_bounds_cover_the_batch():
         assert cover == list(range(B))
 
 
+def test_the_c_abi_shards_as_dist_does():
+    """btrapz_multi_shard_bounds (the one-process multi-GPU step of include/btrapz_hip.h) cuts a batch exactly where
+    spectral_amd.dist.shard_bounds does; with arg-min groups a shard is a whole number of groups.  No GPU needed."""
+    from spectral_amd import native
+    for B, G in ((65536, 8), (1000, 3), (5, 8), (1, 1), (4097, 4), (64, 64)):
+        for g in range(G):
+            assert native.multi_shard_bounds(B, G, g) == shard_bounds(B, G, g), (B, G, g)
+    B, G, group = 128 * 512, 8, 512                       # BASELINE config 5: 16 agents x 512 candidates per GPU
+    assert [native.multi_shard_bounds(B, G, g, group) for g in range(G)] == [(g * 8192, (g + 1) * 8192) for g in range(G)]
+    cuts = [native.multi_shard_bounds(12 * 64, 5, g, 64) for g in range(5)]        # 12 groups over 5 devices: 3, 3, 3, 3, 0
+    assert cuts == [(0, 192), (192, 384), (384, 576), (576, 768), (768, 768)]
+    with pytest.raises(native.BtrapzError):
+        native.multi_shard_bounds(10, 2, 0, 3)            # 10 % 3 != 0
+    with pytest.raises(native.BtrapzError):               # without a HIP device there is no handle, and no CPU stand-in
+        if torch.cuda.is_available():
+            raise native.BtrapzError("box has a GPU")
+        native.MultiContext([0, 0])
+
+
 def test_all_failed_group_reports_minus_one():
     c, i = global_argmin(torch.tensor([float("inf")], dtype=torch.float64), torch.tensor([-1]))
     assert int(i[0]) == -1
