@@ -207,10 +207,9 @@ typedef struct btrapz_options {
   int elastic;
   double elastic_tol;
   double elastic_delta;
-  /* Uniform cold batches of many more candidates than the device holds at once: 1 -> persistent wavefronts draw
-   * candidates from a queue, so that the groups of a wavefront do not wait for its slowest one.  Pays where iteration
-   * counts spread widely (batches with stalling candidates: -10 %), costs where they do not (+6 %); 0 -> off.
-   * Results do not depend on it. */
+  /* EXPERIMENTAL, ignored by the shipped library (honoured by a -DBTRAPZ_EXPERIMENTS build): persistent wavefronts that
+   * draw candidates from a queue.  Scheduling only.  Measured against the two launches of cap_iter: a loss on every bench
+   * batch.  The field stays so that the struct's layout does. */
   int queue;
   /* Few candidates: the split form of the solve kernel -- ONE candidate per wavefront, every segment's rows spread over
    * three lanes (uniform cold batches of at most 21 segments).  Per solve it takes ~0.7 of the time of the
@@ -218,10 +217,10 @@ typedef struct btrapz_options {
    * 0 -> automatic (used when 2 B wavefronts fit the device's SIMDs at once); 1 -> whenever the batch qualifies;
    * -1 -> never.  Same problem, same method: results agree to rounding (the row sums are taken in another order). */
   int split;
-  /* Starting point of a cold solve.  0 (default): the initial state propagated at constant velocity.  1: from there,
-   * one Newton step of the problem WITHOUT its inequality rows first (one block solve with zero row weights, about half
-   * an iteration's work), i.e. the unconstrained optimum, then the usual slacks and multipliers.  The optimum does not
-   * depend on it; the iteration count does (measured: DESIGN.md 3.9). */
+  /* EXPERIMENTAL, ignored by the shipped library (honoured by a -DBTRAPZ_EXPERIMENTS build): 1 = start a cold solve
+   * from the unconstrained optimum (one Newton step of the problem without its inequality rows) instead of the initial
+   * state propagated at constant velocity.  The optimum does not depend on it; the iteration count does, for the worse
+   * (DESIGN.md 3.2).  The field stays so that the struct's layout does. */
   int start;
   /* Uniform cold batches of many more candidates than the device holds at once: two launches instead of one.  In the
    * first, a candidate that is the only one of its wavefront still iterating after cap_iter interior-point iterations
@@ -255,6 +254,9 @@ int btrapz_destroy(btrapz_ctx *ctx);
 const char *btrapz_last_error(const btrapz_ctx *ctx);
 /* Number of HIP devices visible (0 when the runtime finds none). */
 int btrapz_device_count(void);
+/* 1 when the library was built with -DBTRAPZ_EXPERIMENTS (btrapz_options.queue / .start honoured, environment overrides of
+ * the scheduling choices read), else 0: the shipped build. */
+int btrapz_build_has_experiments(void);
 
 /* Solve B candidates of S segments each; all pointers are DEVICE pointers.
  *   seg        [NUM_SEG_FIELDS][B][S]     init     [B][6] (s, ds, dds, l, dl, ddl at t=0)
@@ -280,7 +282,7 @@ int btrapz_rescue_violations_device(btrapz_ctx *ctx, int B, double *viol, void *
 
 /* Which form of the solve kernel the context's last batched solve ran (scheduling only; results do not depend on it):
  * 0 packed (floor(64/S) candidates per wavefront), 1 split (btrapz_options.split), 2 long (65..256 segments),
- * 3 capped first launch + resume launch (btrapz_options.cap_iter), 4 candidate queue (btrapz_options.queue); -1 none yet.
+ * 3 capped first launch + resume launch (btrapz_options.cap_iter), 4 candidate queue (experiment builds); -1 none yet.
  * + 8 when the launch(es) ran the two-wavefronts-per-SIMD form (btrapz_options.lean). */
 int btrapz_last_solve_form(const btrapz_ctx *ctx);
 

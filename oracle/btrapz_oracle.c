@@ -1438,12 +1438,17 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
     /* Safeguard (round 5, found by the sweep over the reference's weight space): unsafeguarded Mehrotra steps can cycle --
      * mu going round 2e-3, 1e-3, 2e-3, 6e-4 for ever with residuals at 1e-13 (seen on 4 of ~57 000 candidates under
      * weight rows with a near-zero jerk weight or zero end weights; a cycle may still creep down in its fourth digit).
-     * Four iterations with less than a halving of the score switch the solve, for good, to plain centred path-following:
-     * no second-order term, sigma at least 0.2.  Linear but sure. */
+     * Four iterations with less than a halving of the score switch the solve, for three iterations, to plain centred
+     * path-following: no second-order term, sigma at least 0.2. */
     /* (only where complementarity is all that is left -- residuals four digits below mu: a slow START, residuals and mu
      *  falling together by 10 % per iteration as on src/c4.txt, is not a cycle and Mehrotra's steps get it going) */
     if (fmax(vnorm_inf(rd, n) / (1 + qn), rpn / (1 + bn)) < 1e-4 * mu &&
-        iter >= 8 && score > 0.5 * score_hist[iter & 3]) safe = 1;   /* (less than a halving in four iterations) */
+        iter >= 8 && score > 0.5 * score_hist[iter & 3]) {   /* (less than a halving in four iterations) */
+      safe = 3;   /* three centred steps, then Mehrotra's again from a better-centred iterate (crawling all the way down at
+                   * sigma = 0.2 spends many iterations at lambda / s = 1e11 and the multiplier update's round-off, amplified
+                   * by that factor each time, ruins the dual residual: src fuzz seed 31, calls 33 and 93) */
+      for (int h = 0; h < 4; h++) score_hist[h] = 1e300;
+    } else if (safe > 0) --safe;
     score_hist[iter & 3] = score;
     double sigma = 0, alpha = 1;
     for (int pass = 0; pass < 2; pass++) {

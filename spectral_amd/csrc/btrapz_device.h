@@ -122,7 +122,9 @@ __global__ void ipm_solve_kernel(const KernelArgs a, const double *__restrict__ 
 __global__ void ipm_solve_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);       // through a.order
 __global__ void ipm_solve_warm_kernel(const KernelArgs a, const double *__restrict__ mqm);          // + btrapz_warm
 __global__ void ipm_solve_warm_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);
+#ifdef BTRAPZ_EXPERIMENTS
 __global__ void ipm_solve_queue_kernel(const KernelArgs a, const double *__restrict__ mqm);         // persistent, candidate queue
+#endif
 __global__ void ipm_solve_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm);       // rescue pass
 __global__ void ipm_solve_split_kernel(const KernelArgs a, const double *__restrict__ mqm);         // one candidate per wavefront, rows over 3 lanes
 __global__ void ipm_solve_capped_kernel(const KernelArgs a, const double *__restrict__ mqm);        // first launch of a capped solve

@@ -158,6 +158,14 @@ BTRAPZ_EXPORT int btrapz_device_count(void) {
   return n;
 }
 
+BTRAPZ_EXPORT int btrapz_build_has_experiments(void) {
+#ifdef BTRAPZ_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 BTRAPZ_EXPORT int btrapz_create(btrapz_ctx **out, int device) {
   if (!out) return BTRAPZ_EINVAL;
   *out = nullptr;
@@ -247,8 +255,12 @@ static void fill_parameters(KernelArgs &a, const btrapz_shared *sh, const btrapz
   a.elastic_tol = (opt && opt->elastic_tol > 0) ? opt->elastic_tol : BTRAPZ_DEFAULT_ELASTIC_TOL;
   a.bucket_S = 0;
   a.cap_iter = 0; a.cap_alone = 0; a.cap_hi = 0; a.cap_score = 0.0; a.susp_cap = 0; a.susp_state = nullptr; a.susp_count = nullptr; a.susp_slot = nullptr; a.susp_key = nullptr;
+#ifdef BTRAPZ_EXPERIMENTS
   static const int start_env = [] { const char *e = experiment_env("BTRAPZ_START"); return e ? atoi(e) : -1; }();
   a.unc_start = start_env >= 0 ? start_env : (opt ? opt->start : 0);
+#else
+  a.unc_start = 0;   // (btrapz_options.start: the optimum does not depend on it, the iteration count does -- for the worse; experiment builds only)
+#endif
 }
 
 // M' pQp_d M on the host (solve_3d.cc:87-143): the single-candidate path hands the table over with its inputs.
@@ -437,8 +449,12 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     // candidates, kernel ms off -> on): scenario_1 x 20 6.93 -> 6.59, its cuboid variant (16 % stalling) 6.57 -> 5.71,
     // generic x 20 5.12 -> 5.33, scenario_1 x 10 2.13 -> 2.34: it pays where iteration counts spread widely, so it is
     // the caller's choice and off by default.
+#ifdef BTRAPZ_EXPERIMENTS
     static const int queue_env = [] { const char *q = experiment_env("BTRAPZ_QUEUE"); return q ? (*q == '0' ? -1 : 1) : 0; }();
     const bool queue_on = queue_env ? queue_env > 0 : (opt && opt->queue > 0);
+#else
+    const bool queue_on = false;   // (btrapz_options.queue: scheduling only, a measured loss -- honoured by experiment builds, ignored here)
+#endif
     a.queue = c->d_queue;
     // Few candidates: one per wavefront, rows over three lanes (btrapz_options.split; ipm_solve_split_kernel)
     const char *split_q = experiment_env("BTRAPZ_SPLIT");
@@ -552,11 +568,13 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     } else if (split_on) {
       c->last_form = 1;
       hipLaunchKernelGGL(ipm_solve_split_kernel, dim3(2u * (unsigned)B), dim3(64), 0, stream, a, (const double *)c->d_mqm);
+#ifdef BTRAPZ_EXPERIMENTS
     } else if (queue_on && !a.order && !warm_kernel && blocks >= 3u * (unsigned)c->resident_waves) {
       HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int) * 2, stream));
       c->last_form = 4;
       hipLaunchKernelGGL(ipm_solve_queue_kernel, dim3((unsigned)c->resident_waves & ~1u), dim3(64), 0, stream, a,
                          (const double *)c->d_mqm);
+#endif
     } else if (lean_on) {
       c->last_form = 8;
       const bool ragged_batch = seg_count != nullptr;   // (a.order without it: hint classes of a uniform batch)

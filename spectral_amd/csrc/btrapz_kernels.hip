@@ -543,7 +543,9 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     if constexpr (RESUME) {   // carry on where the capped launch stopped
       if (valid) state_io(false, a.susp_slot[2LL * b + axis]);
     }
+#ifdef BTRAPZ_EXPERIMENTS   // (btrapz_options.start = 1: a measured loss, DESIGN 3.2 -- compiled into experiment builds only)
     unc_pass = !ELASTIC && !QUEUE && !RESUME && a.unc_start != 0 && !warm_started;
+#endif
   };
   auto write_back = [&]() {
     if constexpr (CAPPED) {
@@ -1282,11 +1284,14 @@ __global__ __launch_bounds__(64) void ipm_solve_resume_kernel(const KernelArgs a
   __shared__ double lds[lds_rows<false>()][64];
   ipm_solve_body<false, true, false, false, false, false, false, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
+#ifdef BTRAPZ_EXPERIMENTS
 // Uniform cold batches much larger than the machine: persistent wavefronts over a candidate queue (see QUEUE above).
+// A measured loss against the two-launch solve on the bench batches: experiment builds only.
 __global__ __launch_bounds__(64) void ipm_solve_queue_kernel(const KernelArgs a, const double *__restrict__ mqm) {
   __shared__ double lds[lds_rows<false>()][64];
   ipm_solve_body<false, false, false, true>(a, mqm, lds, (int)blockIdx.x, (int)threadIdx.x);
 }
+#endif
 // Few candidates (fewer axis problems than SIMDs), at most 21 segments: one candidate per wavefront, its rows split over
 // three lane groups (SPLIT above).  Wavefront w: axis w & 1 of candidate w >> 1.
 __global__ __launch_bounds__(64) void ipm_solve_split_kernel(const KernelArgs a, const double *__restrict__ mqm) {

@@ -74,6 +74,13 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   const int m = S >> 1;
   const bool top = k < m, mid = k == m;
   const int my_step = top ? k : (k > m ? S - 1 - k : m);
+  // LEAN_BPERM: neighbour exchange of the sequential loops through ds_bpermute (lane_fetch, btrapz_ipm.h) -- byte addresses
+  // of the neighbour away from the root / towards it, and of both neighbours for the root's own step
+#ifndef LEAN_BPERM
+#define LEAN_BPERM 1
+#endif
+  [[maybe_unused]] const int addr_prev = (lane - 1) << 2, addr_next = (lane + 1) << 2;
+  [[maybe_unused]] const int addr_leaf = top ? addr_prev : addr_next, addr_root = top ? addr_next : addr_prev;
   const Shared &sh = a.sh;
   const int variant = sh.variant;
   // The kernel's arguments as the loop and the write-back see them: through a pointer into the kernarg segment that is
@@ -712,6 +719,62 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         }
       UNROLL for (int i = 0; i < 6; i++) TF[i] = T[i];
       SEQ_BEGIN();
+#if LEAN_BPERM
+      if constexpr (!SMALL_S) {
+        // One fetch per double from the neighbour AWAY from the root (lane_fetch: per-lane address through the LDS
+        // crossbar) instead of a DPP shift in each direction and an addition: per step 18 LDS-pipe instructions for 45
+        // vector-ALU ones.  The root (block m) is the one lane that needs both neighbours: its step comes after the loop.
+        for (int step = 0; step < m; ++step) {
+          double zin[6], win[3];
+          UNROLL for (int i = 0; i < 6; i++) zin[i] = lane_fetch(addr_leaf, Z[i]);
+          UNROLL for (int i = 0; i < 3; i++) win[i] = lane_fetch(addr_leaf, wp[i]);
+          if (step == my_step) {   // (never the root: its step is m)
+            double Sk[6], F[6];
+            UNROLL for (int i = 0; i < 6; i++) Sk[i] = TF[i] - zin[i];
+            UNROLL for (int i = 0; i < 3; i++) up[i] -= win[i];
+            ldl3(Sk, F);
+            UNROLL for (int i = 0; i < 6; i++) TF[i] = F[i];
+            double Y[9], K[9];
+            UNROLL for (int j = 0; j < 3; j++) {
+              Y[j] = MK[j];
+              Y[3 + j] = MK[3 + j] - F[0] * Y[j];
+              Y[6 + j] = MK[6 + j] - F[1] * Y[j] - F[2] * Y[3 + j];
+            }
+            UNROLL for (int j = 0; j < 3; j++) {
+              K[6 + j] = Y[6 + j] * F[5];
+              K[3 + j] = Y[3 + j] * F[4];
+              K[j] = Y[j] * F[3];
+            }
+            Z[0] = Y[0] * K[0] + Y[3] * K[3] + Y[6] * K[6];
+            Z[1] = Y[0] * K[1] + Y[3] * K[4] + Y[6] * K[7];
+            Z[2] = Y[0] * K[2] + Y[3] * K[5] + Y[6] * K[8];
+            Z[3] = Y[1] * K[1] + Y[4] * K[4] + Y[7] * K[7];
+            Z[4] = Y[1] * K[2] + Y[4] * K[5] + Y[7] * K[8];
+            Z[5] = Y[2] * K[2] + Y[5] * K[5] + Y[8] * K[8];
+            UNROLL for (int j = 0; j < 3; j++) {
+              K[3 + j] -= F[2] * K[6 + j];
+              K[j] -= F[0] * K[3 + j] + F[1] * K[6 + j];
+            }
+            wp[0] = K[0] * up[0] + K[3] * up[1] + K[6] * up[2];
+            wp[1] = K[1] * up[0] + K[4] * up[1] + K[7] * up[2];
+            wp[2] = K[2] * up[0] + K[5] * up[1] + K[8] * up[2];
+            UNROLL for (int i = 0; i < 9; i++) MK[i] = K[i];
+          }
+        }
+        {   // the root: Schur updates from both sides
+          double zin[6], win[3];
+          UNROLL for (int i = 0; i < 6; i++) zin[i] = lane_fetch(addr_prev, Z[i]) + lane_fetch(addr_next, Z[i]);
+          UNROLL for (int i = 0; i < 3; i++) win[i] = lane_fetch(addr_prev, wp[i]) + lane_fetch(addr_next, wp[i]);
+          if (mid) {
+            double Sk[6], F[6];
+            UNROLL for (int i = 0; i < 6; i++) Sk[i] = TF[i] - zin[i];
+            UNROLL for (int i = 0; i < 3; i++) up[i] -= win[i];
+            ldl3(Sk, F);
+            UNROLL for (int i = 0; i < 6; i++) TF[i] = F[i];
+          }
+        }
+      } else
+#endif
       for (int step = 0; step <= m; ++step) {
         double zin[6], win[3];
         if constexpr (SMALL_S) {
@@ -771,6 +834,21 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     auto forward_u = [&](double (&u)[3]) {
       double w[3] = {0.0, 0.0, 0.0};
       SEQ_BEGIN();
+#if LEAN_BPERM
+      if constexpr (!SMALL_S) {
+        for (int step = 0; step < m; ++step) {
+          double win[3];
+          UNROLL for (int i = 0; i < 3; i++) win[i] = lane_fetch(addr_leaf, w[i]);
+          if (step == my_step) {
+            UNROLL for (int i = 0; i < 3; i++) u[i] -= win[i];
+            w[0] = MK[0] * u[0] + MK[3] * u[1] + MK[6] * u[2];
+            w[1] = MK[1] * u[0] + MK[4] * u[1] + MK[7] * u[2];
+            w[2] = MK[2] * u[0] + MK[5] * u[1] + MK[8] * u[2];
+          }
+        }
+        UNROLL for (int i = 0; i < 3; i++) { const double win = lane_fetch(addr_prev, w[i]) + lane_fetch(addr_next, w[i]); u[i] -= mid ? win : 0.0; }
+      } else
+#endif
       for (int step = 0; step <= m; ++step) {
         double win[3];
         if constexpr (SMALL_S) {
@@ -797,6 +875,20 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       double y[3];
       UNROLL for (int i = 0; i < 3; i++) y[i] = mid ? dX[i] : 0.0;
       SEQ_BEGIN();
+#if LEAN_BPERM
+      if constexpr (!SMALL_S) {
+        for (int step = m - 1; step >= 0; --step) {   // (here a lane wants the neighbour TOWARDS the root)
+          double xin[3];
+          UNROLL for (int i = 0; i < 3; i++) xin[i] = lane_fetch(addr_root, y[i]);
+          if (step == my_step) {
+            UNROLL for (int i = 0; i < 3; i++) {
+              dX[i] -= MK[3 * i] * xin[0] + MK[3 * i + 1] * xin[1] + MK[3 * i + 2] * xin[2];
+              y[i] = dX[i];
+            }
+          }
+        }
+      } else
+#endif
       for (int step = m - 1; step >= 0; --step) {
         double xin[3];
         if constexpr (SMALL_S) {

@@ -118,7 +118,7 @@ struct Shard {
   double *own_in = nullptr; size_t own_in_cap = 0;                 // inputs uploaded through btrapz_multi_upload
   double *ctrl = nullptr, *cost = nullptr; int *status = nullptr, *iters = nullptr; size_t out_cand = 0, out_ctrl = 0;
   long long *loc_idx = nullptr; double *loc_cost = nullptr; size_t loc_cap = 0;
-  long long *rec = nullptr, *gathered = nullptr; size_t rec_cap = 0;   // [n][2 + P], [G][n][2 + P]
+  long long *rec = nullptr, *gathered = nullptr; size_t rec_cap = 0, gat_cap = 0;   // [n][2 + P], [G][n][2 + P]
   double *best_cost = nullptr; long long *best_idx = nullptr; double *best_ctrl = nullptr; size_t best_cap = 0, best_ctrl_cap = 0;
   ncclComm_t comm = nullptr;
 };
@@ -284,11 +284,13 @@ static int ensure_outputs(btrapz_multi *m, Shard &s, int S, int n_local, int n_g
     MCHK(m, hipMalloc(&s.loc_idx, sizeof(long long) * nl)); MCHK(m, hipMalloc(&s.loc_cost, sizeof(double) * nl));
     s.loc_cap = nl;
   }
-  const size_t rec = ng * (2 + P);
-  if (rec > s.rec_cap) {
-    (void)hipFree(s.rec); (void)hipFree(s.gathered); s.rec = nullptr; s.gathered = nullptr; s.rec_cap = 0;
-    MCHK(m, hipMalloc(&s.rec, sizeof(long long) * rec)); MCHK(m, hipMalloc(&s.gathered, sizeof(long long) * rec * (size_t)m->G));
-    s.rec_cap = rec;
+  // one arg-min group over the batch: a record of this device and G gathered ones; groups that live on the device: one
+  // record per group, packed straight into `gathered` (the select kernel runs on them with world = 1)
+  const size_t rec = (m->global_groups ? ng : nl) * (2 + P), gat = m->global_groups ? rec * (size_t)m->G : rec;
+  if (rec > s.rec_cap || gat > s.gat_cap) {
+    (void)hipFree(s.rec); (void)hipFree(s.gathered); s.rec = nullptr; s.gathered = nullptr; s.rec_cap = 0; s.gat_cap = 0;
+    MCHK(m, hipMalloc(&s.rec, sizeof(long long) * rec)); MCHK(m, hipMalloc(&s.gathered, sizeof(long long) * gat));
+    s.rec_cap = rec; s.gat_cap = gat;
   }
   const size_t nb = nl > ng ? nl : ng;
   if (nb > s.best_cap) {

@@ -126,7 +126,7 @@ EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "bt
            "btrapz_find_traj_last_iterations", "btrapz_argmin_pairs_device", "btrapz_options_init",
            "btrapz_rescue_violations_device", "btrapz_find_traj_last_status", "btrapz_debug_mqm_tables",
            "btrapz_debug_axis_records", "btrapz_debug_resume_keys", "btrapz_debug_parse_double", "btrapz_debug_format_fixed",
-           "btrapz_last_solve_form",
+           "btrapz_last_solve_form", "btrapz_build_has_experiments",
            "btrapz_multi_create", "btrapz_multi_destroy", "btrapz_multi_last_error", "btrapz_multi_transport",
            "btrapz_multi_transport_library", "btrapz_multi_device_count", "btrapz_multi_shard_bounds", "btrapz_multi_upload",
            "btrapz_multi_set_shards", "btrapz_multi_solve_argmin", "btrapz_multi_result", "btrapz_multi_wait",

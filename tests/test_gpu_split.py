@@ -94,7 +94,10 @@ def test_unconstrained_start_reaches_the_same_optimum(gen, S, variant, split):
     """btrapz_options.start = 1 (one Newton step of the problem without its inequality rows before the first iteration):
     another starting point of the same strictly convex QP -- same candidates accepted, same optimum."""
     import torch
+    from spectral_amd import native
     from spectral_amd.solver import BatchSolver
+    if not native.lib().btrapz_build_has_experiments():
+        pytest.skip("btrapz_options.start is honoured by -DBTRAPZ_EXPERIMENTS builds only (a measured loss: DESIGN 3.2)")
     solver = BatchSolver(0)
     B = 600
     batch, sh = (synth.make_scenario1_batch(B, S, variant) if gen == "scenario1" else synth.make_batch(B, S, config=2, variant=variant))

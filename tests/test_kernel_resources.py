@@ -53,7 +53,7 @@ def test_lean_kernels_fit_two_wavefronts_per_simd():
 def test_packed_kernels_do_not_spill():
     ks = kernels_of("btrapz_kernels.o")
     solve = {n: r for n, r in ks.items() if "ipm_solve_" in n}
-    assert len(solve) >= 12
+    assert len(solve) >= 11      # (round 5: the queue kernel is compiled into -DBTRAPZ_EXPERIMENTS builds only)
     for name, r in solve.items():
         # (.vgpr_count of the metadata is the unified allocation: 256 architectural + the accumulation registers)
         # Cold instantiations: no scratch.  The warm-start ones sit at the full 512 registers and since round 5 (the
