@@ -241,6 +241,16 @@ typedef struct btrapz_options {
    * -1 -> never.  (The rescue pass, start = 1 and the candidate queue always run the one-wavefront form; warm starts --
    * btrapz_solve_warm_device -- have their instantiation of this form too, in one launch.) */
   int lean;
+  /* Cold solves of at most 64 segments without a rescue pass: a pre-pass lists the candidates that CAN start -- it
+   * applies, with doubled tolerances, the tests of the solve kernels' set-up: a row with l > u (e.g. the empty inscribed
+   * interval of a cuboid corridor, cuboid_3d.cc:677-689), an initial state outside segment 0's rows, a joint whose two
+   * sides share no value -- and the solve launch holds those only: no wavefront waits with an idle group, and the other
+   * axis of a candidate that is lost anyway is not solved.  Scheduling only for the candidates that are solved (same
+   * kernels, same bits); a candidate the pre-pass drops gets the status its solve would have reported, cost +inf, iters
+   * 0, and its control points are left untouched.  0 -> automatic (large ragged batches and large batches of the cuboid
+   * variant, where a quarter of the candidates of the bench workloads cannot start: -20 % time; elsewhere the pre-pass
+   * costs 1-2 %); 1 -> always; -1 -> never. */
+  int compact;
 } btrapz_options;
 /* Zeroes *opt (every field: "use the default") and sets struct_size.  Call it before filling the struct in. */
 void btrapz_options_init(btrapz_options *opt);

@@ -114,6 +114,8 @@ __global__ void prism_corridor_batch_short_kernel(const CorridorArgs a, int stag
 __global__ void prism_corridor_first_kernel(const CorridorArgs a, int staged);
 __global__ void prism_corridor_first_short_kernel(const CorridorArgs a, int staged);
 // fixed_S = 0: bucket by segment count (ragged batches); > 0: uniform batch of fixed_S segments, bucket by hint class
+// candidates that cannot start: keys[b] = 0 and their records written here (btrapz_options.compact; btrapz_kernels.hip)
+__global__ void prestart_kernel(const KernelArgs a, int S_uniform, const int *seg_count, int *keys);
 __global__ void bucket_hist_kernel(int B, int seg_stride, const int *seg_count, int *meta, int fixed_S);
 __global__ void bucket_prefix_kernel(int *meta, int fixed_S);
 __global__ void bucket_scatter_kernel(int B, int seg_stride, const int *seg_count, int *meta, int *order,
@@ -135,6 +137,7 @@ __global__ void ipm_solve_lean_kernel(const KernelArgs a, const double *__restri
 __global__ void ipm_solve_lean_hint_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void ipm_solve_lean_ragged_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void ipm_solve_lean_capped_kernel(const KernelArgs a, const double *__restrict__ mqm);
+__global__ void ipm_solve_lean_capped_hint_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void ipm_solve_lean_capped_ragged_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void ipm_solve_lean_resume_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void ipm_solve_lean_resume_ragged_kernel(const KernelArgs a, const double *__restrict__ mqm);

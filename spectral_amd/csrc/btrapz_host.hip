@@ -409,7 +409,28 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   if (elastic < 0 || elastic > 2) { c->err = "invalid argument: btrapz_options.elastic"; return BTRAPZ_EINVAL; }
   unsigned blocks;
   const int *hint = (warm && !seg_count) ? warm->hint : nullptr;   // uniform batches only
-  if (seg_count || hint) {
+  // Candidates that cannot start (btrapz_options.compact): a pre-pass lists the live ones, the launches below take them
+  // through a.order.  Cold solves without a rescue pass only (the rescue pass solves what stalled, axis by axis: it needs
+  // every axis's record); automatic for large ragged batches and large batches of the cuboid variant.
+  const bool warm_args = a.x0 || a.lam0 || a.lam_out;
+  const int compact_opt = opt ? opt->compact : 0;
+  const unsigned waves_needed = 2u * (unsigned)((size_t)B / (size_t)(64 / (S < 64 ? S : 64)) + 1);
+  const bool compact = elastic == 0 && !warm_args && !hint && (seg_count || S <= BTRAPZ_MAX_SEGMENTS) && a.unc_start == 0 &&
+                       (compact_opt > 0 || (compact_opt == 0 && (seg_count || sh->variant == BTRAPZ_CUBOID) && waves_needed >= 3u * (unsigned)c->resident_waves));
+  int *compact_keys = nullptr;
+  if (compact) {
+    if (2 * (size_t)B > c->rescue_cap) {   // (keys [B] at the front of the rescue pass's lists: no rescue pass in this solve)
+      (void)hipFree(c->d_rescue); c->d_rescue = nullptr; c->rescue_cap = 0;
+      HIPCHK(c, hipMalloc(&c->d_rescue, sizeof(int) * 4 * (size_t)B));
+      c->rescue_cap = 2 * (size_t)B;
+    }
+    compact_keys = c->d_rescue;
+    KernelArgs pa = a;
+    pa.seg_stride = S;
+    hipLaunchKernelGGL(prestart_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, stream, pa, seg_count ? 0 : S, seg_count, compact_keys);
+    HIPCHK(c, hipGetLastError());
+  }
+  if (seg_count || hint || compact) {
     if ((size_t)B > c->order_cap) {
       (void)hipFree(c->d_order); c->d_order = nullptr; c->order_cap = 0;
       HIPCHK(c, hipMalloc(&c->d_order, sizeof(int) * (size_t)B));
@@ -418,17 +439,21 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     if (!c->d_meta) HIPCHK(c, hipMalloc(&c->d_meta, sizeof(int) * 198));
     HIPCHK(c, hipMemsetAsync(c->d_meta, 0, sizeof(int) * 198, stream));
     const unsigned nb = (unsigned)((B + 255) / 256);
-    const int fixed_S = seg_count ? 0 : S;
-    const int *keys = seg_count ? seg_count : hint;
+    // keys: segment counts (ragged), hint classes (uniform, fixed_S > 0), or -- compact -- the pre-pass's list keys: the
+    // count / 1 of a live candidate, 0 for one that is not listed (uniform: fixed_S < 0, "a key <= 0 is not listed"); the
+    // pre-pass has written the records of what it dropped, so the scatter kernel writes none
+    const int fixed_S = seg_count ? 0 : (compact ? -S : S);
+    const int *keys = compact ? compact_keys : seg_count ? seg_count : hint;
     hipLaunchKernelGGL(bucket_hist_kernel, dim3(nb), dim3(256), 0, stream, B, S, keys, c->d_meta, fixed_S);
     hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(64), 0, stream, c->d_meta, fixed_S);
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nb), dim3(256), 0, stream, B, S, keys, c->d_meta, c->d_order,
-                       c->d_axis_obj, c->d_axis_status, c->d_axis_iters, fixed_S);
+                       compact ? (double *)nullptr : c->d_axis_obj, compact ? (int *)nullptr : c->d_axis_status,
+                       compact ? (int *)nullptr : c->d_axis_iters, fixed_S);
     HIPCHK(c, hipGetLastError());
     a.order = c->d_order; a.seg_count = seg_count; a.cand_prefix = c->d_meta; a.wave_prefix = c->d_meta + 66;
-    a.bucket_S = fixed_S;
+    a.bucket_S = seg_count ? 0 : S;
     // upper bound on wavefront pairs without a host round trip: every bucket wastes less than one pair
-    const int gpw_min = fixed_S ? 64 / fixed_S : 1;
+    const int gpw_min = seg_count ? 1 : 64 / S;
     blocks = 2u * (unsigned)(B / gpw_min + 65);
   } else {
     const int gpw = S <= 64 ? 64 / S : 1;  // axis problems per wavefront; wave w: axis w&1 of candidates (w>>1)*gpw + [0,gpw)
@@ -492,7 +517,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     // (S <= 32: a wavefront that holds ONE group has nobody to wait for -- with 33..64 segments every group would be
     //  "alone" at once and a quarter of the batch be written out and read back for nothing: ADVICE r4)
     if (cap_iter == 0 && !ragged && S >= 16 && S <= 32 && blocks >= 8u * (unsigned)c->resident_waves) cap_iter = 6;
-    const bool capped = cap_iter > 0 && !long_form && !split_on && (!a.order || ragged) && !warm_kernel && !queue_on && S <= BTRAPZ_MAX_SEGMENTS &&
+    const bool capped = cap_iter > 0 && !long_form && !split_on && (!a.order || ragged || compact) && !warm_kernel && !queue_on && S <= BTRAPZ_MAX_SEGMENTS &&
                         cap_iter < a.max_iter && cap_iter + BTRAPZ_CAP_HI < 4000 && elastic != 2;   // (4000: the lean record's 12-bit counters)
     // Workspace of the two launches: hand-over slots for a quarter of the axis problems (a group that finds none simply
     // goes on), 74 doubles per segment each -- 19 KB per slot at 64 segments, 388 MB for 65 536 candidates of 20 -- but
@@ -537,11 +562,14 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       KernelArgs p1 = a;
       p1.cap_iter = cap_iter; p1.cap_alone = BTRAPZ_CAP_ALONE; p1.cap_hi = cap_iter + BTRAPZ_CAP_HI; p1.cap_score = BTRAPZ_CAP_SCORE; p1.susp_cap = (int)slots; p1.susp_state = c->d_susp_state; p1.susp_count = count;
       p1.susp_slot = slot_of; p1.susp_key = keys;
+      // (a uniform batch that goes through a.order -- compact -- runs the instantiations WITHOUT the end-lane fix-up of
+      //  ragged batches: the bits of a candidate's result must not depend on whether the pre-pass ran)
       if (lean_on) {
         if (ragged) hipLaunchKernelGGL(ipm_solve_lean_capped_ragged_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+        else if (p1.order) hipLaunchKernelGGL(ipm_solve_lean_capped_hint_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
         else hipLaunchKernelGGL(ipm_solve_lean_capped_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
       } else {
-        if (ragged) hipLaunchKernelGGL(ipm_solve_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+        if (p1.order) hipLaunchKernelGGL(ipm_solve_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
         else hipLaunchKernelGGL(ipm_solve_capped_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
       }
       int *lists = c->d_rescue + 2 * (size_t)B;

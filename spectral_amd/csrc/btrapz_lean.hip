@@ -11,6 +11,7 @@ LEAN_INSTANCE(ipm_solve_lean_kernel, false, false, false, false)                
 LEAN_INSTANCE(ipm_solve_lean_hint_kernel, true, false, false, false)             // uniform, hint classes (btrapz_warm.hint)
 LEAN_INSTANCE(ipm_solve_lean_ragged_kernel, true, false, false, true)            // ragged (buckets by segment count)
 LEAN_INSTANCE(ipm_solve_lean_capped_kernel, false, true, false, false)           // first launch, uniform
+LEAN_INSTANCE(ipm_solve_lean_capped_hint_kernel, true, true, false, false)       // first launch, uniform, through a.order (btrapz_options.compact)
 LEAN_INSTANCE(ipm_solve_lean_capped_ragged_kernel, true, true, false, true)      // first launch, ragged
 LEAN_INSTANCE(ipm_solve_lean_resume_kernel, true, false, true, false)            // second launch, uniform
 LEAN_INSTANCE(ipm_solve_lean_resume_ragged_kernel, true, false, true, true)      // second launch, ragged

@@ -74,10 +74,15 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   const int m = S >> 1;
   const bool top = k < m, mid = k == m;
   const int my_step = top ? k : (k > m ? S - 1 - k : m);
-  // LEAN_BPERM: neighbour exchange of the sequential loops through ds_bpermute (lane_fetch, btrapz_ipm.h) -- byte addresses
-  // of the neighbour away from the root / towards it, and of both neighbours for the root's own step
+  // LEAN_BPERM (bit 0: the sweeps, bit 1: the factorisation): neighbour exchange of the sequential loops through
+  // ds_bpermute (lane_fetch, btrapz_ipm.h) instead of a DPP shift in each direction and an addition -- byte addresses of
+  // the neighbour away from the root / towards it, and of both neighbours for the root's own step.  MEASURED, round 5
+  // (tools/ab_variants.py, 65 536 candidates, results bit-identical): per step 18 / 6 LDS-pipe instructions replace 45 / 15
+  // vector-ALU ones, and the solve gets SLOWER -- scenario_1 x 20 two launches 4.05 -> 4.21 ms, generic 3.70 -> 3.85,
+  // cuboid 3.98 -> 4.13, 10 segments 1.65 -> 1.72: a crossbar fetch sits in the dependent chain of every step with
+  // ten times a DPP move's latency.  Off.  (Sweeps only / factorisation only: DESIGN 3.3.)
 #ifndef LEAN_BPERM
-#define LEAN_BPERM 1
+#define LEAN_BPERM 0
 #endif
   [[maybe_unused]] const int addr_prev = (lane - 1) << 2, addr_next = (lane + 1) << 2;
   [[maybe_unused]] const int addr_leaf = top ? addr_prev : addr_next, addr_root = top ? addr_next : addr_prev;
@@ -719,7 +724,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         }
       UNROLL for (int i = 0; i < 6; i++) TF[i] = T[i];
       SEQ_BEGIN();
-#if LEAN_BPERM
+#if LEAN_BPERM & 2
       if constexpr (!SMALL_S) {
         // One fetch per double from the neighbour AWAY from the root (lane_fetch: per-lane address through the LDS
         // crossbar) instead of a DPP shift in each direction and an addition: per step 18 LDS-pipe instructions for 45
@@ -834,7 +839,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     auto forward_u = [&](double (&u)[3]) {
       double w[3] = {0.0, 0.0, 0.0};
       SEQ_BEGIN();
-#if LEAN_BPERM
+#if LEAN_BPERM & 1
       if constexpr (!SMALL_S) {
         for (int step = 0; step < m; ++step) {
           double win[3];
@@ -875,7 +880,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       double y[3];
       UNROLL for (int i = 0; i < 3; i++) y[i] = mid ? dX[i] : 0.0;
       SEQ_BEGIN();
-#if LEAN_BPERM
+#if LEAN_BPERM & 1
       if constexpr (!SMALL_S) {
         for (int step = m - 1; step >= 0; --step) {   // (here a lane wants the neighbour TOWARDS the root)
           double xin[3];
@@ -966,8 +971,13 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     // the corrector's solve -- 210 vector instructions per iteration less and 108 B of scratch per lane more, of iterate
     // state spilled inside the sequential sweeps: 4.94 -> 5.33 ms on the scenario_1 batch, measured, rejected; 0: formed
     // in all three passes, the two maxima of E1 through LDS atomics.
+    // 3 (round 5, default): as 1, but what is kept from E1 to E2 is the multipliers' steps dlambda themselves -- E1 forms
+    // them for the dual step ratio anyway -- so that the update needs no reciprocal slack, no weight and no target at all:
+    // -15 v_rcp_f64 and ~110 multiplications per iteration.  Measured (tools/ab_variants.py, 65 536 candidates, 1 -> 3):
+    // scenario_1 x 20 two launches 4.05 -> 3.97 ms, generic 3.71 -> 3.64, cuboid 3.98 -> 3.90, 10 segments 1.65 -> 1.62;
+    // same accept sets, control points within 8e-7 of those of 1 (the steps are now rounded once, not twice).
 #ifndef LEAN_E_CACHE
-#define LEAN_E_CACHE 1
+#define LEAN_E_CACHE 3
 #endif
     double dc[6];
 #if LEAN_E_CACHE == 2
@@ -1002,7 +1012,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     // ---- E. step to the boundary, then the step ----
     {
       double pr = 0.0, dr = 0.0;
-#if LEAN_E_CACHE == 1
+#if LEAN_E_CACHE == 1 || LEAN_E_CACHE == 3
       double el_[NR], eu_[NR];
 #endif
 #if LEAN_E_CACHE == 2
@@ -1025,6 +1035,9 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           const double gd = row_dot<r>(dc, t);
           const double dsl = gd + rpl, dsu = -gd - rpu;
           const double dll = -el - wl * dsl, dlu = -eu - wu * dsu;
+#if LEAN_E_CACHE == 3   // the multipliers' steps themselves are kept for the update: it then needs no reciprocal at all
+          el_[SI(r)] = dll; eu_[SI(r)] = dlu;
+#endif
           pr = fmax(pr, fmax(-dsl * isl, -dsu * isu));
           const double rll_ = rcp_fast(ll * lu);
           dr = fmax(dr, fmax(-dll * (lu * rll_), -dlu * (ll * rll_)));
@@ -1060,6 +1073,19 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         PHASE_FENCE(opaque6(c); opaque6(dca); opaque6(dc); fence_slacks());
 #endif
         ROW_LIMITS();
+#if LEAN_E_CACHE == 3
+        FOR_ROWS(r)
+          ROW_SEP_R(r);
+          const double ll = LL(r), lu = LU(r);
+          const double s_l = sl[SI(r)], s_u = su[SI(r)];
+          const double gcr = row_dot<r>(c, t);
+          const double rpl = gcr - s_l - LLO(r), rpu = gcr + s_u - LUP(r);
+          const double gd = row_dot<r>(dc, t);
+          const double dsl = gd + rpl, dsu = -gd - rpu;
+          sl[SI(r)] = s_l + alpha_p * dsl; su[SI(r)] = s_u + alpha_p * dsu;
+          LL(r) = ll + alpha_d * el_[SI(r)]; LU(r) = lu + alpha_d * eu_[SI(r)];
+        END_ROWS
+#else
         FOR_ROWS(r)
           LROW(r, LEAN_RCP)
 #if LEAN_E_CACHE
@@ -1072,6 +1098,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           sl[SI(r)] = s_l + alpha_p * dsl; su[SI(r)] = s_u + alpha_p * dsu;
           LL(r) = ll + alpha_d * (-el - wl * dsl); LU(r) = lu + alpha_d * (-eu - wu * dsu);
         END_ROWS
+#endif
       }
     }
 #undef LROW

@@ -45,13 +45,13 @@ class COptions(C.Structure):
     """btrapz_options; struct_size is what btrapz_options_init() sets (the library rejects other layouts)."""
     _fields_ = [("struct_size", C.c_int), ("max_iter", C.c_int), ("eps", C.c_double), ("step_fraction", C.c_double),
                 ("step_threshold", C.c_double), ("elastic", C.c_int), ("elastic_tol", C.c_double),
-                ("elastic_delta", C.c_double), ("queue", C.c_int), ("split", C.c_int), ("start", C.c_int), ("cap_iter", C.c_int), ("lean", C.c_int)]
+                ("elastic_delta", C.c_double), ("queue", C.c_int), ("split", C.c_int), ("start", C.c_int), ("cap_iter", C.c_int), ("lean", C.c_int), ("compact", C.c_int)]
 
 
-def _options(max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, elastic_delta=0.0, queue=0, split=0, start=0, cap_iter=0, lean=0):
+def _options(max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, elastic_delta=0.0, queue=0, split=0, start=0, cap_iter=0, lean=0, compact=0):
     return COptions(C.sizeof(COptions), int(max_iter), float(eps), float(os.environ.get("BTRAPZ_STEP_FRACTION", "0")),
                     float(os.environ.get("BTRAPZ_STEP_THRESHOLD", "0")), int(elastic), float(elastic_tol),
-                    float(elastic_delta), int(queue), int(split), int(start), int(cap_iter), int(lean))
+                    float(elastic_delta), int(queue), int(split), int(start), int(cap_iter), int(lean), int(compact))
 
 
 class CWarm(C.Structure):
@@ -387,8 +387,8 @@ class Context:
 
     # ---- device-pointer path (torch tensors only carry the memory) --------------------------
     def solve_device(self, B, S, shared, seg, init, ref_end, dl_bounds, ctrl, cost, status, iters=None,
-                     stream=None, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, queue=0, split=0, start=0, cap_iter=0, lean=0):
-        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol, queue=queue, split=split, start=start, cap_iter=cap_iter, lean=lean)
+                     stream=None, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, queue=0, split=0, start=0, cap_iter=0, lean=0, compact=0):
+        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol, queue=queue, split=split, start=start, cap_iter=cap_iter, lean=lean, compact=compact)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self._check(lib().btrapz_solve_batch_device(self._h, C.byref(sh), C.byref(opt), B, S, ptr(seg), ptr(init),
                                                     ptr(ref_end), ptr(dl_bounds), ptr(ctrl), ptr(cost),
@@ -413,8 +413,8 @@ class Context:
         return call
 
     def solve_ragged_device(self, B, seg_stride, shared, seg, seg_count, init, ref_end, dl_bounds, ctrl, cost,
-                            status, iters=None, stream=None, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, cap_iter=0, lean=0):
-        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol, cap_iter=cap_iter, lean=lean)
+                            status, iters=None, stream=None, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, cap_iter=0, lean=0, compact=0):
+        sh = CShared.from_shared(shared); opt = _options(max_iter, eps, elastic, elastic_tol, cap_iter=cap_iter, lean=lean, compact=compact)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self._check(lib().btrapz_solve_ragged_device(self._h, C.byref(sh), C.byref(opt), B, seg_stride, ptr(seg),
                                                      ptr(seg_count), ptr(init), ptr(ref_end), ptr(dl_bounds),

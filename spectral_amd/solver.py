@@ -40,7 +40,7 @@ class BatchSolver:
         return self._out[key]
 
     def solve(self, dbatch, shared, max_iter=0, eps=0.0, out=None, warm=None, keep_multipliers=False, elastic=0,
-              elastic_tol=0.0, queue=0, split=0, start=0, cap_iter=0, lean=0):
+              elastic_tol=0.0, queue=0, split=0, start=0, cap_iter=0, lean=0, compact=0):
         """Launches the solve on torch's current stream; returns dict of device tensors.
 
         warm: dict with optional "x0" ([B,2,S,3] joint states, e.g. from eval_states) and "lam" ([2,36,B,S]
@@ -56,7 +56,7 @@ class BatchSolver:
             self.ctx.solve_device(dbatch.B, dbatch.S, shared, dbatch.seg, dbatch.init, dbatch.ref_end,
                                   dbatch.dl_bounds, o["ctrl"], o["cost"], o["status"], o["iters"], stream=stream,
                                   max_iter=max_iter, eps=eps, elastic=elastic, elastic_tol=elastic_tol, queue=queue,
-                                  split=split, start=start, cap_iter=cap_iter, lean=lean)
+                                  split=split, start=start, cap_iter=cap_iter, lean=lean, compact=compact)
             return o
         warm = warm or {}
         x0, lam0, hint = warm.get("x0"), warm.get("lam"), warm.get("hint")
@@ -171,7 +171,7 @@ class BatchSolver:
         rec["_inputs"] = ins
         return rec
 
-    def solve_ragged(self, rec, shared, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, cap_iter=0, lean=0):
+    def solve_ragged(self, rec, shared, max_iter=0, eps=0.0, elastic=0, elastic_tol=0.0, cap_iter=0, lean=0, compact=0):
         """Solve a ragged batch record (from corridor_batch); outputs stay on the device.  cap_iter:
         btrapz_options.cap_iter (0 automatic, -1 one launch, n two launches with hand-over after n iterations)."""
         d = self.device
@@ -182,7 +182,7 @@ class BatchSolver:
         stream = torch.cuda.current_stream(d).cuda_stream
         self.ctx.solve_ragged_device(B, st, shared, rec["seg"], rec["seg_count"], rec["init"], rec["ref_end"],
                                      rec["dl_bounds"], o["ctrl"], o["cost"], o["status"], o["iters"], stream=stream,
-                                     max_iter=max_iter, eps=eps, elastic=elastic, elastic_tol=elastic_tol, cap_iter=cap_iter, lean=lean)
+                                     max_iter=max_iter, eps=eps, elastic=elastic, elastic_tol=elastic_tol, cap_iter=cap_iter, lean=lean, compact=compact)
         return o
 
     def argmin(self, cost, group=None, index_base=0):
