@@ -317,6 +317,7 @@ def main():
                          "traffic": hbm["bytes_per_launch"] if hbm else None, "traffic_source": hbm_src,
                          "kernel": SOLVE_FORMS.get(solve_form, "btrapz::ipm_solve_kernel"), "kernel_ms": kernel_ms, "kernel_source_hash": kernel_stamp(),
                          "algorithmic_bytes_per_solve": batch.algorithmic_bytes(),
+                         "workspace_bytes": solver.ctx.workspace_bytes(),
                          "note": "on-chip solve: the binding resource is FP64 VALU issue + dependent sweeps, not HBM "
                                  "(SURVEY 8d); see fp64_valu" + ("; traffic above the algorithmic bytes is the iterate of the candidates the "
                                  "first launch hands to the second (69-74 doubles per segment, written once and read once, for the ~9 % of "

@@ -262,6 +262,10 @@ typedef struct btrapz_ctx btrapz_ctx;
 int btrapz_create(btrapz_ctx **ctx, int device);
 int btrapz_destroy(btrapz_ctx *ctx);
 const char *btrapz_last_error(const btrapz_ctx *ctx);
+/* Device memory (bytes) the context holds for its launches right now: it grows on demand and is kept.  The largest part is
+ * the hand-over workspace of the two-launch solve (btrapz_options.cap_iter): slots for 15 % of the axis problems, 74 doubles
+ * per segment each, at most 1 GiB. */
+long long btrapz_workspace_bytes(const btrapz_ctx *ctx);
 /* Number of HIP devices visible (0 when the runtime finds none). */
 int btrapz_device_count(void);
 /* 1 when the library was built with -DBTRAPZ_EXPERIMENTS (btrapz_options.queue / .start honoured, environment overrides of

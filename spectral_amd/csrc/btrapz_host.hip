@@ -93,7 +93,9 @@ static inline const char *experiment_env(const char *name) {
 #ifndef BTRAPZ_CAP_SCORE
 #define BTRAPZ_CAP_SCORE 0.0
 #endif
-#define BTRAPZ_SUSP_PERCENT 25
+// (round 5: 25 -> 15 % -- 8.5-12 % of the axis problems of the bench batches hand over; a group that finds no slot goes on
+//  to the end where it is, which costs time, never a result)
+#define BTRAPZ_SUSP_PERCENT 15
 #define BTRAPZ_SUSP_BYTES_MAX (1ull << 30)
 
 // Layout the lean kernels rely on (btrapz_lean_body.h reads the row limits of its axis as (&sh.acc_s[0])[2 axis + i],
@@ -199,6 +201,21 @@ BTRAPZ_EXPORT int btrapz_destroy(btrapz_ctx *c) {
 }
 
 BTRAPZ_EXPORT const char *btrapz_last_error(const btrapz_ctx *c) { return c ? c->err.c_str() : "null context"; }
+// Device memory the context holds for its launches right now (it grows on demand and is kept): per-axis records, bucket
+// tables and lists, the hand-over workspace of the two-launch solve, staging of the host-pointer wrapper.
+BTRAPZ_EXPORT long long btrapz_workspace_bytes(const btrapz_ctx *c) {
+  if (!c) return 0;
+  size_t n = 0;
+  n += c->axis_cap * (sizeof(double) * 5 + sizeof(int) * 2);
+  n += sizeof(double) * 168 + sizeof(int) * 2;
+  n += c->order_cap * sizeof(int) + (c->d_meta ? 198 * sizeof(int) : 0) + c->retry_cap * sizeof(int) + c->strip_cap;
+  n += c->argmin_cap * (sizeof(double) + sizeof(long long));
+  n += c->rescue_cap * 2 * sizeof(int) + (c->d_rescue_meta ? 2 * 198 * sizeof(int) : 0);
+  n += c->stage_cap * sizeof(double) + c->istage_cap * sizeof(int);
+  n += (c->d_single ? sizeof(double) * 12 * BTRAPZ_MAX_SEGMENTS : 0) + (c->d_single_warm ? sizeof(double) * 2 * (2 * 64 * 3 + 2 * 36 * 64) : 0);
+  n += c->susp_state_doubles * sizeof(double) + c->susp_ints * sizeof(int);
+  return (long long)n;
+}
 BTRAPZ_EXPORT int btrapz_last_solve_form(const btrapz_ctx *c) { return c ? c->last_form : -1; }
 
 static int ensure_axis_ws(btrapz_ctx *c, size_t nprob) {
@@ -415,7 +432,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   const bool warm_args = a.x0 || a.lam0 || a.lam_out;
   const int compact_opt = opt ? opt->compact : 0;
   const unsigned waves_needed = 2u * (unsigned)((size_t)B / (size_t)(64 / (S < 64 ? S : 64)) + 1);
-  const bool compact = elastic == 0 && !warm_args && !hint && (seg_count || S <= BTRAPZ_MAX_SEGMENTS) && a.unc_start == 0 &&
+  const bool compact = elastic == 0 && !warm_args && !hint && S <= BTRAPZ_MAX_SEGMENTS && a.unc_start == 0 &&
                        (compact_opt > 0 || (compact_opt == 0 && (seg_count || sh->variant == BTRAPZ_CUBOID) && waves_needed >= 3u * (unsigned)c->resident_waves));
   int *compact_keys = nullptr;
   if (compact) {
@@ -427,7 +444,8 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     compact_keys = c->d_rescue;
     KernelArgs pa = a;
     pa.seg_stride = S;
-    hipLaunchKernelGGL(prestart_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, stream, pa, seg_count ? 0 : S, seg_count, compact_keys);
+    const int pre_gpw = 64 / S;   // (S: the slot stride, at most 64 here)
+    hipLaunchKernelGGL(prestart_kernel, dim3((unsigned)((B + pre_gpw - 1) / pre_gpw)), dim3(64), 0, stream, pa, seg_count ? 0 : S, seg_count, compact_keys);
     HIPCHK(c, hipGetLastError());
   }
   if (seg_count || hint || compact) {
@@ -519,7 +537,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     if (cap_iter == 0 && !ragged && S >= 16 && S <= 32 && blocks >= 8u * (unsigned)c->resident_waves) cap_iter = 6;
     const bool capped = cap_iter > 0 && !long_form && !split_on && (!a.order || ragged || compact) && !warm_kernel && !queue_on && S <= BTRAPZ_MAX_SEGMENTS &&
                         cap_iter < a.max_iter && cap_iter + BTRAPZ_CAP_HI < 4000 && elastic != 2;   // (4000: the lean record's 12-bit counters)
-    // Workspace of the two launches: hand-over slots for a quarter of the axis problems (a group that finds none simply
+    // Workspace of the two launches: hand-over slots for BTRAPZ_SUSP_PERCENT of the axis problems (a group that finds none simply
     // goes on), 74 doubles per segment each -- 19 KB per slot at 64 segments, 388 MB for 65 536 candidates of 20 -- but
     // never more than BTRAPZ_SUSP_BYTES_MAX.  When the device cannot give it, a solve that chose the two launches by
     // itself (cap_iter = 0) runs as one launch; one that was asked for them (cap_iter > 0) fails with BTRAPZ_ENOMEM.

@@ -1326,8 +1326,8 @@ __global__ __launch_bounds__(64) void ipm_solve_elastic_kernel(const KernelArgs 
 // empty inscribed interval (cuboid_3d.cc:677-689), an initial state outside segment 0's rows, a joint whose two sides
 // share no value -- what the set-up of the solve kernels checks.  Left in the launch they cost twice: their groups idle
 // in wavefronts that wait for the live ones, and the OTHER axis of such a candidate is solved in full although the
-// candidate is lost (cuboid: the s axis is dead, the l axis runs its eight iterations).  This pre-pass -- one thread per
-// candidate, both axes, a walk over the segments -- lists the live candidates (keys for the bucket kernels: 0 = dead) and
+// candidate is lost (cuboid: the s axis is dead, the l axis runs its eight iterations).  This pre-pass -- one lane per
+// segment slot, both axes -- lists the live candidates (keys for the bucket kernels: 0 = dead) and
 // writes the dead ones' records itself, so that the solve launch holds live groups only.
 // It applies the kernels' own tests with DOUBLED tolerances (a row with l > u by more than 2e-12 relative to nothing, a
 // joint empty by more than 2e-9, an initial state outside by more than 2e-7): a candidate it passes as live that the
@@ -1335,86 +1335,94 @@ __global__ __launch_bounds__(64) void ipm_solve_elastic_kernel(const KernelArgs 
 // the two can never disagree about a solvable candidate, whatever the compiler contracts into fused multiply-adds.
 // Status: BTRAPZ_PRIMAL_INFEASIBLE / BTRAPZ_MAX_ITER_REACHED for the axis that is dead, exactly what its solve would
 // report; 0 for an axis that was not looked at further (the finalize kernel takes the most severe code).
-__global__ void prestart_kernel(const KernelArgs a, int S_uniform, const int *seg_count, int *keys) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
+__global__ __launch_bounds__(64) void prestart_kernel(const KernelArgs a, int S_uniform, const int *seg_count, int *keys) {
+  // lane = (candidate of the wavefront, slot): floor(64 / seg_stride) candidates per wavefront, every field load 8 contiguous
+  // bytes per lane as in the solve kernels; the joint's other side comes from the next lane, the verdict of a candidate's
+  // lanes through a ballot
+  const int lane = threadIdx.x, stride = a.seg_stride, gpw = 64 / stride;
+  const int g = lane / stride, k = lane - g * stride;
+  const long long cand = (long long)blockIdx.x * gpw + g;
+  const bool in_wave = g < gpw && cand < a.B;
+  const int b = in_wave ? (int)cand : a.B - 1;
   int S = S_uniform;
-  if (seg_count) {
-    S = seg_count[b];
-    if (S < 1 || S > 64 || S > a.seg_stride) {   // no usable corridor (what bucket_scatter_kernel writes for these)
-      keys[b] = 0;
-      a.axis_obj[2 * b] = 0.0; a.axis_obj[2 * b + 1] = 0.0;
-      a.axis_status[2 * b] = BTRAPZ_NO_CORRIDOR; a.axis_status[2 * b + 1] = BTRAPZ_NO_CORRIDOR;
-      a.axis_iters[2 * b] = 0; a.axis_iters[2 * b + 1] = 0;
-      return;
-    }
-  }
-  const size_t BS = (size_t)a.B * a.seg_stride;
+  bool usable = true;
+  if (seg_count) { S = seg_count[b]; usable = S >= 1 && S <= 64 && S <= stride; }
+  const bool act = in_wave && usable && k < S;
+  const bool first = k == 0, last = k == S - 1;
+  const size_t BS = (size_t)a.B * stride;
   const double *sg = a.seg;
   const Shared &sh = a.sh;
+  const size_t e_ = (size_t)b * stride + (act ? k : 0);
+  const double t = sg[BTRAPZ_F_T * BS + e_];
   int st_axis[2] = {0, 0};
+  const unsigned long long gmask = (stride >= 64 ? ~0ull : ((1ull << stride) - 1ull)) << (g < gpw ? g * stride : 0);
   for (int axis = 0; axis < 2; axis++) {
-    bool dead3 = false, dead2 = false;
-    double gapmin = 1e300;
-    // the end of the previous segment: its last rows, and whether they are consistent by themselves
-    double pmplo = 0.0, pmphi = 0.0, pmvlo = 0.0, pmvhi = 0.0;
-    bool p_ok = false;
-    for (int k = 0; k < S; k++) {
-      const size_t e_ = (size_t)b * a.seg_stride + k;
-      const double t = sg[BTRAPZ_F_T * BS + e_];
-      double lb, ls, ub, us, vlo[5], vhi[5];
-      if (axis == 0) {
-        lb = sg[BTRAPZ_F_DOWN_BIAS * BS + e_]; ls = sg[BTRAPZ_F_DOWN_SKEW * BS + e_];
-        ub = sg[BTRAPZ_F_UPP_BIAS * BS + e_];  us = sg[BTRAPZ_F_UPP_SKEW * BS + e_];
-        const double lo = sg[BTRAPZ_F_DS_LO * BS + e_], hi = sg[BTRAPZ_F_DS_HI * BS + e_];
-        UNROLL for (int i = 0; i < 5; i++) { vlo[i] = lo; vhi[i] = hi; }
-      } else {
-        lb = sg[BTRAPZ_F_L_DOWN_BIAS * BS + e_]; ls = sg[BTRAPZ_F_L_DOWN_SKEW * BS + e_];
-        ub = sg[BTRAPZ_F_L_UPP_BIAS * BS + e_];  us = sg[BTRAPZ_F_L_UPP_SKEW * BS + e_];
-        UNROLL for (int i = 0; i < 5; i++) { vlo[i] = a.dl_bounds[(size_t)b * 10 + 2 * i]; vhi[i] = a.dl_bounds[(size_t)b * 10 + 2 * i + 1]; }
-      }
-      double plo0 = lb, dplo = ls * 0.2 * t, phi0 = ub, dphi = us * 0.2 * t;
-      if (sh.variant == BTRAPZ_CUBOID) {
-        if (axis == 0) {
-          plo0 = fmax(0.0, fmax(ls * 0.0 + lb, lb + ls * t));
-          phi0 = fmin(100.0, fmin(us * 0.0 + ub, ub + us * t));
-        } else {
-          plo0 = sg[BTRAPZ_F_BEG_L * BS + e_]; phi0 = sg[BTRAPZ_F_END_L * BS + e_];
-        }
-        dplo = 0.0; dphi = 0.0;
-      }
-      (void)move_far_bounds(plo0, dplo, phi0, dphi, vlo, vhi);
-      const double alo = (axis == 0 ? sh.acc_s[0] : sh.acc_l[0]) * t, ahi = (axis == 0 ? sh.acc_s[1] : sh.acc_l[1]) * t;
-      const double jlo = (axis == 0 ? sh.jerk_s[0] : sh.jerk_l[0]) * t * t, jhi = (axis == 0 ? sh.jerk_s[1] : sh.jerk_l[1]) * t * t;
-      // rows with l > u (all 18 of the reference): the kernels allow 1e-12, this pass 2e-12 and one part in 1e12
-      UNROLL for (int r = 0; r < 6; r++) {
-        const double lo = plo0 + (double)r * dplo, up = phi0 + (double)r * dphi;
-        gapmin = fmin(gapmin, (up - lo) + 2e-12 + 1e-12 * fmax(fabs(lo), fabs(up)));
-      }
-      UNROLL for (int r = 0; r < 5; r++) gapmin = fmin(gapmin, (vhi[r] - vlo[r]) + 2e-12 + 1e-12 * fmax(fabs(vlo[r]), fabs(vhi[r])));
-      gapmin = fmin(gapmin, (ahi - alo) + 2e-12 + 1e-12 * fmax(fabs(alo), fabs(ahi)));
-      gapmin = fmin(gapmin, (jhi - jlo) + 2e-12 + 1e-12 * fmax(fabs(jlo), fabs(jhi)));
-      if (k == 0 && !(t > 0.0)) dead3 = true;   // (the record's first lane decides the status: see the write-back of the kernels)
-      const double mplo = plo0 + 5.0 * dplo, mphi = phi0 + 5.0 * dphi, mvlo = vlo[4], mvhi = vhi[4];
-      if (k > 0) {   // the joint between segment k - 1 and this one
-        const bool own_ok = p_ok && plo0 <= phi0 && vlo[0] <= vhi[0];
-        const double jlo_ = fmax(pmplo, plo0), jhi_ = fmin(pmphi, phi0), jvl = fmax(pmvlo, vlo[0]), jvh = fmin(pmvhi, vhi[0]);
-        const double ptol = 2e-9 * (1.0 + fmax(fabs(jlo_), fabs(jhi_))), vtol = 2e-9 * (1.0 + fmax(fabs(jvl), fabs(jvh)));
-        if (own_ok && (jlo_ > jhi_ + ptol || jvl > jvh + vtol)) dead2 = true;
-      } else {       // segment 0's first rows state the given initial state
-        const double it = 1.0 / t, t20 = t * 0.05;
-        const double X0 = a.init[(size_t)b * 6 + axis * 3], X1 = a.init[(size_t)b * 6 + axis * 3 + 1], X2 = a.init[(size_t)b * 6 + axis * 3 + 2];
-        const double c0 = it * X0, c1 = c0 + 0.2 * X1, c2 = c0 + 0.4 * X1 + t20 * X2;
-        auto outside = [&](double g_, double lo, double hi) {
-          const double tol = 2e-7 * (1.0 + fmax(fabs(lo), fabs(hi)));
-          return g_ < lo - tol || g_ > hi + tol;   // (a value that is not finite is left to the kernel)
-        };
-        if (t > 0.0 && (outside(t * c0, plo0, phi0) || outside(5.0 * (c1 - c0), vlo[0], vhi[0]) || outside(20.0 * ((c0 - 2.0 * c1) + c2), alo, ahi))) dead2 = true;
-      }
-      pmplo = mplo; pmphi = mphi; pmvlo = mvlo; pmvhi = mvhi; p_ok = mplo <= mphi && mvlo <= mvhi;
+    double lb, ls, ub, us, vlo[5], vhi[5];
+    if (axis == 0) {
+      lb = sg[BTRAPZ_F_DOWN_BIAS * BS + e_]; ls = sg[BTRAPZ_F_DOWN_SKEW * BS + e_];
+      ub = sg[BTRAPZ_F_UPP_BIAS * BS + e_];  us = sg[BTRAPZ_F_UPP_SKEW * BS + e_];
+      const double lo = sg[BTRAPZ_F_DS_LO * BS + e_], hi = sg[BTRAPZ_F_DS_HI * BS + e_];
+      UNROLL for (int i = 0; i < 5; i++) { vlo[i] = lo; vhi[i] = hi; }
+    } else {
+      lb = sg[BTRAPZ_F_L_DOWN_BIAS * BS + e_]; ls = sg[BTRAPZ_F_L_DOWN_SKEW * BS + e_];
+      ub = sg[BTRAPZ_F_L_UPP_BIAS * BS + e_];  us = sg[BTRAPZ_F_L_UPP_SKEW * BS + e_];
+      UNROLL for (int i = 0; i < 5; i++) { vlo[i] = a.dl_bounds[(size_t)b * 10 + 2 * i]; vhi[i] = a.dl_bounds[(size_t)b * 10 + 2 * i + 1]; }
     }
-    if (gapmin < 0.0) dead3 = true;
-    st_axis[axis] = dead3 ? BTRAPZ_PRIMAL_INFEASIBLE : dead2 ? BTRAPZ_MAX_ITER_REACHED : 0;
+    double plo0 = lb, dplo = ls * 0.2 * t, phi0 = ub, dphi = us * 0.2 * t;
+    if (sh.variant == BTRAPZ_CUBOID) {
+      if (axis == 0) {
+        plo0 = fmax(0.0, fmax(ls * 0.0 + lb, lb + ls * t));
+        phi0 = fmin(100.0, fmin(us * 0.0 + ub, ub + us * t));
+      } else {
+        plo0 = sg[BTRAPZ_F_BEG_L * BS + e_]; phi0 = sg[BTRAPZ_F_END_L * BS + e_];
+      }
+      dplo = 0.0; dphi = 0.0;
+    }
+    (void)move_far_bounds(plo0, dplo, phi0, dphi, vlo, vhi);
+    const double alo = (axis == 0 ? sh.acc_s[0] : sh.acc_l[0]) * t, ahi = (axis == 0 ? sh.acc_s[1] : sh.acc_l[1]) * t;
+    const double jlo = (axis == 0 ? sh.jerk_s[0] : sh.jerk_l[0]) * t * t, jhi = (axis == 0 ? sh.jerk_s[1] : sh.jerk_l[1]) * t * t;
+    // rows with l > u (all 18 of the reference): the kernels allow 1e-12, this pass 2e-12 and one part in 1e12
+    double gapmin = 1e300;
+    UNROLL for (int r = 0; r < 6; r++) {
+      const double lo = plo0 + (double)r * dplo, up = phi0 + (double)r * dphi;
+      gapmin = fmin(gapmin, (up - lo) + 2e-12 + 1e-12 * fmax(fabs(lo), fabs(up)));
+    }
+    UNROLL for (int r = 0; r < 5; r++) gapmin = fmin(gapmin, (vhi[r] - vlo[r]) + 2e-12 + 1e-12 * fmax(fabs(vlo[r]), fabs(vhi[r])));
+    gapmin = fmin(gapmin, (ahi - alo) + 2e-12 + 1e-12 * fmax(fabs(alo), fabs(ahi)));
+    gapmin = fmin(gapmin, (jhi - jlo) + 2e-12 + 1e-12 * fmax(fabs(jlo), fabs(jhi)));
+    bool dead3 = gapmin < 0.0 || (first && !(t > 0.0));   // (the record's first lane decides on t: see the write-back of the kernels)
+    bool dead2 = false;
+    // the joint at the end of this segment: its last rows against the next segment's first ones
+    const double mplo = plo0 + 5.0 * dplo, mphi = phi0 + 5.0 * dphi, mvlo = vlo[4], mvhi = vhi[4];
+    {
+      const double nplo = dpp_next(plo0), nphi = dpp_next(phi0), nvlo = dpp_next(vlo[0]), nvhi = dpp_next(vhi[0]);
+      if (!last) {
+        const bool own_ok = mplo <= mphi && mvlo <= mvhi && nplo <= nphi && nvlo <= nvhi;
+        const double jl = fmax(mplo, nplo), jh = fmin(mphi, nphi), jvl = fmax(mvlo, nvlo), jvh = fmin(mvhi, nvhi);
+        const double ptol = 2e-9 * (1.0 + fmax(fabs(jl), fabs(jh))), vtol = 2e-9 * (1.0 + fmax(fabs(jvl), fabs(jvh)));
+        dead2 = own_ok && (jl > jh + ptol || jvl > jvh + vtol);
+      }
+    }
+    if (first && t > 0.0) {   // segment 0's first rows state the given initial state
+      const double it = 1.0 / t, t20 = t * 0.05;
+      const double X0 = a.init[(size_t)b * 6 + axis * 3], X1 = a.init[(size_t)b * 6 + axis * 3 + 1], X2 = a.init[(size_t)b * 6 + axis * 3 + 2];
+      const double c0 = it * X0, c1 = c0 + 0.2 * X1, c2 = c0 + 0.4 * X1 + t20 * X2;
+      auto outside = [&](double g_, double lo, double hi) {
+        const double tol = 2e-7 * (1.0 + fmax(fabs(lo), fabs(hi)));
+        return g_ < lo - tol || g_ > hi + tol;   // (a value that is not finite is left to the kernel)
+      };
+      if (outside(t * c0, plo0, phi0) || outside(5.0 * (c1 - c0), vlo[0], vhi[0]) || outside(20.0 * ((c0 - 2.0 * c1) + c2), alo, ahi)) dead2 = true;
+    }
+    const bool any3 = (__ballot(act && dead3) & gmask) != 0, any2 = (__ballot(act && dead2) & gmask) != 0;
+    st_axis[axis] = any3 ? BTRAPZ_PRIMAL_INFEASIBLE : any2 ? BTRAPZ_MAX_ITER_REACHED : 0;
+  }
+  if (!in_wave || !first) return;
+  if (!usable) {   // no usable corridor (what bucket_scatter_kernel writes for these)
+    keys[b] = 0;
+    a.axis_obj[2 * b] = 0.0; a.axis_obj[2 * b + 1] = 0.0;
+    a.axis_status[2 * b] = BTRAPZ_NO_CORRIDOR; a.axis_status[2 * b + 1] = BTRAPZ_NO_CORRIDOR;
+    a.axis_iters[2 * b] = 0; a.axis_iters[2 * b + 1] = 0;
+    return;
   }
   const bool dead = st_axis[0] != 0 || st_axis[1] != 0;
   keys[b] = dead ? 0 : (seg_count ? S : 1);

@@ -126,7 +126,7 @@ EXPORTS = ("btrapz_corridor_from_file", "btrapz_find_traj", "btrapz_create", "bt
            "btrapz_find_traj_last_iterations", "btrapz_argmin_pairs_device", "btrapz_options_init",
            "btrapz_rescue_violations_device", "btrapz_find_traj_last_status", "btrapz_debug_mqm_tables",
            "btrapz_debug_axis_records", "btrapz_debug_resume_keys", "btrapz_debug_parse_double", "btrapz_debug_format_fixed",
-           "btrapz_last_solve_form", "btrapz_build_has_experiments",
+           "btrapz_last_solve_form", "btrapz_build_has_experiments", "btrapz_workspace_bytes",
            "btrapz_multi_create", "btrapz_multi_destroy", "btrapz_multi_last_error", "btrapz_multi_transport",
            "btrapz_multi_transport_library", "btrapz_multi_device_count", "btrapz_multi_shard_bounds", "btrapz_multi_upload",
            "btrapz_multi_set_shards", "btrapz_multi_solve_argmin", "btrapz_multi_result", "btrapz_multi_wait",
@@ -200,6 +200,7 @@ def lib():
         l.btrapz_options_init.argtypes = [C.POINTER(COptions)]; l.btrapz_options_init.restype = None
         l.btrapz_rescue_violations_device.argtypes = [vp, C.c_int, dp, vp]
         l.btrapz_last_solve_form.argtypes = [vp]; l.btrapz_last_solve_form.restype = C.c_int
+        l.btrapz_workspace_bytes.argtypes = [vp]; l.btrapz_workspace_bytes.restype = C.c_longlong
         l.btrapz_debug_mqm_tables.argtypes = [vp, C.POINTER(CShared), dp, dp]
         l.btrapz_solve_batch_device.argtypes = [vp, C.POINTER(CShared), C.POINTER(COptions), C.c_int, C.c_int,
                                                 dp, dp, dp, dp, dp, dp, ip, ip, vp]
@@ -433,6 +434,10 @@ class Context:
                                                    ptr(seg), ptr(seg_count), ptr(init), ptr(ref_end), ptr(dl_bounds),
                                                    ptr(ctrl), ptr(cost), ptr(status), ptr(iters),
                                                    C.c_void_p(stream or 0)), "btrapz_solve_warm_device")
+
+    def workspace_bytes(self):
+        """btrapz_workspace_bytes: device memory the context holds for its launches right now."""
+        return int(lib().btrapz_workspace_bytes(self._h))
 
     def last_solve_form(self):
         """btrapz_last_solve_form: 0 packed, 1 split, 2 long, 3 capped + resume, 4 queue; + 8: the two-wavefronts-per-SIMD form."""

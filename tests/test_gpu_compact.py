@@ -84,9 +84,9 @@ def test_compaction_on_ragged_batches(solver):
     from spectral_amd import knots
     gold = os.path.join(os.path.dirname(__file__), "golden", "inputs")
     W = np.loadtxt(os.path.join(gold, "weights.txt"))
-    for name, variant in (("c_road_s1_3", 0), ("c_road_s1_3", 1), ("c1", 1)):
+    for name, variant in (("c_road_s1_3", 0), ("c2", 1), ("c1", 1)):    # (c_road_s1_3 has no cuboid corridor at all)
         kb = knots.jittered(knots.parse_corridor_file(os.path.join(gold, name + ".txt")), 4096, seed=21, s_shift=1.0)
-        kb.init[::7, 0] += 40.0                                   # every seventh ego starts outside its corridor
+        kb.init[::7, 3] += 40.0                                   # every seventh ego starts outside its (lateral) corridor
         sh = synth.shared_params(variant, weights=W)
         sh.ds_ref, sh.dl_ref = kb.header["ds_ref"], kb.header["dl_ref"]
         sh.dds, sh.ddds, sh.ddl, sh.dddl = kb.header["dds"], kb.header["ddds"], kb.header["ddl"], kb.header["dddl"]
