@@ -37,6 +37,8 @@ def weight_rows(seed, nrand):
         t = line.split()
         if len(t) == 10:
             rows.append(("file", [float(v) for v in t]))
+    every = int(os.environ.get("WFT_FILE_ROW_STRIDE", "1"))      # (the driver suite's slice: every n-th row of the trial log)
+    rows = rows[::every]
     rng = np.random.default_rng(1000 + seed)
     for r in rng.uniform(0.0, 50.0, (nrand, 10)):
         rows.append(("rand", [float(v) for v in r]))
@@ -217,7 +219,8 @@ def main():
                               (split, name, variant, i, kind, err, tol, st, it, rec["iters"], [round(v, 3) for v in w]), flush=True)
             print("  split=%s %s done: %d calls, %.1f s, decisions apart %d, beyond tolerance %d" %
                   (split, name, tally["calls"], time.time() - t0, tally["decisions_apart"], tally["xstar_beyond"]), flush=True)
-    print("weights sweep (find_traj): inputs", INPUTS, "rows", len(rows), "(204 file + %d random + %d degenerate/corner)" % (NRAND, len(rows) - 204 - NRAND),
+    nfile = sum(1 for k, _ in rows if k == "file")
+    print("weights sweep (find_traj): inputs", INPUTS, "rows", len(rows), "(%d file + %d random + %d degenerate/corner)" % (nfile, NRAND, len(rows) - nfile - NRAND),
           "elastic", ELASTIC)
     print("  ", tally)
     print("   worst relative deviation from x*:", {k: "%.2e" % v for k, v in worst.items()}, "at", worst_at)

@@ -45,6 +45,16 @@ for group in \
   step "$name" "$OUT/$name.json" rocprofv3 --pmc $group --output-format csv -d "$OUT/$name" -- python3 "$BENCH" $PMC_ARGS
 done
 
+# L2 behaviour of the solve kernels (round 5: how much of the lean form's scratch re-reads and second record reads reach
+# HBM).  Optional: counter names differ between rocprofv3 releases -- a failure here is noted, not fatal.
+for group in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"; do
+  name=pmc_opt_$(echo "$group" | tr ' ' '+' | cut -c1-60)
+  # shellcheck disable=SC2086
+  if ! rocprofv3 --pmc $group --output-format csv -d "$OUT/$name" -- python3 "$BENCH" $PMC_ARGS > "$OUT/$name.json" 2> "$OUT/$name.err"; then
+    echo "optional counter group not collected: $group" >> "$OUT/optional_missing.txt"
+  fi
+done
+
 # FETCH_SIZE / WRITE_SIZE calibration in the solve kernel's access widths (tools/fetch_calib.hip)
 if /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/fetch_calib "$ROOT/tools/fetch_calib.hip" 2> "$OUT/calib_build.err"; then
   for mode in 8 16; do

@@ -40,6 +40,7 @@ def main(argv=None):
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--oracle", type=int, default=96, help="candidates per batch compared with the oracle's exact solve")
     ap.add_argument("--cases", default="0,1,2,3")
+    ap.add_argument("--caps", default="", help="further hand-over points of the lean two-launch solve to time, e.g. 3,4,8 (strong-scaling shard sizes)")
     a = ap.parse_args(argv)
     solver = BatchSolver(0)
     dev = torch.device("cuda:0")
@@ -60,6 +61,9 @@ def main(argv=None):
             runs[name] = res
             rec[name] = {"solve_ms": ms, "form": form, "mean_iterations": float(res["iters"].mean() + 1),
                          "solved_fraction": float((res["status"] > 0).mean())}
+        for cap in [int(x) for x in a.caps.split(",") if x]:
+            ms, res, form = timed(solver, dev, db, sh, a.reps, lean=1, cap_iter=cap)
+            rec["lean_two_launches_cap%d" % cap] = {"solve_ms": ms, "form": form}
         ref = runs["packed_one_launch"]
         ok = ref["status"] > 0
         for name in ("lean_one_launch", "lean_two_launches", "packed_two_launches"):
