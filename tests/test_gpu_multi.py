@@ -204,6 +204,25 @@ print("nccl world 1 ok")
     assert p.returncode == 0 and "nccl world 1 ok" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
 
 
+def test_a_plain_c_host_program_over_the_c_abi():
+    """spectral_amd/csrc/host_check/multi_host_demo.c: no Python, no torch in the process -- gcc -std=c99, linked against
+    libbtrapz_hip.so and the system HIP runtime like the drop-in libraries.  One device, three logical devices (copies) and
+    RCCL at one rank: the same winner, cost and control points, printed with 17 digits."""
+    import subprocess
+    exe = os.path.join(native.LIB_DIR, "multi_host_demo")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", native.CSRC_DIR, "multi_demo"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = []
+    for args in (["1", "0"], ["1", "0", "0", "0"], ["2", "0"], ["0", "0", "0"]):
+        p = subprocess.run([exe, "3000", "12"] + args, capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode == 0, (args, p.stdout, p.stderr[-800:])
+        outs.append(p.stdout.split())
+    f = lambda o: (o[1], o[3], o[7], o[9])          # winner, cost, two control points
+    assert f(outs[0]) == f(outs[1]) == f(outs[2]) == f(outs[3]) and int(outs[0][1]) >= 0
+    assert [o[5] for o in outs] == ["1", "1", "2", "1"]                 # transports: copies, copies, RCCL, auto -> copies (an ordinal repeats)
+
+
 def test_argument_errors():
     with pytest.raises(native.BtrapzError):
         native.MultiContext([5])                       # no such device on this box
