@@ -217,7 +217,9 @@ def test_a_plain_c_host_program_over_the_c_abi():
     for args in (["1", "0"], ["1", "0", "0", "0"], ["2", "0"], ["0", "0", "0"]):
         p = subprocess.run([exe, "3000", "12"] + args, capture_output=True, text=True, env=env, timeout=300)
         assert p.returncode == 0, (args, p.stdout, p.stderr[-800:])
-        outs.append(p.stdout.split())
+        line = [l for l in p.stdout.splitlines() if l.startswith("winner ")]      # (RCCL prints its version banner to stdout)
+        assert len(line) == 1, p.stdout
+        outs.append(line[0].split())
     f = lambda o: (o[1], o[3], o[7], o[9])          # winner, cost, two control points
     assert f(outs[0]) == f(outs[1]) == f(outs[2]) == f(outs[3]) and int(outs[0][1]) >= 0
     assert [o[5] for o in outs] == ["1", "1", "2", "1"]                 # transports: copies, copies, RCCL, auto -> copies (an ordinal repeats)
