@@ -84,6 +84,13 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 #ifndef LEAN_BPERM
 #define LEAN_BPERM 0
 #endif
+  // (timing experiments only: -DLEAN_HALF_STEPS runs half the steps of every sequential loop -- wrong results, the cost of
+  //  an elimination that needed half as many: DESIGN 3.3)
+#ifdef LEAN_HALF_STEPS
+#define LEAN_STEPS_HI(m_) (((m_) + 1) / 2)
+#else
+#define LEAN_STEPS_HI(m_) (m_)
+#endif
   [[maybe_unused]] const int addr_prev = (lane - 1) << 2, addr_next = (lane + 1) << 2;
   [[maybe_unused]] const int addr_leaf = top ? addr_prev : addr_next, addr_root = top ? addr_next : addr_prev;
   const Shared &sh = a.sh;
@@ -635,6 +642,9 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         }
       }
     }
+#ifdef LEAN_FIXED_ITERS   // (timing experiments only: every group runs exactly this many iterations, whatever its iterate does)
+    done = !valid || eit >= LEAN_FIXED_ITERS;
+#endif
     if (__all(done)) break;
     if constexpr (WARM) {
       if (__any(restart_now)) {
@@ -780,7 +790,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         }
       } else
 #endif
-      for (int step = 0; step <= m; ++step) {
+      for (int step = 0; step <= LEAN_STEPS_HI(m); ++step) {
         double zin[6], win[3];
         if constexpr (SMALL_S) {
           double pz[6], nz[6], pw[3], nw[3];
@@ -854,7 +864,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         UNROLL for (int i = 0; i < 3; i++) { const double win = lane_fetch(addr_prev, w[i]) + lane_fetch(addr_next, w[i]); u[i] -= mid ? win : 0.0; }
       } else
 #endif
-      for (int step = 0; step <= m; ++step) {
+      for (int step = 0; step <= LEAN_STEPS_HI(m); ++step) {
         double win[3];
         if constexpr (SMALL_S) {
           double pw[3], nw[3];
@@ -882,7 +892,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       SEQ_BEGIN();
 #if LEAN_BPERM & 1
       if constexpr (!SMALL_S) {
-        for (int step = m - 1; step >= 0; --step) {   // (here a lane wants the neighbour TOWARDS the root)
+        for (int step = LEAN_STEPS_HI(m) - 1; step >= 0; --step) {   // (here a lane wants the neighbour TOWARDS the root)
           double xin[3];
           UNROLL for (int i = 0; i < 3; i++) xin[i] = lane_fetch(addr_root, y[i]);
           if (step == my_step) {
@@ -894,7 +904,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         }
       } else
 #endif
-      for (int step = m - 1; step >= 0; --step) {
+      for (int step = LEAN_STEPS_HI(m) - 1; step >= 0; --step) {
         double xin[3];
         if constexpr (SMALL_S) {
           double py[3], ny[3];
