@@ -38,17 +38,6 @@ __device__ __forceinline__ double dpp_next(double x) {
   return __hiloint2double(hi, lo);
 }
 
-// lane i <- lane addr / 4 through the LDS crossbar (ds_bpermute_b32: no LDS memory involved; the address is per lane, so
-// ONE fetch serves lanes that want their left neighbour and lanes that want their right one -- a DPP shift has one
-// direction for the whole wavefront, and the two-sided sweeps of the lean form then pay two shifts and an addition per
-// double.  An LDS-pipe instruction, not a vector-ALU one: the lean form is bound by vector-ALU issue.)
-__device__ __forceinline__ double lane_fetch(int addr, double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_ds_bpermute(addr, lo);
-  hi = __builtin_amdgcn_ds_bpermute(addr, hi);
-  return __hiloint2double(hi, lo);
-}
-
 // ---- constraint rows of one segment (solve_3d.cc:823-888): 6 pos, 5 vel, 4 acc, 3 jerk ----
 // row r: first column, number of columns, coefficients (position rows carry the runtime t).
 __host__ __device__ constexpr int row_col0(int r) { return r < 6 ? r : r < 11 ? r - 6 : r < 15 ? r - 11 : r - 15; }

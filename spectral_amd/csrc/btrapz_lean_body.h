@@ -66,49 +66,29 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   S = __builtin_amdgcn_readfirstlane(S);
   const int gpw = 64 / S;
   const int g = lane / S;
-  const int pos = lane - g * S;          // position of the lane in its group
+  const int k = lane - g * S;
   const bool lane_in_group = g < gpw;
   const int gl = lane_in_group ? g : gpw - 1;
   const int gbase = gl * S;
-  // LEAN_CR -- odd-even layout and one level of cyclic reduction (round 5; cold solves of uniform batches).  The block
-  // tridiagonal Newton system is eliminated in a chain of floor(S / 2) + 1 dependent steps in which 2 of a group's S lanes
-  // work: 40 % of the kernel's vector instructions.  Here the lanes of a group hold the EVEN segments first (positions 0 ..
-  // nr - 1, nr = ceil(S / 2)), then the odd ones: the odd joints -- no two of them coupled -- are eliminated at once, every
-  // odd lane for itself (S_k^-1 applied to both couplings, Schur updates to both even neighbours, the new coupling between
-  // them), and the even joints that remain form a block tridiagonal chain of HALF the length on ADJACENT lanes, which the
-  // two-sided elimination below runs over in floor(nr / 2) + 1 steps with its DPP shifts unchanged.  A symmetric pivot
-  // order on a positive definite matrix: as stable as the chain.  What it costs: the odd lanes keep two 3 x 3 blocks
-  // instead of one (S_k^-1 C_a, S_k^-1 C_b: +9 doubles of state), and a segment's neighbours are no longer the
-  // neighbouring lanes, so the row passes' joint exchange (previous segment's end state, next segment's contribution)
-  // goes through ds_bpermute with per-lane addresses -- outside any dependent chain, where its latency is hidden.
-#ifndef LEAN_CR
-#define LEAN_CR 0
-#endif
-  constexpr bool CRL = LEAN_CR && !SMALL_S && !WARM;
-  const int nr = (S + 1) >> 1;            // CRL: even segments (the reduced chain's length)
-  const int k = CRL ? (pos < nr ? 2 * pos : 2 * (pos - nr) + 1) : pos;   // the lane's segment
   const bool first = (k == 0), last = (k == S - 1);
-  [[maybe_unused]] const bool odd_seg = CRL && pos >= nr;
-  // the chain of the sequential loops: all S joints, or (CRL) the nr even ones on positions 0 .. nr - 1
-  const int cn = CRL ? nr : S;
-  const int m = cn >> 1;
-  const bool in_chain = !CRL || pos < nr;
-  const bool top = in_chain && pos < m, mid = in_chain && pos == m;
-  const int my_step = !in_chain ? -1 : (top ? pos : (pos > m ? cn - 1 - pos : m));
-  // byte addresses (ds_bpermute) of the lanes that hold the previous / next segment
-  [[maybe_unused]] const int addr_pseg = (gbase + (odd_seg ? pos - nr : nr + pos - 1)) << 2;
-  [[maybe_unused]] const int addr_nseg = (gbase + (odd_seg ? pos - nr + 1 : nr + pos)) << 2;
-  // (Round 5, measured and removed: the neighbour exchange of the sequential loops through ds_bpermute -- one fetch per
-  //  double with a per-lane address instead of a DPP shift in each direction and an addition; 18 / 6 LDS-pipe instructions
-  //  for 45 / 15 vector ones per step, results bit-identical, and SLOWER: scenario_1 x 20 two launches 4.05 -> 4.21 ms, sweeps
-  //  only 4.18, factorisation only 4.17 -- a crossbar fetch in every step's dependent chain.  DESIGN 3.3, profiles/r05_ab.txt.)
-  // (timing experiments only: -DLEAN_HALF_STEPS runs half the steps of every sequential loop -- wrong results, the cost of
-  //  an elimination that needed half as many: DESIGN 3.3)
-#ifdef LEAN_HALF_STEPS
-#define LEAN_STEPS_HI(m_) (((m_) + 1) / 2)
-#else
-#define LEAN_STEPS_HI(m_) (m_)
-#endif
+  const int m = S >> 1;
+  const bool top = k < m, mid = k == m;
+  const int my_step = top ? k : (k > m ? S - 1 - k : m);
+  // Round 5, three attempts on the sequential loops -- 40 % of the kernel's vector instructions at 2 of a group's S lanes
+  // useful -- measured and REMOVED (kill criterion of the round's brief; rows in DESIGN 3.3, records in profiles/r05_ab.txt,
+  // the code in the history: commits "Lean form: neighbour exchange ... ds_bpermute" and "EXPERIMENT ... cyclic reduction"):
+  //  * neighbour exchange through ds_bpermute (one fetch per double with a per-lane address instead of a DPP shift in each
+  //    direction and an addition; 18 / 6 LDS-pipe instructions for 45 / 15 vector ones per step; results bit-identical):
+  //    SLOWER, scenario_1 x 20 two launches 4.05 -> 4.21 ms (sweeps only 4.18, factorisation only 4.17) -- a crossbar fetch
+  //    in every step's dependent chain;
+  //  * an upper bound: every sequential loop at HALF its steps (timing build, results garbage, 8 iterations fixed):
+  //    3.91 -> 3.28 ms -- what an elimination of half the depth could gain at most: 16 %;
+  //  * that elimination: odd-even lane layout + one level of cyclic reduction (the odd joints eliminated at once, every
+  //    odd lane for itself; the even joints' chain of half the length on adjacent lanes; segment neighbours through
+  //    ds_bpermute outside the chains).  CORRECT on the first run (46 lean-form tests, accept sets, control points within
+  //    1.5e-6 of this arrangement's) and 48 % SLOWER, 3.97 -> 5.86 ms: an odd joint keeps TWO 3 x 3 blocks (S^-1 C_a,
+  //    S^-1 C_b) where a chain joint keeps one -- +18 registers in a kernel that has none: scratch 92 -> 316-412 B per
+  //    lane, and no longer read-only data: 112 scratch loads and 21 stores per iteration instead of 15 and 4.
   const Shared &sh = a.sh;
   const int variant = sh.variant;
   // The kernel's arguments as the loop and the write-back see them: through a pointer into the kernarg segment that is
@@ -124,10 +104,8 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   typedef const double __attribute__((address_space(4))) ctable_t;
   ctable_t *mq = (ctable_t *)(mqm + axis * 84);
   const double inv_m = 1.0 / ((double)(2 * NR) * (double)S);
-  // value of the previous / next SEGMENT's lane (the neighbouring lane, or -- CRL -- wherever the layout put it; a lane
-  // without such a neighbour reads something it must not use: every use is masked by first / last)
-  auto from_prev = [&](double x) -> double { if constexpr (CRL) return lane_fetch(addr_pseg, x); else return dpp_prev(x); };
-  auto from_next = [&](double x) -> double { if constexpr (CRL) return lane_fetch(addr_nseg, x); else return dpp_next(x); };
+  auto from_prev = [&](double x) -> double { return dpp_prev(x); };
+  auto from_next = [&](double x) -> double { return dpp_next(x); };
 
   // ---- which candidate this group solves ----
   long long cand = (long long)pair * gpw + gl;
@@ -458,14 +436,11 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       wave_lds_sync();
       lds[LN_RED][lane] = t;
       wave_lds_sync();
-      for (int j = 0; j < S; j++) {   // (j: a position; its segment in the layout of this kernel)
-        const int kj = CRL ? (j < nr ? 2 * j : 2 * (j - nr) + 1) : j;
-        tsum += (kj <= k) ? lds[LN_RED][gbase + j] : 0.0;
-      }
+      for (int j = 0; j < S; j++) tsum += (j <= k) ? lds[LN_RED][gbase + j] : 0.0;
       Xcold0 = Xinit[0] + Xinit[1] * tsum;
     }
     {
-      const Red4 r0 = group_reduce<0, 1, 1, 2>(lds + LN_RED, lane, gbase, pos, S, no_solution_lane ? 1.0 : 0.0, bnorm, qn, gapmin);
+      const Red4 r0 = group_reduce<0, 1, 1, 2>(lds + LN_RED, lane, gbase, k, S, no_solution_lane ? 1.0 : 0.0, bnorm, qn, gapmin);
       bnorm = r0.b; qn = r0.c; gapmin = r0.d;
       no_solution = r0.a > 0.0;
     }
@@ -510,7 +485,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 
   // ---- capped / resume: a group's iterate in a.susp_state, slot-major, field i of lane k at [slot][i][k] ----------
   [[maybe_unused]] auto state_io = [&](const bool store, const long long slot) {
-    double *base = ka->susp_state + (size_t)slot * LEAN_SUSP_FIELDS * ka->seg_stride + pos;   // (by position: the resume launch has the layout of the capped one)
+    double *base = ka->susp_state + (size_t)slot * LEAN_SUSP_FIELDS * ka->seg_stride + k;
     const size_t fs = ka->seg_stride;
     int f = 0;
     auto io = [&](double &v) { if (store) base[(size_t)f * fs] = v; else v = base[(size_t)f * fs]; ++f; };
@@ -601,7 +576,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     if (!(mu_part == mu_part) || !(rd_part == rd_part) || !(rp_part == rp_part) || !(dscale == dscale) ||
         !(fabs(rd_part) < 1e300) || !(fabs(mu_part) < 1e300))
       rp_part = 1e300;
-    const Red4 rr = group_reduce_mixed<0, 1, 1, 1>(lds + LN_RED, lane, gbase, pos, S, lane_in_group, mu_part, rd_part, rp_part, dscale);
+    const Red4 rr = group_reduce_mixed<0, 1, 1, 1>(lds + LN_RED, lane, gbase, k, S, lane_in_group, mu_part, rd_part, rp_part, dscale);
     const double mu = rr.a * inv_m;
     [[maybe_unused]] bool restart_now = false;
     // ---- termination (the packed form's rules: DESIGN.md 3.4) ----
@@ -663,9 +638,6 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         }
       }
     }
-#ifdef LEAN_FIXED_ITERS   // (timing experiments only: every group runs exactly this many iterations, whatever its iterate does)
-    done = !valid || eit >= LEAN_FIXED_ITERS;
-#endif
     if (__all(done)) break;
     if constexpr (WARM) {
       if (__any(restart_now)) {
@@ -746,103 +718,21 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     // predictor's forward sweep rides along.  MK: M01 of the neighbour towards the root until the lane's step, then
     // K = S_k^{-1} Mc; TF: the diagonal block until then, then its factor ----
     double MK[9], TF[6], Z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    [[maybe_unused]] double KB[9];   // CRL, odd lanes: S_k^-1 C_b (MK holds S_k^-1 C_a, TF the factor of S_k)
-    // C -> K = S^-1 C (in place), Kp = D^-1 L^-1 C and Y = L^-1 C, for the factor F of S (ldl3): Y' Kp is C' S^-1 C
-    [[maybe_unused]] auto apply_factor = [&](const double (&F)[6], double (&C)[9], double (&Y)[9], double (&Kp)[9]) {
-      UNROLL for (int j = 0; j < 3; j++) {
-        Y[j] = C[j];
-        Y[3 + j] = C[3 + j] - F[0] * Y[j];
-        Y[6 + j] = C[6 + j] - F[1] * Y[j] - F[2] * Y[3 + j];
-      }
-      UNROLL for (int j = 0; j < 3; j++) {
-        Kp[6 + j] = Y[6 + j] * F[5];
-        Kp[3 + j] = Y[3 + j] * F[4];
-        Kp[j] = Y[j] * F[3];
-      }
-      UNROLL for (int j = 0; j < 3; j++) {
-        C[6 + j] = Kp[6 + j];
-        C[3 + j] = Kp[3 + j] - F[2] * C[6 + j];
-        C[j] = Kp[j] - (F[0] * C[3 + j] + F[1] * C[6 + j]);
-      }
-    };
     {
       double wp[3] = {0.0, 0.0, 0.0};
-      if constexpr (CRL) {
-        // ---- level 1 of the reduction: every odd joint k, on its own lane, at once.  C_a = coupling (k, k - 1), C_b =
-        // coupling (k, k + 1), rows the joint's own: the lane's M01 transposed and the next segment's M01.
-        // (side a, its exchange, then side b and its exchange; K = S^-1 C column by column straight into the arrays that
-        //  keep it, the Schur products from K and the raw coupling: no temporary 3 x 3 block outlives its side)
-        UNROLL for (int i = 0; i < 6; i++) TF[i] = T[i];
-        double F[6];
-        {
-          double Zaa[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, wa[3] = {0.0, 0.0, 0.0};
-          if (odd_seg) {
-            ldl3(T, F);
-            // C_a = M01' (rows own): column j of C_a is row j of M01
-            UNROLL for (int j = 0; j < 3; j++) ldl3_solve(F, M01[j * 3], M01[j * 3 + 1], M01[j * 3 + 2], MK[j], MK[3 + j], MK[6 + j]);
-            // Zaa = C_a' K_a (symmetric): (i, j) = sum_r C_a[r][i] K_a[r][j] = sum_r M01[i][r] MK[r][j]
-            Zaa[0] = M01[0] * MK[0] + M01[1] * MK[3] + M01[2] * MK[6];
-            Zaa[1] = M01[0] * MK[1] + M01[1] * MK[4] + M01[2] * MK[7];
-            Zaa[2] = M01[0] * MK[2] + M01[1] * MK[5] + M01[2] * MK[8];
-            Zaa[3] = M01[3] * MK[1] + M01[4] * MK[4] + M01[5] * MK[7];
-            Zaa[4] = M01[3] * MK[2] + M01[4] * MK[5] + M01[5] * MK[8];
-            Zaa[5] = M01[6] * MK[2] + M01[7] * MK[5] + M01[8] * MK[8];
-            UNROLL for (int j = 0; j < 3; j++) wa[j] = MK[j] * up[0] + MK[3 + j] * up[1] + MK[6 + j] * up[2];
-          }
-          ROW_SEP();
-          // an even joint's NEXT segment is odd: its a side is this joint
-          UNROLL for (int i = 0; i < 6; i++) { const double za = from_next(Zaa[i]); if (!odd_seg) TF[i] -= last ? 0.0 : za; }
-          UNROLL for (int i = 0; i < 3; i++) { const double a_ = from_next(wa[i]); if (!odd_seg) up[i] -= last ? 0.0 : a_; }
-        }
-        ROW_SEP();
-        double R[9];
-        {
-          double Cb[9];
-          UNROLL for (int i = 0; i < 9; i++) { const double v = from_next(M01[i]); Cb[i] = last ? 0.0 : v; }
-          double Zbb[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, wb[3] = {0.0, 0.0, 0.0}, Zab[9];
-          UNROLL for (int i = 0; i < 9; i++) Zab[i] = 0.0;
-          if (odd_seg) {
-            UNROLL for (int j = 0; j < 3; j++) ldl3_solve(F, Cb[j], Cb[3 + j], Cb[6 + j], KB[j], KB[3 + j], KB[6 + j]);
-            // Zbb = C_b' K_b (symmetric); Zab = K_a' C_b = C_a' S^-1 C_b: the coupling the two even neighbours get
-            Zbb[0] = Cb[0] * KB[0] + Cb[3] * KB[3] + Cb[6] * KB[6];
-            Zbb[1] = Cb[0] * KB[1] + Cb[3] * KB[4] + Cb[6] * KB[7];
-            Zbb[2] = Cb[0] * KB[2] + Cb[3] * KB[5] + Cb[6] * KB[8];
-            Zbb[3] = Cb[1] * KB[1] + Cb[4] * KB[4] + Cb[7] * KB[7];
-            Zbb[4] = Cb[1] * KB[2] + Cb[4] * KB[5] + Cb[7] * KB[8];
-            Zbb[5] = Cb[2] * KB[2] + Cb[5] * KB[5] + Cb[8] * KB[8];
-            UNROLL for (int i = 0; i < 3; i++)
-              UNROLL for (int j = 0; j < 3; j++) Zab[i * 3 + j] = MK[i] * Cb[j] + MK[3 + i] * Cb[3 + j] + MK[6 + i] * Cb[6 + j];
-            UNROLL for (int j = 0; j < 3; j++) wb[j] = KB[j] * up[0] + KB[3 + j] * up[1] + KB[6 + j] * up[2];
-            UNROLL for (int i = 0; i < 6; i++) TF[i] = F[i];
-          }
-          ROW_SEP();
-          // an even joint's PREVIOUS segment is odd: its b side is this joint; the coupling to the even joint beyond the
-          // next segment comes from that (odd) segment
-          UNROLL for (int i = 0; i < 6; i++) { const double zb = from_prev(Zbb[i]); if (!odd_seg) TF[i] -= first ? 0.0 : zb; }
-          UNROLL for (int i = 0; i < 3; i++) { const double b_ = from_prev(wb[i]); if (!odd_seg) up[i] -= first ? 0.0 : b_; }
-          UNROLL for (int i = 0; i < 9; i++) { const double v = from_next(Zab[i]); R[i] = (last || odd_seg) ? 0.0 : -v; }
-        }
-        // the reduced chain on positions 0 .. nr - 1: Mc = coupling (own joint, neighbour towards the root), rows own
-        UNROLL for (int i = 0; i < 3; i++)
-          UNROLL for (int j = 0; j < 3; j++) {
-            const double pR = dpp_prev(R[j * 3 + i]);
-            if (!odd_seg) MK[i * 3 + j] = top ? R[i * 3 + j] : pR;
-          }
-      } else {
       UNROLL for (int i = 0; i < 3; i++)
         UNROLL for (int j = 0; j < 3; j++) {
           const double nM = from_next(M01[i * 3 + j]);
           MK[i * 3 + j] = top ? nM : M01[j * 3 + i];
         }
       UNROLL for (int i = 0; i < 6; i++) TF[i] = T[i];
-      }
       SEQ_BEGIN();
-      for (int step = 0; step <= LEAN_STEPS_HI(m); ++step) {
+      for (int step = 0; step <= m; ++step) {
         double zin[6], win[3];
         if constexpr (SMALL_S) {
           double pz[6], nz[6], pw[3], nw[3];
-          UNROLL for (int i = 0; i < 6; i++) { pz[i] = dpp_prev(Z[i]); nz[i] = dpp_next(Z[i]); }
-          UNROLL for (int i = 0; i < 3; i++) { pw[i] = dpp_prev(wp[i]); nw[i] = dpp_next(wp[i]); }
+          UNROLL for (int i = 0; i < 6; i++) { pz[i] = from_prev(Z[i]); nz[i] = from_next(Z[i]); }
+          UNROLL for (int i = 0; i < 3; i++) { pw[i] = from_prev(wp[i]); nw[i] = from_next(wp[i]); }
           if (S <= 2) {
             UNIFORM_BLOCK;
             UNROLL for (int i = 0; i < 6; i++) { pz[i] = first ? 0.0 : pz[i]; nz[i] = last ? 0.0 : nz[i]; }
@@ -851,8 +741,8 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           UNROLL for (int i = 0; i < 6; i++) zin[i] = pz[i] + nz[i];
           UNROLL for (int i = 0; i < 3; i++) win[i] = pw[i] + nw[i];
         } else {   // (the unwanted neighbour still holds 0 when a lane's step comes: see the packed form)
-          UNROLL for (int i = 0; i < 6; i++) { const double p = dpp_prev(Z[i]), n = dpp_next(Z[i]); zin[i] = p + n; }
-          UNROLL for (int i = 0; i < 3; i++) { const double p = dpp_prev(wp[i]), n = dpp_next(wp[i]); win[i] = p + n; }
+          UNROLL for (int i = 0; i < 6; i++) { const double p = from_prev(Z[i]), n = from_next(Z[i]); zin[i] = p + n; }
+          UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(wp[i]), n = from_next(wp[i]); win[i] = p + n; }
         }
         if (step == my_step) {
           double Sk[6], F[6];
@@ -895,29 +785,16 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     // One solve with the factor: u (reduced to the joint states) -> dX by the sweeps -> dc.
     auto forward_u = [&](double (&u)[3]) {
       double w[3] = {0.0, 0.0, 0.0};
-      if constexpr (CRL) {   // level 1: the odd joints' right-hand sides, reduced into their even neighbours'
-        double wa[3] = {0.0, 0.0, 0.0}, wb[3] = {0.0, 0.0, 0.0};
-        if (odd_seg) {
-          UNROLL for (int j = 0; j < 3; j++) {
-            wa[j] = MK[j] * u[0] + MK[3 + j] * u[1] + MK[6 + j] * u[2];
-            wb[j] = KB[j] * u[0] + KB[3 + j] * u[1] + KB[6 + j] * u[2];
-          }
-        }
-        UNROLL for (int i = 0; i < 3; i++) {
-          const double b_ = from_prev(wb[i]), a_ = from_next(wa[i]);
-          if (!odd_seg) u[i] -= (first ? 0.0 : b_) + (last ? 0.0 : a_);
-        }
-      }
       SEQ_BEGIN();
-      for (int step = 0; step <= LEAN_STEPS_HI(m); ++step) {
+      for (int step = 0; step <= m; ++step) {
         double win[3];
         if constexpr (SMALL_S) {
           double pw[3], nw[3];
-          UNROLL for (int i = 0; i < 3; i++) { pw[i] = dpp_prev(w[i]); nw[i] = dpp_next(w[i]); }
+          UNROLL for (int i = 0; i < 3; i++) { pw[i] = from_prev(w[i]); nw[i] = from_next(w[i]); }
           if (S <= 2) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) { pw[i] = first ? 0.0 : pw[i]; nw[i] = last ? 0.0 : nw[i]; } }
           UNROLL for (int i = 0; i < 3; i++) win[i] = pw[i] + nw[i];
         } else {
-          UNROLL for (int i = 0; i < 3; i++) { const double p = dpp_prev(w[i]), n = dpp_next(w[i]); win[i] = p + n; }
+          UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(w[i]), n = from_next(w[i]); win[i] = p + n; }
         }
         if (step == my_step) {
           UNROLL for (int i = 0; i < 3; i++) u[i] -= win[i];
@@ -935,15 +812,15 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       double y[3];
       UNROLL for (int i = 0; i < 3; i++) y[i] = mid ? dX[i] : 0.0;
       SEQ_BEGIN();
-      for (int step = LEAN_STEPS_HI(m) - 1; step >= 0; --step) {
+      for (int step = m - 1; step >= 0; --step) {
         double xin[3];
         if constexpr (SMALL_S) {
           double py[3], ny[3];
-          UNROLL for (int i = 0; i < 3; i++) { py[i] = dpp_prev(y[i]); ny[i] = dpp_next(y[i]); }
+          UNROLL for (int i = 0; i < 3; i++) { py[i] = from_prev(y[i]); ny[i] = from_next(y[i]); }
           if (S <= 2) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) { py[i] = first ? 0.0 : py[i]; ny[i] = last ? 0.0 : ny[i]; } }
           UNROLL for (int i = 0; i < 3; i++) xin[i] = py[i] + ny[i];
         } else {
-          UNROLL for (int i = 0; i < 3; i++) { const double p = dpp_prev(y[i]), n = dpp_next(y[i]); xin[i] = p + n; }
+          UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(y[i]), n = from_next(y[i]); xin[i] = p + n; }
         }
         if (step == my_step) {
           UNROLL for (int i = 0; i < 3; i++) {
@@ -953,14 +830,6 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         }
       }
       SEQ_END();
-      if constexpr (CRL) {   // level 1: the odd joints from their even neighbours' steps (dX holds S_k^-1 u_k there)
-        double xa[3], xb[3];
-        UNROLL for (int i = 0; i < 3; i++) { xa[i] = from_prev(dX[i]); const double v = from_next(dX[i]); xb[i] = last ? 0.0 : v; }
-        if (odd_seg) {
-          UNROLL for (int i = 0; i < 3; i++)
-            dX[i] -= (MK[3 * i] * xa[0] + MK[3 * i + 1] * xa[1] + MK[3 * i + 2] * xa[2]) + (KB[3 * i] * xb[0] + KB[3 * i + 1] * xb[1] + KB[3 * i + 2] * xb[2]);
-        }
-      }
       const NullMap nm = {it, t * 0.05};
       double dXp[3];
       UNROLL for (int i = 0; i < 3; i++) { const double vv = from_prev(dX[i]); dXp[i] = first ? 0.0 : vv; }
@@ -996,7 +865,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         S1 += al + au;
         S4 += al * ql + au * qu;
       END_ROWS
-      const Red4 ra = group_reduce_mixed<0, 0, 1, 2>(lds + LN_RED, lane, gbase, pos, S, lane_in_group, S1, S4, qmax, qmin);
+      const Red4 ra = group_reduce_mixed<0, 0, 1, 2>(lds + LN_RED, lane, gbase, k, S, lane_in_group, S1, S4, qmax, qmin);
       const double ap = rcp(fmax(-ra.d, 1.0)), ad = rcp(fmax(1.0 + ra.c, 1.0));
       const double mua = ((1.0 - ad) * rr.a + (ap - ad - ap * ad) * ra.a - ap * ad * ra.b) * inv_m;
       const double sr = mua * rcp(mu);
@@ -1096,10 +965,10 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 #define LEAN_E_ATOMIC 0
 #endif
 #if LEAN_E_CACHE && !LEAN_E_ATOMIC
-      const Red4 rs2 = group_reduce2<1, 1>(lds + LN_RED, lane, gbase, pos, S, pr, dr);
+      const Red4 rs2 = group_reduce2<1, 1>(lds + LN_RED, lane, gbase, k, S, pr, dr);
       const Red4 rs = {0.0, rs2.a, rs2.b, 0.0};
 #else
-      const Red4 rs = group_reduce_mixed<-1, 1, 1, -1>(lds + LN_RED, lane, gbase, pos, S, lane_in_group, 0.0, pr, dr, 0.0);
+      const Red4 rs = group_reduce_mixed<-1, 1, 1, -1>(lds + LN_RED, lane, gbase, k, S, lane_in_group, 0.0, pr, dr, 0.0);
 #endif
     LEAN_MARK("E2");
       const double m_ = fmax(rs.b, rs.c);
@@ -1198,7 +1067,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       const double qi = (qB + qA * (double)(i + 1)) + (i == 0 ? -qC : i == 5 ? qC + qend : 0.0);
       obj += c[i] * (0.5 * s + qi);
     }
-    const Red4 ro = group_reduce_mixed<0, -1, -1, -1>(lds + LN_RED, lane, gbase, pos, S, lane_in_group, obj, 0.0, 0.0, 0.0);
+    const Red4 ro = group_reduce_mixed<0, -1, -1, -1>(lds + LN_RED, lane, gbase, k, S, lane_in_group, obj, 0.0, 0.0, 0.0);
     if (valid && !(CAPPED && suspended)) {
       double *dst = ka->ctrl + (size_t)b * 12 * ka->seg_stride + (size_t)axis * 6 * S + (size_t)k * 6;
 #ifndef LEAN_TRACE

@@ -47,7 +47,8 @@ def test_lean_kernels_fit_two_wavefronts_per_simd():
         # scratch: read-mostly problem data the allocator evicts -- a bound, so that a change that makes the
         # kernel spill its state (the 744 B of the packed form under the same budget: 12.5 ms) does not pass unnoticed
         # (round 4, final: 96-120 B in the cold instantiations, 188-212 B in the warm-start ones)
-        assert r["scratch"] <= (256 if "warm" in name else 136), (name, r)
+        # (round 5, final: 92-116 B in the cold instantiations, 188-196 B in the warm-start ones)
+        assert r["scratch"] <= (200 if "warm" in name else 120), (name, r)
 
 
 def test_packed_kernels_do_not_spill():
