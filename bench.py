@@ -387,6 +387,33 @@ def main():
                 b2, sh2 = make_workload("scenario1", B, S, 1, 0)
                 out["config4"] = timed_config("BASELINE config 4: " + workload_label("scenario1", B, S, 1, 1, "weak"), "scenario1", b2, sh2, 1)
             del b2
+            # Informational, NOT `value`: two INDEPENDENT batches in flight (a serving loop that does not wait for batch i's
+            # winner before it launches batch i + 1): two contexts on two streams, the same step each.  What it hides is the
+            # tail of a step -- the last round of wavefronts and the resume launch run at a fraction of the machine's width.
+            try:
+                solver_b = BatchSolver(local_rank)
+                streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+                pair = [(solver, db), (solver_b, solver_b.upload(batch))]
+
+                def step_on(k):
+                    sv, dbk = pair[k]
+                    with torch.cuda.stream(streams[k]):
+                        ok = sv.solve(dbk, shared, lean=a.lean)
+                        sv.argmin(ok["cost"], index_base=index_base)
+                for k in (0, 1, 0, 1):
+                    step_on(k)
+                torch.cuda.synchronize(dev)
+                n2 = 2 * max(a.steps // 2, 4)
+                t2 = time.perf_counter()
+                for i in range(n2):
+                    step_on(i & 1)
+                torch.cuda.synchronize(dev)
+                dt2 = time.perf_counter() - t2
+                out["two_batches_in_flight"] = {"solves_per_s": B * n2 / dt2, "ms_per_batch": 1e3 * dt2 / n2, "batches": n2,
+                                                "note": "two independent batches on two streams / contexts; informational -- `value` is one batch at a time"}
+                del solver_b, pair
+            except Exception as e:
+                out["two_batches_in_flight"] = {"error": repr(e)[:200]}
         # the other named configurations, in the same (driver-timed) run: BASELINE config 5 (receding horizon, one GPU)
         # and the knot-level pipeline through the tools that profiles/ documents
         keep = lambda d, keys: {k: d[k] for k in keys if k in d}

@@ -389,7 +389,7 @@ BTRAPZ_EXPORT int btrapz_multi_solve_argmin(btrapz_multi *m, const btrapz_shared
         hipLaunchKernelGGL(multi_pack_kernel, dim3(1), dim3(256), 0, s.stream, 1, P, s.base, (const long long *)s.loc_idx, (const double *)s.loc_cost,
                            (const double *)s.ctrl, s.rec);
       } else {   // an empty shard takes part in the gather with "nobody": +inf, -1
-        const long long none[2] = {0x7ff0000000000000LL, -1};
+        static const long long none[2] = {0x7ff0000000000000LL, -1};   // (static: an asynchronous copy may read it after this call returns)
         MCHK(m, hipMemsetAsync(s.rec, 0, sizeof(long long) * (2 + (size_t)P), s.stream));
         MCHK(m, hipMemcpyAsync(s.rec, none, sizeof(none), hipMemcpyHostToDevice, s.stream));
       }

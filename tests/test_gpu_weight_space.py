@@ -7,8 +7,8 @@ suite (the full sweeps: profiles/r05_fuzz_campaign.txt):
                                    -- on 3 bundled inputs x 2 variants x (every 5th trial row + 24 seeded draws + the
                                    degenerate rows: a *_ref / end weight of 0, all weights 1e-6, the corners of the box):
                                    accept decision and control points against the oracle's exact (or relaxed) solve;
-  tests/fuzz/weights_batched.py    every batched form (lean / packed, one and two launches, ragged, warm, split) on 384
-                                   candidates of each bench family under 4 rows chosen for spread + the degenerate rows +
+  tests/fuzz/weights_batched.py    every batched form (lean / packed, one and two launches, ragged, warm, split) on 256
+                                   candidates of each bench family under 3 rows chosen for spread + the degenerate rows +
                                    other header limits + the reference's default +-1e10 bounds
                                    (src/piecewise_jerk_problem.cc:9,25-35)."""
 import os
@@ -36,12 +36,12 @@ def test_find_traj_over_the_weight_space():
 
 
 def test_batched_forms_over_the_weight_space():
-    p = subprocess.run([sys.executable, os.path.join(FUZZ, "weights_batched.py"), "384", "4", "0", "-", "8"],
+    p = subprocess.run([sys.executable, os.path.join(FUZZ, "weights_batched.py"), "256", "3", "0", "-", "8"],
                        capture_output=True, text=True, env=dict(os.environ, PYTHONUNBUFFERED="1"), timeout=900)
     tail = p.stdout[-3000:]
     assert p.returncode == 0, (tail, p.stderr[-1500:])
     m = re.search(r"'cases': (\d+), 'forms': (\d+), 'candidates': (\d+), 'accept_differences': (\d+), 'beyond_tolerance': (\d+)", p.stdout)
     assert m, tail
     cases, forms, cand, acc, beyond = map(int, m.groups())
-    assert cases >= 40 and forms >= 9 * cases and acc == 0 and beyond == 0, tail
+    assert cases >= 36 and forms >= 9 * cases and acc == 0 and beyond == 0, tail
     assert "'objective_beyond': 0" in p.stdout, tail
