@@ -236,7 +236,7 @@ typedef struct btrapz_options {
   /* Cold solves of at most 64 segments (uniform or ragged batches, one launch or the two of cap_iter): the form of the
    * solve kernel that runs TWO wavefronts per SIMD -- the same iteration on half the per-lane state (slacks in registers,
    * multipliers in LDS, everything else recomputed: btrapz_lean.hip).  Same problem, same method, same termination rules;
-   * results agree with the one-wavefront form to rounding.  0 -> automatic (batches of at least three wavefronts per
+   * results agree with the one-wavefront form to rounding.  0 -> automatic (batches of at least 1.25 wavefronts per
    * SIMD: below that the one-wavefront form's shorter instruction stream is faster); 1 -> whenever the solve qualifies;
    * -1 -> never.  (The rescue pass, start = 1 and the candidate queue always run the one-wavefront form; warm starts --
    * btrapz_solve_warm_device -- have their instantiation of this form too, in one launch.) */

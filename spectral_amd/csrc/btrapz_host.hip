@@ -95,7 +95,9 @@ static inline const char *experiment_env(const char *name) {
 #endif
 // (round 5: 25 -> 15 % -- 8.5-12 % of the axis problems of the bench batches hand over; a group that finds no slot goes on
 //  to the end where it is, which costs time, never a result)
+#ifndef BTRAPZ_SUSP_PERCENT
 #define BTRAPZ_SUSP_PERCENT 15
+#endif
 #define BTRAPZ_SUSP_BYTES_MAX (1ull << 30)
 
 // Layout the lean kernels rely on (btrapz_lean_body.h reads the row limits of its axis as (&sh.acc_s[0])[2 axis + i],
@@ -529,7 +531,10 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     // 1.032, 16 384 1.964 -> 1.733, 65 536 7.05 -> 5.61: a lone wavefront per SIMD runs the packed form's shorter
     // instruction stream faster; from about three wavefronts per SIMD on the second resident one pays.
     const unsigned est_waves = 2u * (unsigned)((size_t)B / (size_t)(64 / (S < 64 ? S : 64)) + 1);
-    const bool lean_on = lean_ok && (lean_opt > 0 || (lean_opt == 0 && est_waves >= 3u * (unsigned)c->resident_waves));
+    // (round 5, re-measured with the final kernels, packed -> lean in one launch, ms: scenario_1 x 20 -- 512 candidates
+    //  0.30 -> 0.34, 2 048 0.40 -> 0.38, 4 096 0.63 -> 0.52, 8 192 0.91 -> 0.78; generic x 10 -- 2 048 0.14 -> 0.17, 4 096
+    //  0.22 -> 0.19, 8 192 0.33 -> 0.29: the crossover sits at about 1.25 wavefronts per SIMD, not at 3)
+    const bool lean_on = lean_ok && (lean_opt > 0 || (lean_opt == 0 && 4u * est_waves >= 5u * (unsigned)c->resident_waves));
     const bool ragged = seg_count != nullptr;
     const bool cap_requested = cap_iter > 0;   // (by the caller; the automatic choice below falls back to one launch when the workspace cannot be had)
     // (S <= 32: a wavefront that holds ONE group has nobody to wait for -- with 33..64 segments every group would be

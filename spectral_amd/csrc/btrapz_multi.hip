@@ -137,6 +137,14 @@ struct btrapz_multi {
   bool solved = false;
 };
 
+// The entry points below walk the devices with hipSetDevice: the calling thread gets its current device back on return
+// (a caller that shares the thread with PyTorch, or with its own single-device code, must not find it changed).
+struct DeviceGuard {
+  int dev = -1;
+  DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+  ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
 #define MCHK(m, call)                                                                          \
   do {                                                                                         \
     hipError_t e_ = (call);                                                                    \
@@ -176,6 +184,7 @@ static void free_shard(Shard &s) {
 
 BTRAPZ_EXPORT int btrapz_multi_destroy(btrapz_multi *m) {
   if (!m) return BTRAPZ_EINVAL;
+  DeviceGuard guard_;
   if (m->have_comms)
     for (Shard &s : m->sh)
       if (s.comm) { (void)hipSetDevice(s.device); (void)hipStreamSynchronize(s.stream); (void)m->rccl.CommDestroy(s.comm); s.comm = nullptr; }
@@ -196,6 +205,7 @@ BTRAPZ_EXPORT int btrapz_multi_create(btrapz_multi **out, const int *devices, in
     if (devices[g] < 0 || devices[g] >= ndev) return BTRAPZ_ENODEVICE;
     for (int h = 0; h < g; h++) distinct = distinct && devices[h] != devices[g];
   }
+  DeviceGuard guard_;
   btrapz_multi *m = new btrapz_multi();
   m->G = G; m->sh.resize(G);
   for (int g = 0; g < G; g++) {
@@ -314,6 +324,7 @@ static int set_shape(btrapz_multi *m, int B, int S, int group) {
 BTRAPZ_EXPORT int btrapz_multi_upload(btrapz_multi *m, int B, int S, int group, const double *seg, const double *init,
                                       const double *ref_end, const double *dl_bounds) {
   if (!m) return BTRAPZ_EINVAL;
+  DeviceGuard guard_;
   if (!seg || !init || !ref_end || !dl_bounds) { m->err = "invalid argument"; return BTRAPZ_EINVAL; }
   int rc = set_shape(m, B, S, group);
   if (rc != BTRAPZ_OK) return rc;
@@ -363,6 +374,7 @@ BTRAPZ_EXPORT int btrapz_multi_set_shards(btrapz_multi *m, int B, int S, int gro
 
 BTRAPZ_EXPORT int btrapz_multi_solve_argmin(btrapz_multi *m, const btrapz_shared *shared, const btrapz_options *opt) {
   if (!m) return BTRAPZ_EINVAL;
+  DeviceGuard guard_;
   if (!shared || m->B < 1) { m->err = "invalid argument (no batch: call btrapz_multi_upload or btrapz_multi_set_shards first)"; return BTRAPZ_EINVAL; }
   const int G = m->G, S = m->S, P = 12 * S;
   const int n_gather = m->global_groups ? 1 : 0;
@@ -445,6 +457,7 @@ BTRAPZ_EXPORT int btrapz_multi_solve_argmin(btrapz_multi *m, const btrapz_shared
 
 BTRAPZ_EXPORT int btrapz_multi_result(btrapz_multi *m, int device_slot, long long *best_idx, double *best_cost, double *best_ctrl) {
   if (!m) return BTRAPZ_EINVAL;
+  DeviceGuard guard_;
   if (!m->solved || device_slot < -1 || device_slot >= m->G) { m->err = "invalid argument (or no step issued yet)"; return BTRAPZ_EINVAL; }
   const size_t P = 12 * (size_t)m->S;
   if (m->global_groups) {
@@ -474,6 +487,7 @@ BTRAPZ_EXPORT int btrapz_multi_result(btrapz_multi *m, int device_slot, long lon
 
 BTRAPZ_EXPORT int btrapz_multi_wait(btrapz_multi *m) {
   if (!m) return BTRAPZ_EINVAL;
+  DeviceGuard guard_;
   for (Shard &s : m->sh) { MCHK(m, hipSetDevice(s.device)); MCHK(m, hipStreamSynchronize(s.stream)); }
   return BTRAPZ_OK;
 }
@@ -490,6 +504,7 @@ BTRAPZ_EXPORT int btrapz_multi_shard_view(btrapz_multi *m, int device_slot, btra
 
 BTRAPZ_EXPORT int btrapz_multi_download(btrapz_multi *m, double *ctrl, double *cost, int *status, int *iters) {
   if (!m) return BTRAPZ_EINVAL;
+  DeviceGuard guard_;
   if (!m->solved) { m->err = "no step issued yet"; return BTRAPZ_EINVAL; }
   const size_t P = 12 * (size_t)m->S;
   for (Shard &s : m->sh) {

@@ -167,9 +167,9 @@ def test_ragged_batches_in_two_launches_give_the_one_launch_results_bit_for_bit(
         sh.ds_ref, sh.dl_ref = kb.header["ds_ref"], kb.header["dl_ref"]
         sh.dds, sh.ddds, sh.ddl, sh.dddl = kb.header["dds"], kb.header["ddds"], kb.header["ddl"], kb.header["dddl"]
         rec = solver.corridor_batch(kb, 0, seg_stride=32)
-        a = {k: v.cpu().numpy().copy() for k, v in solver.solve_ragged(rec, sh, cap_iter=-1).items()}
+        a = {k: v.cpu().numpy().copy() for k, v in solver.solve_ragged(rec, sh, cap_iter=-1, lean=-1).items()}
         assert solver.ctx.last_solve_form() == 0
-        b = {k: v.cpu().numpy().copy() for k, v in solver.solve_ragged(rec, sh, cap_iter=cap).items()}
+        b = {k: v.cpu().numpy().copy() for k, v in solver.solve_ragged(rec, sh, cap_iter=cap, lean=-1).items()}
         assert solver.ctx.last_solve_form() == 3
         torch.cuda.synchronize()
         assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["cost"], b["cost"])
