@@ -214,6 +214,55 @@ def main():
                 tally["cases"] += 1
                 check("%s/dl1e10_%s" % (fname, cname), bt, shc, res, xs, st)
                 print("  %s/dl1e10_%s done (%d solved)" % (fname, cname, (st > 0).sum()), flush=True)
+    # ---- ragged batches from knot-level inputs (the corridor stage on the device), real segment counts, under the spread rows
+    if os.environ.get("WB_RAGGED", "1") != "0":
+        import tempfile
+        from spectral_amd import knots
+        tmp = tempfile.mkdtemp()
+        NR = int(os.environ.get("WB_RAGGED_N", "96"))
+        for name, variant in (("c1", 0), ("c2", 1), ("c_road_s1_3", 0), ("c3", 1), ("scenario_1 scenes", 0)):
+            if name == "scenario_1 scenes":      # 18-24 segments per candidate (synth.scenario1_knots)
+                kb = synth.scenario1_knots(512, 20, seed=500 + SEED)
+            else:
+                kb = knots.jittered(knots.parse_corridor_file(os.path.join(GOLD, name + ".txt")), 512, seed=77 + SEED, s_shift=0.6, l_shift=0.05)
+            rec = solver.corridor_batch(kb, variant, seg_stride=32)
+            counts = rec["seg_count"].cpu().numpy()
+            for cname, w in rows[:3] + rows[NROWS:NROWS + 2]:
+                shc = synth.shared_params(variant, weights=w)
+                h = kb.header
+                shc.ds_ref, shc.dl_ref, shc.dds, shc.ddds, shc.ddl, shc.dddl = h["ds_ref"], h["dl_ref"], h["dds"], h["ddds"], h["ddl"], h["dddl"]
+                res = {}
+                for form, kw in (("ragged lean", dict(lean=1, cap_iter=-1, compact=-1)), ("ragged packed", dict(lean=-1, cap_iter=-1, compact=-1)),
+                                 ("ragged lean, pre-pass", dict(lean=1, cap_iter=-1, compact=1)), ("ragged lean two launches", dict(lean=1, cap_iter=6, compact=-1))):
+                    o = solver.solve_ragged(rec, shc, **kw)
+                    torch.cuda.synchronize()
+                    res[form] = {k: v.cpu().numpy().copy() for k, v in o.items()}
+                tally["cases"] += 1
+                for b in range(NR):
+                    path = os.path.join(tmp, "c.txt"); knots.write_corridor_file(path, kb, b)
+                    want, x = False, None
+                    try:
+                        inp = O.ParsedInput(path)
+                        n, cubes = O.pipeline(variant, inp)
+                        if 1 <= n <= 32 and all(c.t > 0 for c in cubes):
+                            x, _, info = O.AssembledQp(variant, cubes, O.params_from_weights(w), inp).solve_exact()
+                            want = info.status in (1, 2)
+                    except Exception:
+                        want = False
+                    for form, r in res.items():
+                        tally["forms"] += 0; tally["candidates"] += 1
+                        got = r["status"][b] > 0
+                        if got != want:
+                            tally["accept_differences"] += 1
+                            print("ACCEPT ragged %s v%d %s %s b=%d: hip %d oracle %s segments %d" % (name, variant, cname, form, b, r["status"][b], want, counts[b]), flush=True)
+                        elif got:
+                            Sb = int(counts[b])
+                            err = np.abs(r["ctrl"][b, :12 * Sb] - x).max() / np.abs(x).max()
+                            worst["ragged"] = max(worst.get("ragged", 0.0), float(err))
+                            if err > (1e-4 if r["status"][b] == 2 else 1e-5):
+                                tally["beyond_tolerance"] += 1
+                                print("XSTAR ragged %s v%d %s %s b=%d err %.3e status %d" % (name, variant, cname, form, b, err, r["status"][b]), flush=True)
+                print("  ragged %s/v%d %s: %d candidates x 4 forms, counts %d..%d" % (name, variant, cname, NR, counts[:NR].min(), counts[:NR].max()), flush=True)
     print("weights sweep (batched forms): B", B, "families", list(fam), "rows", [k for k, _ in rows])
     print("  ", tally)
     print("   worst relative deviation from x* per form:", {k: "%.2e" % v for k, v in worst.items()})
