@@ -95,7 +95,8 @@ bool load_rccl(Rccl &r, std::string &why) {
     tries.push_back("librccl.so"); tries.push_back("librccl.so.1");
     for (const std::string &p : tries) {
       if (void *h = dlopen(p.c_str(), RTLD_NOW | RTLD_LOCAL)) { r.handle = h; r.path = p; break; }
-      why += p + ": " + (dlerror() ? dlerror() : "?") + "; ";
+      const char *de = dlerror();   // (one call: dlerror clears the message it returns)
+      why += p + ": " + (de ? de : "?") + "; ";
     }
   }
   if (!r.handle) return false;
