@@ -1376,8 +1376,16 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
   double *Adx = (double *)malloc(sizeof(double) * m), *tt = (double *)malloc(sizeof(double) * (mi + 1));
   double *bx = (double *)malloc(sizeof(double) * n), *by = (double *)calloc(m, sizeof(double));
   double qn = vnorm_inf(qp->q, n), bn = 0;
-  for (int i = 0; i < m; i++) { bn = fmax(bn, fabs(qp->l[i])); bn = fmax(bn, fabs(qp->u[i])); }
-  for (int i = 0; i < m; i++) if (!iseq[i]) { int r = rowpos[i]; sl[r] = fmax(0.0 - qp->l[i], 1.0); su[r] = fmax(qp->u[i] - 0.0, 1.0); ll[r] = 1.0; lu_[r] = 1.0; }
+  /* Bounds that are no bounds (the reference leaves rows it does not use at +-1e10, src/trp.cc dl_bounds and the header's
+   * limits; OSQP treats them as finite rows that never become active): they do not measure the problem -- a primal residual
+   * relative to 1e10 would accept anything -- and a multiplier of 1 on a slack of 1e10 starts the method at mu = 1e9, where
+   * every step length is 1e-6 (round 5: candidate 26 of tests/test_gpu_forms.py's far-bounds batch never left the start).
+   * Such sides start centred with the rest, lambda = 1e4 / slack. */
+  for (int i = 0; i < m; i++) { if (fabs(qp->l[i]) < 1e9) bn = fmax(bn, fabs(qp->l[i])); if (fabs(qp->u[i]) < 1e9) bn = fmax(bn, fabs(qp->u[i])); }
+  for (int i = 0; i < m; i++) if (!iseq[i]) {
+    int r = rowpos[i]; sl[r] = fmax(0.0 - qp->l[i], 1.0); su[r] = fmax(qp->u[i] - 0.0, 1.0);
+    ll[r] = fmin(1.0, 1e4 / sl[r]); lu_[r] = fmin(1.0, 1e4 / su[r]);
+  }
   int best_it = 0, safe = 0;
   double score_hist[4] = {1e300, 1e300, 1e300, 1e300};
   for (iter = 0; iter < max_iter; iter++) {

@@ -183,3 +183,38 @@ def test_accepted_results_of_the_batched_entry_points_are_finite_and_inside_thei
     torch.cuda.synchronize()
     acc = o["status"].cpu().numpy() > 0
     assert np.isfinite(o["ctrl"].cpu().numpy()[acc]).all() and np.isfinite(o["cost"].cpu().numpy()[acc]).all()
+
+
+@pytest.mark.parametrize("family", ["generic20", "scenario1", "generic10 cuboid"])
+def test_bounds_left_at_the_references_default_are_no_bounds(solver, family):
+    """Rows left at +-1e10 (src/piecewise_jerk_problem.cc:9,25-35) in any field a caller can leave there -- corridor lines,
+    velocity intervals, the five dl pairs, the header's acceleration and jerk limits: the solve treats them as absent
+    (btrapz_ipm.h, "bounds that are no bounds") and must land on the optimum the oracle finds with the literal 1e10."""
+    import copy
+    import torch
+    rng = np.random.default_rng(17)
+    batch, sh = {"generic20": lambda: synth.make_batch(384, 20, config=3), "scenario1": lambda: synth.make_scenario1_batch(384, 20, 0),
+                 "generic10 cuboid": lambda: synth.make_batch(384, 10, config=2, variant=1)}[family]()
+    b = copy.copy(batch)
+    b.seg = batch.seg.copy(); b.dl_bounds = batch.dl_bounds.copy()
+    pick = lambda p: rng.random((batch.B, batch.S)) < p
+    m = pick(0.15); b.seg[L.F_UPP_BIAS][m] = 1e10; b.seg[L.F_UPP_SKEW][m] = 0.0
+    m = pick(0.15); b.seg[L.F_DOWN_BIAS][m] = -1e10; b.seg[L.F_DOWN_SKEW][m] = 0.0
+    m = pick(0.10); b.seg[L.F_L_UPP_BIAS][m] = 1e10; b.seg[L.F_L_UPP_SKEW][m] = 0.0; b.seg[L.F_END_L][m] = 1e10
+    m = pick(0.10); b.seg[L.F_L_DOWN_BIAS][m] = -1e10; b.seg[L.F_L_DOWN_SKEW][m] = 0.0; b.seg[L.F_BEG_L][m] = -1e10
+    m = pick(0.20); b.seg[L.F_DS_HI][m] = 1e10
+    m = pick(0.20); b.seg[L.F_DS_LO][m] = -1e10
+    m = rng.random(b.dl_bounds.shape) < 0.3
+    b.dl_bounds[m] = np.where(np.arange(10) % 2 == 0, -1e10, 1e10)[np.nonzero(m)[1]]
+    shf = copy.copy(sh)
+    shf.ddl = (-1e10, 1e10); shf.dddl = (sh.dddl[0], 1e10); shf.ddds = (-1e10, sh.ddds[1])
+    n = 96
+    xs, obj, st, it = O.batch_solve(b, shf, 0, n, exact=True, threads=8)
+    assert (st > 0).sum() > n // 2
+    db = solver.upload(b)
+    for label, kw in (("lean", dict(lean=1, cap_iter=-1, split=-1)), ("packed", dict(lean=-1, cap_iter=-1, split=-1)), ("lean two launches", dict(lean=1, cap_iter=5, split=-1)),
+                      ("warm entry", dict(lean=1, keep_multipliers=True))):
+        o = solver.solve(db, shf, **kw)
+        torch.cuda.synchronize()
+        r = {k: v.cpu().numpy().copy() for k, v in o.items() if k in ("ctrl", "cost", "status", "iters")}
+        check("%s far bounds %s" % (family, label), r, xs, obj, st, n=n)
