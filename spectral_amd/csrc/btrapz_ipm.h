@@ -38,15 +38,6 @@ __device__ __forceinline__ double dpp_next(double x) {
   return __hiloint2double(hi, lo);
 }
 
-// lane i <- lane src (byte address 4 * src) through the LDS crossbar: ~10 x the latency of a DPP move, so only OUTSIDE the
-// dependent chains of the sequential loops (see LEAN_MIRROR in btrapz_lean_body.h).
-__device__ __forceinline__ double lane_fetch(double x, int src4) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_ds_bpermute(src4, lo);
-  hi = __builtin_amdgcn_ds_bpermute(src4, hi);
-  return __hiloint2double(hi, lo);
-}
-
 // ---- constraint rows of one segment (solve_3d.cc:823-888): 6 pos, 5 vel, 4 acc, 3 jerk ----
 // row r: first column, number of columns, coefficients (position rows carry the runtime t).
 __host__ __device__ constexpr int row_col0(int r) { return r < 6 ? r : r < 11 ? r - 6 : r < 15 ? r - 11 : r - 15; }

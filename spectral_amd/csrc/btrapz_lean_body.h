@@ -74,24 +74,6 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   const int m = S >> 1;
   const bool top = k < m, mid = k == m;
   const int my_step = top ? k : (k > m ? S - 1 - k : m);
-#ifndef LEAN_MIRROR
-#define LEAN_MIRROR 1
-#endif
-#if LEAN_MIRROR
-  // LEAN_MIRROR (round 5): inside the factorisation and the sweeps the BOTTOM chain of a group sits mirrored -- position
-  // p > m holds segment S + m - p, so segment S-1 (step 0) is at m+1 and segment m+1 (the chain's end) at S-1.  Both
-  // chains then run the same way along the lanes: a step's neighbour is lane - 1 forwards and lane + 1 backwards for
-  // EVERY lane, one DPP shift per double instead of one in each direction and an addition (the natural layout pays for
-  // the two chains meeting at the root from opposite sides).  What it costs sits outside the dependent chains: the
-  // blocks of the bottom half go to their positions, and the steps come back, through ds_bpermute (independent
-  // fetches, issued back to back), and the root -- adjacent to the top chain's end only -- fetches the bottom chain's end
-  // the same way, once per sweep.  The arithmetic is that of the natural layout, operation for operation.
-  const bool in_bottom = lane_in_group && k > m;
-  const int mir4 = 4 * (in_bottom ? gbase + S + m - k : lane);                                    // the involution k <-> S + m - k
-  const int seq_step = k > m ? k - m - 1 : my_step;                                               // step of the segment AT this position
-  const bool far_end = lane_in_group && S >= 3 && k == S - 1;                                     // position of segment m+1
-  const int far4 = 4 * ((lane_in_group && S >= 3) ? (mid ? gbase + S - 1 : far_end ? gbase + m : lane) : lane);
-#endif
   // Round 5, three attempts on the sequential loops -- 40 % of the kernel's vector instructions at 2 of a group's S lanes
   // useful -- measured and REMOVED (kill criterion of the round's brief; rows in DESIGN 3.3, records in profiles/r05_ab.txt,
   // the code in the history: commits "Lean form: neighbour exchange ... ds_bpermute" and "EXPERIMENT ... cyclic reduction"):
@@ -744,59 +726,6 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           MK[i * 3 + j] = top ? nM : M01[j * 3 + i];
         }
       UNROLL for (int i = 0; i < 6; i++) TF[i] = T[i];
-#if LEAN_MIRROR
-      // to the mirrored positions (18 doubles; independent fetches)
-      UNROLL for (int i = 0; i < 9; i++) MK[i] = lane_fetch(MK[i], mir4);
-      UNROLL for (int i = 0; i < 6; i++) TF[i] = lane_fetch(TF[i], mir4);
-      UNROLL for (int i = 0; i < 3; i++) up[i] = lane_fetch(up[i], mir4);
-      SEQ_BEGIN();
-      for (int step = 0; step <= m; ++step) {
-        double zin[6], win[3];
-        UNROLL for (int i = 0; i < 6; i++) zin[i] = from_prev(Z[i]);
-        UNROLL for (int i = 0; i < 3; i++) win[i] = from_prev(wp[i]);
-        if (step == m) {   // (wave-uniform: the root's step -- the bottom chain's end comes from the far position)
-          UNIFORM_BLOCK;
-          UNROLL for (int i = 0; i < 6; i++) { const double f = lane_fetch(Z[i], far4); zin[i] += f; }
-          UNROLL for (int i = 0; i < 3; i++) { const double f = lane_fetch(wp[i], far4); win[i] += f; }
-        }
-        if (step == seq_step) {
-          double Sk[6], F[6];
-          UNROLL for (int i = 0; i < 6; i++) Sk[i] = TF[i] - zin[i];
-          UNROLL for (int i = 0; i < 3; i++) up[i] -= win[i];
-          ldl3(Sk, F);
-          UNROLL for (int i = 0; i < 6; i++) TF[i] = F[i];
-          if (!mid) {
-            // K = S_k^{-1} Mc and Z = Mc' K through Y = L^{-1} Mc (S_k = L D L'): Z = Y' D^{-1} Y, K = L^{-T} D^{-1} Y
-            double Y[9], K[9];
-            UNROLL for (int j = 0; j < 3; j++) {
-              Y[j] = MK[j];
-              Y[3 + j] = MK[3 + j] - F[0] * Y[j];
-              Y[6 + j] = MK[6 + j] - F[1] * Y[j] - F[2] * Y[3 + j];
-            }
-            UNROLL for (int j = 0; j < 3; j++) {
-              K[6 + j] = Y[6 + j] * F[5];
-              K[3 + j] = Y[3 + j] * F[4];
-              K[j] = Y[j] * F[3];
-            }
-            Z[0] = Y[0] * K[0] + Y[3] * K[3] + Y[6] * K[6];
-            Z[1] = Y[0] * K[1] + Y[3] * K[4] + Y[6] * K[7];
-            Z[2] = Y[0] * K[2] + Y[3] * K[5] + Y[6] * K[8];
-            Z[3] = Y[1] * K[1] + Y[4] * K[4] + Y[7] * K[7];
-            Z[4] = Y[1] * K[2] + Y[4] * K[5] + Y[7] * K[8];
-            Z[5] = Y[2] * K[2] + Y[5] * K[5] + Y[8] * K[8];
-            UNROLL for (int j = 0; j < 3; j++) {
-              K[3 + j] -= F[2] * K[6 + j];
-              K[j] -= F[0] * K[3 + j] + F[1] * K[6 + j];
-            }
-            wp[0] = K[0] * up[0] + K[3] * up[1] + K[6] * up[2];
-            wp[1] = K[1] * up[0] + K[4] * up[1] + K[7] * up[2];
-            wp[2] = K[2] * up[0] + K[5] * up[1] + K[8] * up[2];
-            UNROLL for (int i = 0; i < 9; i++) MK[i] = K[i];
-          }
-        }
-      }
-      SEQ_END();
-#else
       SEQ_BEGIN();
       for (int step = 0; step <= m; ++step) {
         double zin[6], win[3];
@@ -852,29 +781,10 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         }
       }
       SEQ_END();
-#endif
     }
     // One solve with the factor: u (reduced to the joint states) -> dX by the sweeps -> dc.
     auto forward_u = [&](double (&u)[3]) {
       double w[3] = {0.0, 0.0, 0.0};
-#if LEAN_MIRROR
-      UNROLL for (int i = 0; i < 3; i++) u[i] = lane_fetch(u[i], mir4);
-      SEQ_BEGIN();
-      for (int step = 0; step <= m; ++step) {
-        double win[3];
-        UNROLL for (int i = 0; i < 3; i++) win[i] = from_prev(w[i]);
-        if (step == m) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) { const double f = lane_fetch(w[i], far4); win[i] += f; } }
-        if (step == seq_step) {
-          UNROLL for (int i = 0; i < 3; i++) u[i] -= win[i];
-          if (!mid) {
-            w[0] = MK[0] * u[0] + MK[3] * u[1] + MK[6] * u[2];
-            w[1] = MK[1] * u[0] + MK[4] * u[1] + MK[7] * u[2];
-            w[2] = MK[2] * u[0] + MK[5] * u[1] + MK[8] * u[2];
-          }
-        }
-      }
-      SEQ_END();
-#else
       SEQ_BEGIN();
       for (int step = 0; step <= m; ++step) {
         double win[3];
@@ -896,36 +806,11 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         }
       }
       SEQ_END();
-#endif
     };
     auto backward_u = [&](const double (&u)[3], double (&dX)[3], double (&dc)[6]) {
       ldl3_solve(TF, u[0], u[1], u[2], dX[0], dX[1], dX[2]);
       double y[3];
       UNROLL for (int i = 0; i < 3; i++) y[i] = mid ? dX[i] : 0.0;
-#if LEAN_MIRROR
-      {
-        // the bottom chain's end takes the root's step from the far position, before the loop: at its own step the lane
-        // behind it has published nothing yet, so the sum p + n of the natural layout is this one term
-        double xf[3];
-        UNROLL for (int i = 0; i < 3; i++) xf[i] = lane_fetch(y[i], far4);
-        if (far_end) {
-          UNROLL for (int i = 0; i < 3; i++) dX[i] -= MK[3 * i] * xf[0] + MK[3 * i + 1] * xf[1] + MK[3 * i + 2] * xf[2];
-        }
-      }
-      SEQ_BEGIN();
-      for (int step = m - 1; step >= 0; --step) {
-        double xin[3];
-        UNROLL for (int i = 0; i < 3; i++) xin[i] = from_next(y[i]);
-        if (step == seq_step) {   // (the far end reads zeros here: the lane behind it belongs to another group and has not run)
-          UNROLL for (int i = 0; i < 3; i++) {
-            dX[i] -= MK[3 * i] * xin[0] + MK[3 * i + 1] * xin[1] + MK[3 * i + 2] * xin[2];
-            y[i] = dX[i];
-          }
-        }
-      }
-      SEQ_END();
-      UNROLL for (int i = 0; i < 3; i++) dX[i] = lane_fetch(dX[i], mir4);   // back to the natural layout
-#else
       SEQ_BEGIN();
       for (int step = m - 1; step >= 0; --step) {
         double xin[3];
@@ -945,7 +830,6 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         }
       }
       SEQ_END();
-#endif
       const NullMap nm = {it, t * 0.05};
       double dXp[3];
       UNROLL for (int i = 0; i < 3; i++) { const double vv = from_prev(dX[i]); dXp[i] = first ? 0.0 : vv; }
