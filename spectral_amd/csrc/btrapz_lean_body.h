@@ -727,22 +727,20 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         }
       UNROLL for (int i = 0; i < 6; i++) TF[i] = T[i];
       SEQ_BEGIN();
-      for (int step = 0; step <= m; ++step) {
+      // Steps 0 .. m-1, the two chains.  Every lane but the root wants ONE neighbour, the one away from the root: the shift
+      // from the left for all lanes, then the shift from the right under the BOTTOM lanes' execution mask into the same
+      // registers (a branch, not a select: a source lane outside the mask -- the first lane of the next group, right of
+      // a group's last -- reads as 0, which is what that lane's step 0 wants).  Four moves per double and no addition
+      // (round 5: until then both shifts for every lane and p + n, the unwanted side still 0 -- the same numbers;
+      // scenario_1 x 20 two launches 4.00 -> 3.90 ms, generic 3.68 -> 3.63, cuboid 3.38 -> 3.32, 10 segments 1.63 -> 1.61).
+      for (int step = 0; step < m; ++step) {
         double zin[6], win[3];
-        if constexpr (SMALL_S) {
-          double pz[6], nz[6], pw[3], nw[3];
-          UNROLL for (int i = 0; i < 6; i++) { pz[i] = from_prev(Z[i]); nz[i] = from_next(Z[i]); }
-          UNROLL for (int i = 0; i < 3; i++) { pw[i] = from_prev(wp[i]); nw[i] = from_next(wp[i]); }
-          if (S <= 2) {
-            UNIFORM_BLOCK;
-            UNROLL for (int i = 0; i < 6; i++) { pz[i] = first ? 0.0 : pz[i]; nz[i] = last ? 0.0 : nz[i]; }
-            UNROLL for (int i = 0; i < 3; i++) { pw[i] = first ? 0.0 : pw[i]; nw[i] = last ? 0.0 : nw[i]; }
-          }
-          UNROLL for (int i = 0; i < 6; i++) zin[i] = pz[i] + nz[i];
-          UNROLL for (int i = 0; i < 3; i++) win[i] = pw[i] + nw[i];
-        } else {   // (the unwanted neighbour still holds 0 when a lane's step comes: see the packed form)
-          UNROLL for (int i = 0; i < 6; i++) { const double p = from_prev(Z[i]), n = from_next(Z[i]); zin[i] = p + n; }
-          UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(wp[i]), n = from_next(wp[i]); win[i] = p + n; }
+        UNROLL for (int i = 0; i < 6; i++) zin[i] = from_prev(Z[i]);
+        UNROLL for (int i = 0; i < 3; i++) win[i] = from_prev(wp[i]);
+        if (k > m) {
+          UNIFORM_BLOCK;
+          UNROLL for (int i = 0; i < 6; i++) zin[i] = from_next(Z[i]);
+          UNROLL for (int i = 0; i < 3; i++) win[i] = from_next(wp[i]);
         }
         if (step == my_step) {
           double Sk[6], F[6];
@@ -750,7 +748,7 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           UNROLL for (int i = 0; i < 3; i++) up[i] -= win[i];
           ldl3(Sk, F);
           UNROLL for (int i = 0; i < 6; i++) TF[i] = F[i];
-          if (!mid) {
+          {   // (steps below m: never the root)
             // K = S_k^{-1} Mc and Z = Mc' K through Y = L^{-1} Mc (S_k = L D L'): Z = Y' D^{-1} Y, K = L^{-T} D^{-1} Y
             double Y[9], K[9];
             UNROLL for (int j = 0; j < 3; j++) {
@@ -780,30 +778,39 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           }
         }
       }
+      {   // step m, the root: both neighbours (one or two segments: the root is a group's last lane and has no right one)
+        double zin[6], win[3];
+        UNROLL for (int i = 0; i < 6; i++) { const double p = from_prev(Z[i]); double n = from_next(Z[i]); if constexpr (SMALL_S) n = last ? 0.0 : n; zin[i] = p + n; }
+        UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(wp[i]); double n = from_next(wp[i]); if constexpr (SMALL_S) n = last ? 0.0 : n; win[i] = p + n; }
+        if (mid) {
+          double Sk[6], F[6];
+          UNROLL for (int i = 0; i < 6; i++) Sk[i] = TF[i] - zin[i];
+          UNROLL for (int i = 0; i < 3; i++) up[i] -= win[i];
+          ldl3(Sk, F);
+          UNROLL for (int i = 0; i < 6; i++) TF[i] = F[i];
+        }
+      }
       SEQ_END();
     }
     // One solve with the factor: u (reduced to the joint states) -> dX by the sweeps -> dc.
     auto forward_u = [&](double (&u)[3]) {
       double w[3] = {0.0, 0.0, 0.0};
       SEQ_BEGIN();
-      for (int step = 0; step <= m; ++step) {
+      for (int step = 0; step < m; ++step) {
         double win[3];
-        if constexpr (SMALL_S) {
-          double pw[3], nw[3];
-          UNROLL for (int i = 0; i < 3; i++) { pw[i] = from_prev(w[i]); nw[i] = from_next(w[i]); }
-          if (S <= 2) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) { pw[i] = first ? 0.0 : pw[i]; nw[i] = last ? 0.0 : nw[i]; } }
-          UNROLL for (int i = 0; i < 3; i++) win[i] = pw[i] + nw[i];
-        } else {
-          UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(w[i]), n = from_next(w[i]); win[i] = p + n; }
-        }
+        UNROLL for (int i = 0; i < 3; i++) win[i] = from_prev(w[i]);
+        if (k > m) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) win[i] = from_next(w[i]); }
         if (step == my_step) {
           UNROLL for (int i = 0; i < 3; i++) u[i] -= win[i];
-          if (!mid) {
-            w[0] = MK[0] * u[0] + MK[3] * u[1] + MK[6] * u[2];
-            w[1] = MK[1] * u[0] + MK[4] * u[1] + MK[7] * u[2];
-            w[2] = MK[2] * u[0] + MK[5] * u[1] + MK[8] * u[2];
-          }
+          w[0] = MK[0] * u[0] + MK[3] * u[1] + MK[6] * u[2];
+          w[1] = MK[1] * u[0] + MK[4] * u[1] + MK[7] * u[2];
+          w[2] = MK[2] * u[0] + MK[5] * u[1] + MK[8] * u[2];
         }
+      }
+      {
+        double win[3];
+        UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(w[i]); double n = from_next(w[i]); if constexpr (SMALL_S) n = last ? 0.0 : n; win[i] = p + n; }
+        if (mid) { UNROLL for (int i = 0; i < 3; i++) u[i] -= win[i]; }
       }
       SEQ_END();
     };
@@ -813,15 +820,9 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       UNROLL for (int i = 0; i < 3; i++) y[i] = mid ? dX[i] : 0.0;
       SEQ_BEGIN();
       for (int step = m - 1; step >= 0; --step) {
-        double xin[3];
-        if constexpr (SMALL_S) {
-          double py[3], ny[3];
-          UNROLL for (int i = 0; i < 3; i++) { py[i] = from_prev(y[i]); ny[i] = from_next(y[i]); }
-          if (S <= 2) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) { py[i] = first ? 0.0 : py[i]; ny[i] = last ? 0.0 : ny[i]; } }
-          UNROLL for (int i = 0; i < 3; i++) xin[i] = py[i] + ny[i];
-        } else {
-          UNROLL for (int i = 0; i < 3; i++) { const double p = from_prev(y[i]), n = from_next(y[i]); xin[i] = p + n; }
-        }
+        double xin[3];   // (towards the root: from the right for the top lanes, from the left under the mask of the root and the bottom lanes)
+        UNROLL for (int i = 0; i < 3; i++) xin[i] = from_next(y[i]);
+        if (k >= m) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) xin[i] = from_prev(y[i]); }
         if (step == my_step) {
           UNROLL for (int i = 0; i < 3; i++) {
             dX[i] -= MK[3 * i] * xin[0] + MK[3 * i + 1] * xin[1] + MK[3 * i + 2] * xin[2];
