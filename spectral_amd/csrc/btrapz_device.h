@@ -134,16 +134,12 @@ __global__ void ipm_solve_capped_ordered_kernel(const KernelArgs a, const double
 __global__ void ipm_solve_resume_kernel(const KernelArgs a, const double *__restrict__ mqm);        // ... and the launch that carries the suspended problems on
 // the solve at two wavefronts per SIMD (btrapz_lean_body.h; instantiated in btrapz_lean.hip and btrapz_lean_warm.hip)
 __global__ void ipm_solve_lean_kernel(const KernelArgs a, const double *__restrict__ mqm);
-__global__ void ipm_solve_lean_hint_kernel(const KernelArgs a, const double *__restrict__ mqm);
-__global__ void ipm_solve_lean_ragged_kernel(const KernelArgs a, const double *__restrict__ mqm);
+__global__ void ipm_solve_lean_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void ipm_solve_lean_capped_kernel(const KernelArgs a, const double *__restrict__ mqm);
-__global__ void ipm_solve_lean_capped_hint_kernel(const KernelArgs a, const double *__restrict__ mqm);
-__global__ void ipm_solve_lean_capped_ragged_kernel(const KernelArgs a, const double *__restrict__ mqm);
+__global__ void ipm_solve_lean_capped_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void ipm_solve_lean_resume_kernel(const KernelArgs a, const double *__restrict__ mqm);
-__global__ void ipm_solve_lean_resume_ragged_kernel(const KernelArgs a, const double *__restrict__ mqm);
 __global__ void ipm_solve_lean_warm_kernel(const KernelArgs a, const double *__restrict__ mqm);
-__global__ void ipm_solve_lean_warm_hint_kernel(const KernelArgs a, const double *__restrict__ mqm);
-__global__ void ipm_solve_lean_warm_ragged_kernel(const KernelArgs a, const double *__restrict__ mqm);
+__global__ void ipm_solve_lean_warm_ordered_kernel(const KernelArgs a, const double *__restrict__ mqm);
 #define BTRAPZ_SUSPENDED (-7)   // internal: an axis problem the capped launch handed over (never leaves the library)
 __global__ void ipm_solve_long_kernel(const KernelArgs a, const double *__restrict__ mqm);          // 65..256 segments: one axis problem per workgroup
 __global__ void ipm_solve_long_elastic_kernel(const KernelArgs a, const double *__restrict__ mqm);  // rescue pass of the long form (<= 192 segments)

@@ -585,11 +585,10 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       KernelArgs p1 = a;
       p1.cap_iter = cap_iter; p1.cap_alone = BTRAPZ_CAP_ALONE; p1.cap_hi = cap_iter + BTRAPZ_CAP_HI; p1.cap_score = BTRAPZ_CAP_SCORE; p1.susp_cap = (int)slots; p1.susp_state = c->d_susp_state; p1.susp_count = count;
       p1.susp_slot = slot_of; p1.susp_key = keys;
-      // (a uniform batch that goes through a.order -- compact -- runs the instantiations WITHOUT the end-lane fix-up of
-      //  ragged batches: the bits of a candidate's result must not depend on whether the pre-pass ran)
+      // (the ordered instantiation serves ragged batches and uniform ones that go through a.order -- the pre-pass -- and
+      //  gives a uniform batch the bits of the memory-order one: btrapz_lean_body.h)
       if (lean_on) {
-        if (ragged) hipLaunchKernelGGL(ipm_solve_lean_capped_ragged_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
-        else if (p1.order) hipLaunchKernelGGL(ipm_solve_lean_capped_hint_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
+        if (p1.order) hipLaunchKernelGGL(ipm_solve_lean_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
         else hipLaunchKernelGGL(ipm_solve_lean_capped_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
       } else {
         if (p1.order) hipLaunchKernelGGL(ipm_solve_capped_ordered_kernel, dim3(blocks), dim3(64), 0, stream, p1, (const double *)c->d_mqm);
@@ -608,8 +607,7 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
       p2.bucket_S = ragged ? 0 : S;
       // (ragged: no candidate has more than min(S, 64) segments, so no wavefront holds fewer groups than that allows)
       const unsigned rblocks = 2u * (unsigned)(slots / (size_t)(64 / (S < 64 ? S : 64)) + 65);
-      if (lean_on && ragged) hipLaunchKernelGGL(ipm_solve_lean_resume_ragged_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
-      else if (lean_on) hipLaunchKernelGGL(ipm_solve_lean_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
+      if (lean_on) hipLaunchKernelGGL(ipm_solve_lean_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
       else hipLaunchKernelGGL(ipm_solve_resume_kernel, dim3(rblocks), dim3(64), 0, stream, p2, (const double *)c->d_mqm);
       c->last_form = lean_on ? 11 : 3;
     } else if (long_form) {
@@ -628,9 +626,9 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
 #endif
     } else if (lean_on) {
       c->last_form = 8;
-      const bool ragged_batch = seg_count != nullptr;   // (a.order without it: hint classes of a uniform batch)
-      auto lean_kernel = warm_kernel ? (ragged_batch ? ipm_solve_lean_warm_ragged_kernel : a.order ? ipm_solve_lean_warm_hint_kernel : ipm_solve_lean_warm_kernel)
-                                     : (ragged_batch ? ipm_solve_lean_ragged_kernel : a.order ? ipm_solve_lean_hint_kernel : ipm_solve_lean_kernel);
+      // (a.order: the buckets of a ragged batch, or the hint classes / the pre-pass's list of a uniform one)
+      auto lean_kernel = warm_kernel ? (a.order ? ipm_solve_lean_warm_ordered_kernel : ipm_solve_lean_warm_kernel)
+                                     : (a.order ? ipm_solve_lean_ordered_kernel : ipm_solve_lean_kernel);
       hipLaunchKernelGGL(lean_kernel, dim3(blocks), dim3(64), 0, stream, a, (const double *)c->d_mqm);
     } else {
       c->last_form = 0;

@@ -33,7 +33,7 @@ enum { LN_LL = 0, LN_LU = 15, LN_RED = 30, LN_XB = 34, LN_XI = 37, LN_ROWS = 40 
 enum { LEAN_SUSP_FIELDS = 3 + 4 * 15 + 3 + 8 };   // slot stride: SUSP_FIELDS of the packed form (the host sizes one workspace);
                                                   // the lean record itself is 69 doubles per lane (3 + 3 + 60 + 3 of bookkeeping)
 
-template <bool ORDERED, bool CAPPED, bool RESUME, bool SMALL_S, bool WARM = false>
+template <bool ORDERED, bool CAPPED, bool RESUME, bool WARM = false>
 __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const double *__restrict__ mqm, double (*lds)[64],
                                                 const int wave_id, const int lane) {
   static_assert(!(CAPPED && RESUME), "one launch is the first or the second");
@@ -42,12 +42,14 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
   constexpr bool FULL = false;
   constexpr int NR = 15;
   constexpr bool PERAXIS = RESUME;
-  // SMALL_S -- one or two segments: the root of the two-sided elimination is an end lane, and the neighbour it lacks is
-  // another group's lane: a fix-up in the sequential loops (wave-uniform branch; the two DPP directions kept apart until
-  // it: +2 % on every solve, measured).  Only the instantiations that serve ragged batches carry it -- a ragged batch may
-  // hold buckets of one or two segments; a uniform batch of fewer than three takes the packed form (btrapz_host.hip).
-  // (A template parameter of its own, not a function of ORDERED: the resume launch of a uniform batch reads lists too,
-  //  and it must run the arithmetic of the capped launch it carries on, instruction for instruction.)
+  // One or two segments (ragged batches may hold such buckets; a uniform batch of fewer than three takes the packed form,
+  // btrapz_host.hip): the root of the two-sided elimination is then a group's last lane, and what its right neighbour --
+  // another group's first lane -- holds is not the root's to add: one select at the root's step, carried by the
+  // instantiations that read their candidates through a.order (ragged batches, hint classes, the pre-pass's lists, resume
+  // lists).  With three or more segments the select passes the value through, so a scheduling hint, the pre-pass or a
+  // second launch cannot change a result's bits.  (Until round 5 a wave-uniform fix-up inside every step of the sequential
+  // loops, +2 % on every solve of an instantiation that carried it, and a template parameter of its own.)
+  constexpr bool SMALL_S = ORDERED;
   const int axis = __builtin_amdgcn_readfirstlane(wave_id & 1);
   int S, pair = wave_id >> 1, ncand = a.B, cand0 = 0;
   if constexpr (ORDERED) {

@@ -5,8 +5,7 @@
 
 namespace btrapz {
 
-LEAN_INSTANCE(ipm_solve_lean_warm_kernel, false, false, false, false, true)         // uniform, memory order
-LEAN_INSTANCE(ipm_solve_lean_warm_hint_kernel, true, false, false, false, true)     // uniform, hint classes
-LEAN_INSTANCE(ipm_solve_lean_warm_ragged_kernel, true, false, false, true, true)    // ragged
+LEAN_INSTANCE(ipm_solve_lean_warm_kernel, false, false, false, true)          // uniform, memory order
+LEAN_INSTANCE(ipm_solve_lean_warm_ordered_kernel, true, false, false, true)   // through a.order: ragged batches, hint classes
 
 }  // namespace btrapz

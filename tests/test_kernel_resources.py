@@ -39,7 +39,7 @@ def test_lean_kernels_fit_two_wavefronts_per_simd():
     ks = {}
     ks.update(kernels_of("btrapz_lean.o")); ks.update(kernels_of("btrapz_lean_warm.o"))
     lean = {n: r for n, r in ks.items() if "ipm_solve_lean" in n}
-    assert len(lean) == 11, sorted(lean)
+    assert len(lean) == 7, sorted(lean)   # (round 5: 11 until the ordered instantiations served ragged and uniform batches alike)
     for name, r in lean.items():
         # 512 registers per SIMD lane: two wavefronts need <= 256 each, all architectural; 160 KB of LDS per CU over eight
         assert r["vgpr"] <= 256 and r["agpr"] == 0, (name, r)

@@ -177,6 +177,35 @@ def main():
                        note="rocprofv3 --pmc passes (tools/collect_profiles.sh), means over the launches of one "
                             "bench.py --steps 3 --warmup 1 run; SQ cycle counters are in units of 4 clock cycles."),
                   open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)
+    # L2 behaviour per solve kernel (round 5; the optional counter groups of collect_profiles.sh): mean per launch
+    l2 = {}
+    for kern in ("ipm_solve_lean_capped_kernel", "ipm_solve_lean_resume_kernel"):
+        per = {}
+        for path in glob.glob(os.path.join(src, "pmc_opt_*", "**", "*counter_collection.csv"), recursive=True):
+            sums, launches = {}, {}
+            for row in csv.DictReader(open(path, newline="")):
+                if kern + "(" not in row["Kernel_Name"] and not row["Kernel_Name"].split("(")[0].endswith(kern):
+                    continue
+                sums[row["Counter_Name"]] = sums.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                launches.setdefault(row["Counter_Name"], set()).add(row["Dispatch_Id"])
+            for k, v in sums.items():
+                # (gpurun's merge keeps earlier runs' files: the newest CSV wins)
+                if k not in per or os.path.getmtime(path) > per[k][1]:
+                    per[k] = (v / max(len(launches[k]), 1), os.path.getmtime(path))
+        if per:
+            d = {k: v[0] for k, v in sorted(per.items())}
+            if d.get("TCC_REQ_sum"):
+                d["l2_hit_fraction"] = d.get("TCC_HIT_sum", 0.0) / d["TCC_REQ_sum"]
+            if d.get("TCP_TCC_READ_REQ_sum"):
+                d["read_requests_reaching_memory_fraction"] = d.get("TCC_EA0_RDREQ_sum", 0.0) / d["TCP_TCC_READ_REQ_sum"]
+            if d.get("TCP_TCC_WRITE_REQ_sum"):
+                d["write_requests_reaching_memory_fraction"] = d.get("TCC_EA0_WRREQ_sum", 0.0) / d["TCP_TCC_WRITE_REQ_sum"]
+            l2[kern] = d
+    if l2:
+        json.dump(dict(note="L2 (TCC) and L1->L2 (TCP_TCC) request counters of the two solve kernels of BASELINE config 3 (65 536 x 20, lean "
+                            "form, two launches), rocprofv3 --pmc in separate passes (tools/collect_profiles.sh quick), mean per launch.  "
+                            "TCC_EA0_* are the L2's memory-side requests (what FETCH_SIZE / WRITE_SIZE derive from).",
+                       kernels=l2, kernel_source_hash=stamp), open(os.path.join(dst, f"{tag}_pmc_l2.json"), "w"), indent=1)
     print("wrote profiles for", tag, "counters:", sorted(c))
 
 
