@@ -342,3 +342,50 @@ def test_a_candidate_with_an_infinite_bound_is_not_reported_solved(solver, lean)
     assert (r["status"][bad] <= 0).all() and not np.isfinite(r["cost"][bad]).any(), r["status"][bad]
     ok = np.ones(512, bool); ok[bad] = False
     assert np.array_equal(r["status"][ok], clean["status"][ok]) and np.array_equal(r["ctrl"][ok], clean["ctrl"][ok])
+
+
+def test_ragged_buckets_of_one_and_two_segments_in_the_lean_kernels(solver):
+    """Groups of one or two segments in the lean ORDERED instantiations (ragged batches): the root of the two-sided
+    elimination is the group's last lane, and its right neighbour is ANOTHER group's first lane -- what the root's step
+    must not add (btrapz_lean_body.h; since round 5 one select at the root's step, no fix-up inside the loops).  Mixed
+    buckets of 1, 2, 3 and 5 segments, shuffled, in one and two launches: the oracle's x*, and the packed form's accept set."""
+    import torch
+    from spectral_amd import layout as L
+    parts = [synth.make_batch(96, S, config=2) for S in (1, 2, 3, 5)]
+    sh = parts[0][1]
+    stride = 8
+    B = sum(p[0].B for p in parts)
+    seg = np.zeros((L.NUM_SEG_FIELDS, B, stride)); cnt = np.zeros(B, dtype=np.int32)
+    init = np.zeros((B, 6)); ref_end = np.zeros((B, 2)); dlb = np.zeros((B, 10))
+    src = [(pb, b) for pb, _ in parts for b in range(pb.B)]
+    perm = np.random.default_rng(4).permutation(B)
+    for dst, i in enumerate(perm):
+        pb, b = src[i]
+        seg[:, dst, :pb.S] = pb.seg[:, b, :]; cnt[dst] = pb.S
+        init[dst], ref_end[dst], dlb[dst] = pb.init[b], pb.ref_end[b], pb.dl_bounds[b]
+    t = lambda a: torch.from_numpy(a).to(solver.device)
+    rec = dict(B=B, seg_stride=stride, seg=t(seg), seg_count=t(cnt), init=t(init), ref_end=t(ref_end), dl_bounds=t(dlb))
+    res = {}
+    for label, kw in (("packed", dict(lean=-1, cap_iter=-1)), ("lean", dict(lean=1, cap_iter=-1)), ("lean2", dict(lean=1, cap_iter=3))):
+        o = solver.solve_ragged(rec, sh, **kw)
+        torch.cuda.synchronize()
+        res[label] = ({k: v.cpu().numpy().copy() for k, v in o.items()}, solver.ctx.last_solve_form())
+    assert (res["packed"][1], res["lean"][1], res["lean2"][1]) == (0, 8, 11)
+    p, l, l2 = res["packed"][0], res["lean"][0], res["lean2"][0]
+    assert np.array_equal(p["status"] > 0, l["status"] > 0) and (l["status"] > 0).sum() > B // 2
+    assert np.array_equal(l["status"], l2["status"]) and np.array_equal(l["cost"], l2["cost"]) and np.array_equal(l["iters"], l2["iters"])
+    ok = l["status"] > 0
+    assert np.array_equal(l["ctrl"][ok], l2["ctrl"][ok])
+    checked = {1: 0, 2: 0, 3: 0, 5: 0}
+    oracle = {pb.S: O.batch_solve(pb, sh, 0, 12, exact=True) for pb, _ in parts}
+    for dst, i in enumerate(perm):
+        pb, b = src[i]
+        if b >= 12:
+            continue
+        xs, obj, st, _ = oracle[pb.S]
+        assert (st[b] > 0) == (l["status"][dst] > 0), (pb.S, b)
+        if st[b] > 0:
+            assert np.abs(l["ctrl"][dst, :12 * pb.S] - xs[b]).max() <= RTOL * np.abs(xs[b]).max(), (pb.S, b)
+            assert np.abs(p["ctrl"][dst, :12 * pb.S] - xs[b]).max() <= RTOL * np.abs(xs[b]).max(), (pb.S, b)
+            checked[pb.S] += 1
+    assert all(v >= 6 for v in checked.values()), checked
