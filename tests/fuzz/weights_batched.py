@@ -165,6 +165,9 @@ def main():
                 bad = err > tol
                 key = (form,)
                 worst[form] = max(worst.get(form, 0.0), float(err.max()))
+                if err.max() > 3e-6 and form in ("lean", "packed"):   # (for the record: where the sweep's worst deviations sit)
+                    j = idx[np.argmax(err)]
+                    print("  NOTE %s %s: worst %.3e at b=%d (status %d, iters %d)" % (label, form, err.max(), j, r["status"][j], r["iters"][j]), flush=True)
                 if bad.any():
                     tally["beyond_tolerance"] += int(bad.sum())
                     j = idx[np.argmax(err)]
