@@ -1379,12 +1379,16 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
   /* Bounds that are no bounds (the reference leaves rows it does not use at +-1e10, src/trp.cc dl_bounds and the header's
    * limits; OSQP treats them as finite rows that never become active): they do not measure the problem -- a primal residual
    * relative to 1e10 would accept anything -- and a multiplier of 1 on a slack of 1e10 starts the method at mu = 1e9, where
-   * every step length is 1e-6 (round 5: candidate 26 of tests/test_gpu_forms.py's far-bounds batch never left the start).
-   * Such sides start centred with the rest, lambda = 1e4 / slack. */
+   * every step length is 1e-6 (round 5: candidate 26 of tests/test_gpu_forms.py's far-bounds batch never left the start);
+   * and a slack of 1e10 carries 1e-6 of absolute round-off into its row's residual (seen as 6e-6 in x* on the sweep's
+   * +-1e10 cases).  Such a side takes no part: no slack, multiplier 0, out of mu and of the residual norms. */
+  int *farl = (int *)calloc(mi + 1, sizeof(int)), *faru = (int *)calloc(mi + 1, sizeof(int)), nside = 0;
   for (int i = 0; i < m; i++) { if (fabs(qp->l[i]) < 1e9) bn = fmax(bn, fabs(qp->l[i])); if (fabs(qp->u[i]) < 1e9) bn = fmax(bn, fabs(qp->u[i])); }
   for (int i = 0; i < m; i++) if (!iseq[i]) {
     int r = rowpos[i]; sl[r] = fmax(0.0 - qp->l[i], 1.0); su[r] = fmax(qp->u[i] - 0.0, 1.0);
-    ll[r] = fmin(1.0, 1e4 / sl[r]); lu_[r] = fmin(1.0, 1e4 / su[r]);
+    farl[r] = isfinite(qp->l[i]) && qp->l[i] <= -1e9; faru[r] = isfinite(qp->u[i]) && qp->u[i] >= 1e9;   /* (an infinite bound is not a far one: such a corridor has no answer here, as in the product) */
+    ll[r] = farl[r] ? 0.0 : 1.0; lu_[r] = faru[r] ? 0.0 : 1.0;
+    nside += !farl[r] + !faru[r];
   }
   int best_it = 0, safe = 0;
   double score_hist[4] = {1e300, 1e300, 1e300, 1e300};
@@ -1401,10 +1405,11 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
       if (iseq[i]) { re[r] = Ax[i] - qp->l[i]; rpn = fmax(rpn, fabs(re[r])); }
       else {
         const double v = Ax[i] - delta * (lu_[r] - ll[r]);
-        rpl[r] = v - sl[r] - qp->l[i]; rpu[r] = v + su[r] - qp->u[i]; mu += sl[r] * ll[r] + su[r] * lu_[r]; rpn = fmax(rpn, fmax(fabs(rpl[r]), fabs(rpu[r])));
+        rpl[r] = farl[r] ? 0.0 : v - sl[r] - qp->l[i]; rpu[r] = faru[r] ? 0.0 : v + su[r] - qp->u[i];
+        mu += sl[r] * ll[r] + su[r] * lu_[r]; rpn = fmax(rpn, fmax(fabs(rpl[r]), fabs(rpu[r])));
       }
     }
-    mu = mi ? mu / (2.0 * mi) : 0;
+    mu = nside ? mu / nside : 0;
     double score = fmax(fmax(vnorm_inf(rd, n) / (1 + qn), rpn / (1 + bn)), mu);
     {  /* fmax() skips NaN: an iterate or a residual that is not finite must not pass for a small score */
       int finite = isfinite(mu) && isfinite(bn) && isfinite(qn);
@@ -1464,6 +1469,8 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
         if (pass == 0) { rcl[r] = sl[r] * ll[r]; rcu[r] = su[r] * lu_[r]; }
         else if (safe) { rcl[r] = sl[r] * ll[r] - sigma * mu; rcu[r] = su[r] * lu_[r] - sigma * mu; }
         else { rcl[r] = sl[r] * ll[r] - sigma * mu + dsl[r] * dll[r]; rcu[r] = su[r] * lu_[r] - sigma * mu + dsu[r] * dlu[r]; }
+        if (farl[r]) rcl[r] = 0.0;
+        if (faru[r]) rcu[r] = 0.0;
       }
       for (int j = 0; j < n; j++) rhs[j] = -rd[j];
       for (int i = 0; i < m; i++) {
@@ -1497,7 +1504,7 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
       for (int i = 0; i < m; i++) if (!iseq[i]) {
         int r = rowpos[i];
         const double g = (Adx[i] - delta * tt[r]) / (1.0 + delta * W[r]);
-        dsl[r] = g + rpl[r]; dsu[r] = -g - rpu[r];
+        dsl[r] = farl[r] ? 0.0 : g + rpl[r]; dsu[r] = faru[r] ? 0.0 : -g - rpu[r];
         dll[r] = (-rcl[r] - ll[r] * dsl[r]) / sl[r]; dlu[r] = (-rcu[r] - lu_[r] * dsu[r]) / su[r];
         if (dsl[r] < 0) ap = fmin(ap, -sl[r] / dsl[r]);
         if (dsu[r] < 0) ap = fmin(ap, -su[r] / dsu[r]);
@@ -1507,7 +1514,7 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
       if (pass == 0) {
         double mua = 0;
         for (int r = 0; r < mi; r++) mua += (sl[r] + ap * dsl[r]) * (ll[r] + ad * dll[r]) + (su[r] + ap * dsu[r]) * (lu_[r] + ad * dlu[r]);
-        mua = mi ? mua / (2.0 * mi) : 0;
+        mua = nside ? mua / nside : 0;
         sigma = mu > 0 ? pow(mua / mu, 3) : 0;
         if (safe) sigma = fmax(sigma, 0.2);
       } else {
@@ -1523,7 +1530,7 @@ static int ipm_core(const orc_qp *qp, double delta, double eps, int max_iter, do
   if (y_out) memcpy(y_out, by, sizeof(double) * m);
   status = best_score < 1e-7 ? 1 : (best_score < 1e-5 ? 2 : -2);
   for (int j = 0; j < n; j++) { double s = 0; const double *pr = Pd + (size_t)j * n; for (int k = 0; k < n; k++) s += pr[k] * bx[k]; obj += 0.5 * bx[j] * s + qp->q[j] * bx[j]; }
-  free(K0); free(rhs0); free(rres); free(dsc);
+  free(K0); free(rhs0); free(rres); free(dsc); free(farl); free(faru);
   free(Ad); free(Pd); free(K); free(piv); free(x); free(nu); free(sl); free(su); free(ll); free(lu_); free(Ax); free(rd);
   free(rpl); free(rpu); free(re); free(W); free(rhs); free(dsl); free(dsu); free(dll); free(dlu); free(rcl); free(rcu); free(Adx); free(tt); free(bx); free(by);
   }
