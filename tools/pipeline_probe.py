@@ -15,13 +15,18 @@ def main():
     solver = BatchSolver(0); d = solver.device
     B = int(os.environ.get("PP_BATCH", "65536")); st = 16
     kb = knots.jittered(knots.parse_corridor_file(os.path.join(gold, os.environ.get("PP_INPUT", "c_road_s1_3") + ".txt")), B, seed=3)
-    sh = synth.shared_params(0, weights=W)
+    sh = synth.shared_params(int(os.environ.get('PP_VARIANT', '0')), weights=W)
     sh.ds_ref, sh.dl_ref = kb.header["ds_ref"], kb.header["dl_ref"]
     sh.dds, sh.ddds, sh.ddl, sh.dddl = kb.header["dds"], kb.header["ddds"], kb.header["ddl"], kb.header["dddl"]
-    rec = solver.corridor_batch(kb, 0, seg_stride=st)
+    rec = solver.corridor_batch(kb, int(os.environ.get('PP_VARIANT', '0')), seg_stride=st)
     out = {}
     base = None
-    for label, kw in (("one", dict(cap_iter=-1)), ("one_nocompact", dict(cap_iter=-1, compact=-1)), ("cap4", dict(cap_iter=4)), ("cap6", dict(cap_iter=6)), ("cap8", dict(cap_iter=8)), ("cap10", dict(cap_iter=10)), ("packed", dict(cap_iter=-1, lean=-1))):
+    variant = int(os.environ.get("PP_VARIANT", "0"))
+    cases = [("one_nocompact", dict(cap_iter=-1, compact=-1)), ("one_compact", dict(cap_iter=-1, compact=1)), ("default", dict())]
+    for cap in (4, 5, 6, 7, 8):
+        cases += [("cap%d_nocompact" % cap, dict(cap_iter=cap, compact=-1))]
+    cases += [("cap6_compact", dict(cap_iter=6, compact=1)), ("packed", dict(cap_iter=-1, lean=-1, compact=-1))]
+    for label, kw in cases:
         for _ in range(2): o = solver.solve_ragged(rec, sh, **kw)
         torch.cuda.synchronize()
         best = 1e9
