@@ -818,18 +818,18 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     };
     auto backward_u = [&](const double (&u)[3], double (&dX)[3], double (&dc)[6]) {
       ldl3_solve(TF, u[0], u[1], u[2], dX[0], dX[1], dX[2]);
-      double y[3];
-      UNROLL for (int i = 0; i < 3; i++) y[i] = mid ? dX[i] : 0.0;
       SEQ_BEGIN();
       for (int step = m - 1; step >= 0; --step) {
-        double xin[3];   // (towards the root: from the right for the top lanes, from the left under the mask of the root and the bottom lanes)
-        UNROLL for (int i = 0; i < 3; i++) xin[i] = from_next(y[i]);
-        if (k >= m) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) xin[i] = from_prev(y[i]); }
+        // towards the root: from the right for the top lanes, from the left under the mask of the root and the bottom lanes.
+        // The neighbour towards the root has run the step before (the root needs none), so its dX is final when it is read:
+        // no second copy of the finished steps (until round 5 a lane published y = its final dX, 0 before, because both sides were added)
+        double xin[3];
+        UNROLL for (int i = 0; i < 3; i++) xin[i] = from_next(dX[i]);
+        if (k >= m) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) xin[i] = from_prev(dX[i]); }
         if (step == my_step) {
-          UNROLL for (int i = 0; i < 3; i++) {
-            dX[i] -= MK[3 * i] * xin[0] + MK[3 * i + 1] * xin[1] + MK[3 * i + 2] * xin[2];
-            y[i] = dX[i];
-          }
+          double r[3];
+          UNROLL for (int i = 0; i < 3; i++) r[i] = MK[3 * i] * xin[0] + MK[3 * i + 1] * xin[1] + MK[3 * i + 2] * xin[2];
+          UNROLL for (int i = 0; i < 3; i++) dX[i] -= r[i];
         }
       }
       SEQ_END();
