@@ -674,11 +674,12 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           const double ll = LL(r), lu = LU(r);
           const double gcr = row_dot<r>(c, t);
           const double s_l = sl[SI(r)], s_u = su[SI(r)];
-          const double rpl = gcr - s_l - LLO(r), rpu = gcr + s_u - LUP(r);
           RCP_PAIR(LEAN_RCP, s_l, s_u, isl, isu);
           const double wl = ll * isl, wu = lu * isu;
           row_outer<r>(wl + wu, t2, H);
-          row_scatter<r>(wl * (s_l + rpl) - wu * (s_u - rpu), t, hr);
+          // s_l + rp_l = G c - l and s_u - rp_u = u - G c: the slacks drop out of the predictor's right-hand side (round 5:
+          // formed directly -- four additions per row less than through the residuals, and one rounding less each)
+          row_scatter<r>(wl * (gcr - LLO(r)) - wu * (LUP(r) - gcr), t, hr);
         END_ROWS
       }
       ROW_SEP();
@@ -826,10 +827,9 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         double xin[3];
         UNROLL for (int i = 0; i < 3; i++) xin[i] = from_next(dX[i]);
         if (k >= m) { UNIFORM_BLOCK; UNROLL for (int i = 0; i < 3; i++) xin[i] = from_prev(dX[i]); }
-        if (step == my_step) {
-          double r[3];
-          UNROLL for (int i = 0; i < 3; i++) r[i] = MK[3 * i] * xin[0] + MK[3 * i + 1] * xin[1] + MK[3 * i + 2] * xin[2];
-          UNROLL for (int i = 0; i < 3; i++) dX[i] -= r[i];
+        if (step == my_step) {   // dX -= K xin, three fused multiply-adds per entry (until round 5 the product first, then the difference: 12 instructions for 9)
+          UNROLL for (int i = 0; i < 3; i++)
+            dX[i] = __builtin_fma(-MK[3 * i + 2], xin[2], __builtin_fma(-MK[3 * i + 1], xin[1], __builtin_fma(-MK[3 * i], xin[0], dX[i])));
         }
       }
       SEQ_END();
@@ -843,6 +843,13 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     LEAN_MARK("C");
     // ---- C. predictor (sigma = 0): statistics of the affine step ----
     // per row: multipliers from the lane's LDS column; slack, residuals and reciprocals recomputed
+    // (Round 5, built and REMOVED: the passes from here on working on the MOVED control points -- ds_l = (G (c + dc) - l) -
+    //  s_l, one row product where the residual and the step's row product are two: -240 instructions per iteration and a
+    //  worse method.  The slack then follows G (c + dc), rounded along a different path than the G c the next iteration
+    //  evaluates from the joint states, and the difference -- 1e-11 on a jerk row -- comes back every iteration as a fresh
+    //  primal residual the size of the active rows' slacks: +1.5 iterations, a third of the solves end at the round-off
+    //  floor, control points 1e-4 off.  As written here the residual is ONE expression of the current control points in
+    //  every pass, the step's row product an accurate small number, and the slacks absorb the expression's rounding.)
 #define LROW(r, RCP)                                                                                 \
       ROW_SEP_R(r);                                                                                   \
       const double ll = LL(r), lu = LU(r);                                                            \
@@ -884,26 +891,17 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
       const double ga = row_dot<r>(dca, t);                                                         \
       const double dsa = ga + rpl, dua = -ga - rpu;                                                 \
       const double rcl = __builtin_fma(second_order, (ll * dsa) * (1.0 + dsa * isl), __builtin_fma(s_l, ll, -sigma_mu)); \
-      const double rcu = __builtin_fma(second_order, (lu * dua) * (1.0 + dua * isu), __builtin_fma(s_u, lu, -sigma_mu)); \
-      const double el = rcl * isl, eu = rcu * isu, wl = ll * isl, wu = lu * isu;
-    // LEAN_E_CACHE: the corrected complementarity targets rc / s, el and eu, are the same numbers in the corrector's
-    // right-hand side (pass D), the step ratios (E1) and the update (E2).  1 (default): formed in D and again in E1, kept
-    // from E1 to E2 in the 60 registers the factorisation's blocks have just left; 2: formed in D only and kept through
-    // the corrector's solve -- 210 vector instructions per iteration less and 108 B of scratch per lane more, of iterate
-    // state spilled inside the sequential sweeps: 4.94 -> 5.33 ms on the scenario_1 batch, measured, rejected; 0: formed
-    // in all three passes, the two maxima of E1 through LDS atomics.
-    // 3 (round 5, default): as 1, but what is kept from E1 to E2 is the multipliers' steps dlambda themselves -- E1 forms
-    // them for the dual step ratio anyway -- so that the update needs no reciprocal slack, no weight and no target at all:
-    // -15 v_rcp_f64 and ~110 multiplications per iteration.  Measured (tools/ab_variants.py, 65 536 candidates, 1 -> 3):
-    // scenario_1 x 20 two launches 4.05 -> 3.97 ms, generic 3.71 -> 3.64, cuboid 3.98 -> 3.90, 10 segments 1.65 -> 1.62;
-    // same accept sets, control points within 8e-7 of those of 1 (the steps are now rounded once, not twice).
-#ifndef LEAN_E_CACHE
-#define LEAN_E_CACHE 3
-#endif
+      const double rcu = __builtin_fma(second_order, (lu * dua) * (1.0 + dua * isu), __builtin_fma(s_u, lu, -sigma_mu));
+    // The corrected complementarity residuals rc are the same numbers in the corrector's right-hand side (pass D) and in
+    // the step ratios (E1).  They are formed in both and kept in neither: a cache through the corrector's solve makes the
+    // allocator spill ITERATE state inside the sequential sweeps (round 4: -210 instructions, +108 B of scratch per lane,
+    // 4.94 -> 5.33 ms).  What IS kept, from E1 to the update E2 in the 60 registers the factorisation's blocks have just
+    // left, is the multipliers' steps dlambda -- E1 forms them for the dual step ratio anyway -- so that the update needs no
+    // reciprocal slack, no weight and no target (round 5: -15 v_rcp_f64, ~-110 multiplications per iteration; 4.05 ->
+    // 3.97 ms on the scenario_1 batch).  Round 5, later: both passes apply ONE reciprocal slack per side to
+    // (rc + lambda rp) and (rc + lambda ds) instead of forming the targets rc / s and the weights lambda / s first, and
+    // the predictor's right-hand side (A2) takes s + rp = G c - l directly: -150 instructions per iteration, 3.86 -> 3.78 ms.
     double dc[6];
-#if LEAN_E_CACHE == 2
-    double el_[NR], eu_[NR];
-#endif
     {
       double h[6], u[3];
       UNROLL for (int i = 0; i < 6; i++) h[i] = 0.0;
@@ -913,10 +911,8 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
         FOR_ROWS(r)
           LROW(r, LEAN_RCP)
           LROW_CORR(r)
-#if LEAN_E_CACHE == 2
-          el_[SI(r)] = el; eu_[SI(r)] = eu;
-#endif
-          row_scatter<r>((el - eu) + (wl * rpl + wu * rpu), t, h);
+          // (rc_l + lambda_l rp_l) / s_l - (rc_u - lambda_u rp_u) / s_u
+          row_scatter<r>(isl * __builtin_fma(ll, rpl, rcl) - isu * __builtin_fma(-lu, rpu, rcu), t, h);
         END_ROWS
       }
       {
@@ -933,46 +929,24 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
     // ---- E. step to the boundary, then the step ----
     {
       double pr = 0.0, dr = 0.0;
-#if LEAN_E_CACHE == 1 || LEAN_E_CACHE == 3
-      double el_[NR], eu_[NR];
-#endif
-#if LEAN_E_CACHE == 2
-      PHASE_FENCE(opaque6(c); opaque6(dc); fence_slacks());
-#else
+      double dll_[NR], dlu_[NR];
       PHASE_FENCE(opaque6(c); opaque6(dca); opaque6(dc); fence_slacks());
-#endif
       {
         ROW_LIMITS();
         FOR_ROWS(r)
           LROW(r, LEAN_RCP)
-#if LEAN_E_CACHE == 2
-          const double wl = ll * isl, wu = lu * isu, el = el_[SI(r)], eu = eu_[SI(r)];
-#else
           LROW_CORR(r)
-#endif
-#if LEAN_E_CACHE == 1
-          el_[SI(r)] = el; eu_[SI(r)] = eu;
-#endif
           const double gd = row_dot<r>(dc, t);
           const double dsl = gd + rpl, dsu = -gd - rpu;
-          const double dll = -el - wl * dsl, dlu = -eu - wu * dsu;
-#if LEAN_E_CACHE == 3   // the multipliers' steps themselves are kept for the update: it then needs no reciprocal at all
-          el_[SI(r)] = dll; eu_[SI(r)] = dlu;
-#endif
+          const double dll = -isl * __builtin_fma(ll, dsl, rcl), dlu = -isu * __builtin_fma(lu, dsu, rcu);   // dlambda = -(rc + lambda ds) / s
+          dll_[SI(r)] = dll; dlu_[SI(r)] = dlu;
           pr = fmax(pr, fmax(-dsl * isl, -dsu * isu));
           const double rll_ = rcp_fast(ll * lu);
           dr = fmax(dr, fmax(-dll * (lu * rll_), -dlu * (ll * rll_)));
         END_ROWS
       }
-#ifndef LEAN_E_ATOMIC
-#define LEAN_E_ATOMIC 0
-#endif
-#if LEAN_E_CACHE && !LEAN_E_ATOMIC
       const Red4 rs2 = group_reduce2<1, 1>(lds + LN_RED, lane, gbase, k, S, pr, dr);
       const Red4 rs = {0.0, rs2.a, rs2.b, 0.0};
-#else
-      const Red4 rs = group_reduce_mixed<-1, 1, 1, -1>(lds + LN_RED, lane, gbase, k, S, lane_in_group, 0.0, pr, dr, 0.0);
-#endif
     LEAN_MARK("E2");
       const double m_ = fmax(rs.b, rs.c);
       const double tau = (m_ * ka->tau_thr <= 1.0 && eit - it0 < ka->tau_iters) ? ka->tau : fmin(ka->tau, 0.995);
@@ -988,13 +962,8 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
 #endif
       if (!done && alpha == alpha) {
         UNROLL for (int i = 0; i < 3; i++) X[i] += alpha_p * dX[i];
-#if LEAN_E_CACHE
         PHASE_FENCE(opaque6(c); opaque6(dc); fence_slacks());
-#else
-        PHASE_FENCE(opaque6(c); opaque6(dca); opaque6(dc); fence_slacks());
-#endif
         ROW_LIMITS();
-#if LEAN_E_CACHE == 3
         FOR_ROWS(r)
           ROW_SEP_R(r);
           const double ll = LL(r), lu = LU(r);
@@ -1004,22 +973,8 @@ __device__ __forceinline__ void lean_solve_body(const KernelArgs &a, const doubl
           const double gd = row_dot<r>(dc, t);
           const double dsl = gd + rpl, dsu = -gd - rpu;
           sl[SI(r)] = s_l + alpha_p * dsl; su[SI(r)] = s_u + alpha_p * dsu;
-          LL(r) = ll + alpha_d * el_[SI(r)]; LU(r) = lu + alpha_d * eu_[SI(r)];
+          LL(r) = ll + alpha_d * dll_[SI(r)]; LU(r) = lu + alpha_d * dlu_[SI(r)];
         END_ROWS
-#else
-        FOR_ROWS(r)
-          LROW(r, LEAN_RCP)
-#if LEAN_E_CACHE
-          const double wl = ll * isl, wu = lu * isu, el = el_[SI(r)], eu = eu_[SI(r)];
-#else
-          LROW_CORR(r)
-#endif
-          const double gd = row_dot<r>(dc, t);
-          const double dsl = gd + rpl, dsu = -gd - rpu;
-          sl[SI(r)] = s_l + alpha_p * dsl; su[SI(r)] = s_u + alpha_p * dsu;
-          LL(r) = ll + alpha_d * (-el - wl * dsl); LU(r) = lu + alpha_d * (-eu - wu * dsu);
-        END_ROWS
-#endif
       }
     }
 #undef LROW
