@@ -127,12 +127,50 @@ def test_weight_search_result_is_what_the_goldens_pin():
     assert res["files"]["s7_slt_3d_3.txt"]["all"]["max_abs_diff"] > 0.1
 
 
+def test_scenario1_cannot_be_pinned_by_a_reference_written_file(tmp_path):
+    """VERDICT r5 item 2.  scenario_1 = src/c1.txt.  Every hypothesis that could tie one of the saved s1_* trajectories to it
+    (tests/golden/pin_scenario1.py: the OSQP port's stopping point under the 204 logged weight rows; the old libbtrapz.so's
+    c1.txt -> slt_3d.txt pair; the segment references read at four other places than solve_3d.cc:1159-1166 reads them) ends
+    at "no": no file comes closer than 0.2 m in all seven columns.  The cause is in the reference: its harness rewrites the
+    corridor file at every replanning step (cart_frenet.py:385-386), so a saved output's input is gone unless the run
+    happened to be the last one -- c4 / c5 / c2 were (pinned above), c1 was not.  scenario_1's anchor therefore stays the row
+    count + first row (PAIRS) and x* -- and the test below is a NOTE on how close a free fit gets, not evidence."""
+    import json, subprocess, sys
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    rec = json.load(open(os.path.join(gold, "scenario1_pin_search.json")))
+    assert rec["pinned_by_any_hypothesis"] == []
+    assert len(rec["hypotheses"]) == 7
+    for name, h in rec["hypotheses"].items():
+        assert h["pinned"] == []
+        for f, r in h.get("files", {}).items():
+            if r["all"] is not None:
+                assert r["all"]["max_abs_diff"] > 0.2, (name, f)     # 400 x the print precision
+    h2 = rec["hypotheses"]["H2_old_library_pair"]
+    assert not h2["slt_3d.txt"]["first_row_is_c1s"] and h2["slt_3d.txt"]["first_row"][3] == 5.0
+    assert h2["s1_slt_3d.txt"]["first_row_is_c1s"] and h2["s1_slt_3d.txt"]["rows"] == 75
+    assert h2["s1_slt_3d.txt"]["rows_from_c1_trapezoid"] == 70 and h2["s1_slt_3d.txt"]["rows_from_c1_cuboid"] == 74
+    # the committed record is what the script writes (the whole search takes seconds)
+    work = tmp_path / "golden"
+    import shutil
+    shutil.copytree(gold, str(work), ignore=shutil.ignore_patterns("*.npz", "corridors.json", "__pycache__"))
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(__file__)))
+    src = open(os.path.join(str(work), "pin_scenario1.py")).read().replace("ROOT = os.path.dirname(os.path.dirname(HERE))",
+                                                                           "ROOT = %r" % os.path.dirname(os.path.dirname(__file__)))
+    open(os.path.join(str(work), "pin_scenario1.py"), "w").write(src)
+    r = subprocess.run([sys.executable, os.path.join(str(work), "pin_scenario1.py")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    again = json.load(open(os.path.join(str(work), "scenario1_pin_search.json")))
+    assert again == rec
+
+
 FIT = [("s1_slt_3d_30.txt", "c1", 0, 0.0085), ("s1_cub_3d_3.txt", "c1", 1, 0.0150), ("s1_cub_3d_30.txt", "c1", 1, 0.0205)]
 
 
 @pytest.mark.parametrize("ref,name,variant,s_residual", FIT)
 def test_scenario1_lateral_columns_are_reproduced_by_fitted_weights(ref, name, variant, s_residual, tmp_path):
-    """Round 3 (tests/golden/fit_weights.py -> weight_fit.json): no LOGGED weight row reproduces the saved scenario_1
+    """A NOTE, not a pin (ten free parameters that run to 1.6e5 are a fit): how close a free choice of weights
+    brings the restatement to three files the reference wrote from some version of src/c1.txt.
+    Round 3 (tests/golden/fit_weights.py -> weight_fit.json): no LOGGED weight row reproduces the saved scenario_1
     trajectories, but a continuous fit of the weights does on the lateral axis -- the l, dl, ddl columns of three files
     the reference wrote from src/c1.txt come back to print precision from the restatement's x* -- and brings the
     longitudinal columns from 0.05-0.7 to the stated residual (a floor every start of the fit ends at: those runs
