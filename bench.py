@@ -69,6 +69,12 @@ def parse():
     ap.add_argument("--share-device", action="store_true",
                     help="dry run of the N > 1 flow on a 1-GPU box: every rank uses device 0 (use with --backend gloo)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0: pick a free one)")
+    ap.add_argument("--host", default="ranks", choices=["ranks", "one-process"],
+                    help="who drives the N devices: `ranks` = one process per GPU (torch.distributed; what the driver's torchrun line "
+                         "starts), `one-process` = ONE host process over the C-ABI's btrapz_multi_* step (a context + stream per device, "
+                         "RCCL resolved by dlopen, else peer copies; no torch in the process).  The launcher starts the second as a fresh "
+                         "child when the ranks end non-zero without a line")
+    ap.add_argument("--fallback-from", default="", help=argparse.SUPPRESS)   # (set by the launcher: why the ranks did not produce the line)
     return ap.parse_args()
 
 
@@ -91,7 +97,44 @@ def self_launch(a):
     env = dict(os.environ)
     # (dmabuf IPC: the only mode this pool's host driver supports -- see spectral_amd.dist.init_process_group)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)   # the launcher's exit code: non-zero when any rank failed (it ends the others)
+    rc, got_line = run_child(cmd, env)
+    if rc == 0 or got_line:
+        return rc                          # the launcher's exit code: non-zero when any rank failed (it ends the others)
+    # The ranks ended without a line (RCCL's bootstrap, IPC handles, a rank that died): the same step has a second host
+    # that needs neither torch.distributed nor IPC -- one process, all devices (btrapz_multi_*).  A FRESH child of this
+    # launcher, which has not touched the GPU; never a re-exec of a process that has.
+    sys.stderr.write("bench.py: the %d ranks ended with exit code %d before a line was printed: running the step with --host one-process\n" % (a.gpus, rc))
+    return one_process_child(a, "torch.distributed ranks (backend %s) ended with exit code %d before their first line" % (a.backend, rc))
+
+
+def run_child(cmd, env):
+    """Runs cmd, passes its stdout through, says whether a JSON line was among it."""
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    got = False
+    for line in p.stdout:
+        got = got or line.lstrip().startswith("{")
+        sys.stdout.write(line); sys.stdout.flush()
+    return p.wait(), got
+
+
+def one_process_argv():
+    argv, skip = [], False
+    for x in sys.argv[1:]:          # the same command line without what belongs to the ranks
+        if skip:
+            skip = False
+        elif x in ("--host", "--fallback-from", "--backend", "--master-port"):
+            skip = True
+        elif not x.startswith(("--host=", "--fallback-from=", "--backend=", "--master-port=")):
+            argv.append(x)
+    return argv
+
+
+def one_process_child(a, reason):
+    argv = one_process_argv()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                            "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    rc, _ = run_child([sys.executable, os.path.abspath(__file__)] + argv + ["--host", "one-process", "--fallback-from", reason], env)
+    return rc
 
 
 def kernel_stamp():
@@ -173,9 +216,133 @@ def cpu_baseline(batch, shared, seconds):
             "libosqp_so": osqp}
 
 
+class HipEvents:
+    """hipEvent timing on a stream of the C-ABI's own (ctypes on the HIP runtime the library is bound to; the one-process
+    host has no torch in it)."""
+
+    def __init__(self):
+        import ctypes as C
+        from spectral_amd import native
+        native.lib()
+        self.C, self.hip = C, C.CDLL(native.ROCM_HIP_RUNTIME if "torch" not in sys.modules else
+                                     os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib", "libamdhip64.so"))
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+
+    def create(self):
+        e = self.C.c_void_p()
+        assert self.hip.hipEventCreate(self.C.byref(e)) == 0
+        return e
+
+    def record(self, e, stream):
+        assert self.hip.hipEventRecord(e, stream) == 0
+
+    def elapsed_ms(self, e0, e1):
+        ms = self.C.c_float()
+        assert self.hip.hipEventElapsedTime(self.C.byref(ms), e0, e1) == 0
+        return float(ms.value)
+
+
+def one_process_main(a):
+    """--host one-process: the same step -- solve of the device's shard, local arg-min, ONE gather of (cost, index, the local
+    winner's control points), the same lexicographic min on every device -- driven by ONE host process through the C-ABI
+    (btrapz_multi_*, csrc/btrapz_multi.hip): a context and a stream per device, every launch asynchronous, the gather by
+    RCCL (librccl resolved at run time) or, without it, by stream-ordered peer copies.  --share-device: N LOGICAL devices
+    on device 0 (own context, stream, buffers and shard each; copies as transport)."""
+    from spectral_amd import native
+    from spectral_amd.layout import Batch
+    if not os.path.exists(native.LIB_PATH):
+        native.build()
+    N, S = a.gpus, a.segments
+    have = int(native.lib().btrapz_device_count())
+    if have < 1:
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    if have < N and not a.share_device:
+        sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) visible\n" % (N, have))
+        return 3
+    devices = [0] * N if a.share_device else list(range(N))
+    if a.scaling == "weak":       # a batch per device, the ranks' batches in rank order: shard g of the C-ABI == rank g's batch
+        parts = [make_workload(a.workload, a.batch, S, a.variant, r) for r in range(N)]
+        shared = parts[0][1]
+        cat = lambda k, ax: np.ascontiguousarray(np.concatenate([getattr(p[0], k) for p in parts], axis=ax))
+        batch = Batch(B=N * a.batch, S=S, seg=cat("seg", 1), init=cat("init", 0), ref_end=cat("ref_end", 0), dl_bounds=cat("dl_bounds", 0))
+        del parts
+    else:
+        batch, shared = make_workload(a.workload, a.batch, S, a.variant, 0)
+    total = batch.B
+    m = native.MultiContext(devices, native.MULTI_AUTO)
+    m.upload(batch)
+    call = m.prepared_step(shared, lean=a.lean)
+    ev = HipEvents()
+    stream0 = m.view(0).stream
+    native.lib()  # (bound)
+    for _ in range(a.warmup):
+        call()
+    m.wait()
+    pairs = [(ev.create(), ev.create()) for _ in range(a.steps)]
+    ev.hip.hipSetDevice(devices[0])
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev.record(pairs[i][0], stream0)      # device slot 0's stream: its share of the step, gather and select included
+        call()
+        ev.record(pairs[i][1], stream0)
+    m.wait()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([ev.elapsed_ms(e0, e1) for e0, e1 in pairs]))
+    win_idx, win_cost, win_ctrl = m.result()
+    res = m.download()
+    status, iters = res["status"], res["iters"]
+    ok = (status == 1) | (status == 2)
+    mean_iters = float(np.mean(iters + 1))
+    B0 = m.view(0).B
+    form0 = int(native.lib().btrapz_last_solve_form(m.view(0).ctx))
+    rccl = m.transport() == native.MULTI_RCCL
+    alg = batch.algorithmic_bytes() * B0
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    flops = 2.0 * B0 * S * mean_iters * FLOPS_PER_SEGMENT_ITER
+    out = {
+        "metric": "trajectory QP solves/sec (20-seg order-5 corridor)", "value": total * a.steps / elapsed, "unit": "solves/s",
+        "n_gpus": N, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload_label(a.workload, a.batch, S, a.variant, N, a.scaling), "generator": a.workload,
+                   "batch_per_gpu": a.batch if a.scaling == "weak" else None, "batch_total": total, "segments": S, "variant": a.variant,
+                   "parallelism": "shard%d" % N,
+                   "host": "one process, %d device slot(s) %s through the C-ABI (btrapz_multi_*): a context + stream per device" % (N, devices),
+                   "collective": "none" if N == 1 else (
+                       "rccl ncclAllGather in one group call (%s)" % m.transport_library() if rccl else
+                       "stream-ordered peer copies (hipMemcpyPeerAsync / same-device copies for logical devices)" +
+                       (": " + m.fallback_reason() if m.fallback_reason() else "")) + " of (cost, index, the local winner's control points) = %d B per device and step" % (16 + 96 * S),
+                   "fallback_from": a.fallback_from or None},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": SOLVE_FORMS.get(form0, "btrapz::ipm_solve_kernel"), "kernel_ms": kernel_ms, "kernel_source_hash": kernel_stamp(),
+                     "algorithmic_bytes_per_solve": batch.algorithmic_bytes(),
+                     "note": "device slot 0: HIP events on ITS stream around the whole step (solve of its %d candidates + arg-min + pack + gather + "
+                             "select; the solve kernels are all but ~30 us of it) -- the one-process host issues a step as ONE C call; "
+                             "on-chip solve, FP64 VALU issue is the binding resource (SURVEY 8d)" % B0,
+                     "fp64_valu": {"achieved_tflops": flops / (kernel_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                                   "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                   "model": "%.0f useful flops per segment per iteration x %.2f mean iterations" % (FLOPS_PER_SEGMENT_ITER, mean_iters)}},
+        "solved_fraction": float(ok.mean()), "mean_ipm_iterations": mean_iters,
+        "status_counts": {str(int(k)): int((status == k).sum()) for k in np.unique(status)},
+        "winner": {"index": int(win_idx), "cost": float(win_cost), "ctrl_sum": float(np.sum(win_ctrl)), "ctrl_head": [float(v) for v in win_ctrl[:4]]},
+        "shard_sizes": [int(m.view(g).B) for g in range(N)],
+        "cpu_baseline": None,
+    }
+    out["solved_solves_per_s"] = out["value"] * out["solved_fraction"]
+    if N == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(batch, shared, a.cpu_seconds)
+    m.close()
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     a = parse()
     world_env = os.environ.get("WORLD_SIZE")
+    if a.host == "one-process":
+        if world_env is not None and int(os.environ.get("RANK", "0")) != 0:
+            return                               # (started under torchrun: ONE of the ranks is the one process)
+        raise SystemExit(one_process_main(a))
     if a.gpus > 1 and world_env is None:
         raise SystemExit(self_launch(a))
     import torch
@@ -206,7 +373,33 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         from spectral_amd.dist import init_process_group
-        init_process_group(a.backend, local_rank)      # 60 s timeout on every collective; RCCL bound to the device at once
+        try:
+            init_process_group(a.backend, local_rank)      # 60 s timeout on every collective; RCCL bound to the device at once
+            # first contact, before anything is timed: one collective of the step's own kind on this rank's device
+            probe = torch.full((1, 2), float(rank), dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+            got = torch.empty((world, 2), dtype=torch.float64, device=probe.device)
+            dist.all_gather_into_tensor(got, probe)
+            torch.cuda.synchronize()
+            assert got[:, 0].tolist() == [float(r) for r in range(world)], got
+        except Exception as e:
+            # The ranks cannot talk (RCCL's bootstrap, IPC handles, an unknown backend): the step has a second host that needs
+            # neither.  Rank 0 starts it as a FRESH child process (never a re-exec: this process has initialised the GPU) and
+            # leaves with its exit code; the other ranks leave quietly, so that the launcher sees the child's line and code.
+            sys.stderr.write("bench.py: rank %d: first contact over %s failed: %r\n" % (rank, a.backend, e))
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+            if rank != 0:
+                os._exit(0)
+            sys.stderr.write("bench.py: rank 0: running the step with --host one-process instead\n")
+            argv = [x for x in one_process_argv() if x]
+            env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                                    "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + argv +
+                                 ["--host", "one-process", "--fallback-from", "rank 0's first collective over %s: %s" % (a.backend, repr(e)[:160])],
+                                 env=env, stdout=line_out)
+            os._exit(rc)
     solver = BatchSolver(local_rank)
     dev = solver.device
 

@@ -207,9 +207,10 @@ typedef struct btrapz_options {
   int elastic;
   double elastic_tol;
   double elastic_delta;
-  /* EXPERIMENTAL, ignored by the shipped library (honoured by a -DBTRAPZ_EXPERIMENTS build): persistent wavefronts that
-   * draw candidates from a queue.  Scheduling only.  Measured against the two launches of cap_iter: a loss on every bench
-   * batch.  The field stays so that the struct's layout does. */
+  /* EXPERIMENTAL, honoured by a -DBTRAPZ_EXPERIMENTS build only; the shipped library has no such kernel and answers
+   * queue > 0 with BTRAPZ_EINVAL (btrapz_build_has_experiments() says which build a caller holds): persistent wavefronts
+   * that draw candidates from a queue.  Scheduling only.  Measured against the two launches of cap_iter: a loss on every
+   * bench batch.  The field stays so that the struct's layout does. */
   int queue;
   /* Few candidates: the split form of the solve kernel -- ONE candidate per wavefront, every segment's rows spread over
    * three lanes (uniform cold batches of at most 21 segments).  Per solve it takes ~0.7 of the time of the
@@ -217,7 +218,8 @@ typedef struct btrapz_options {
    * 0 -> automatic (used when 2 B wavefronts fit the device's SIMDs at once); 1 -> whenever the batch qualifies;
    * -1 -> never.  Same problem, same method: results agree to rounding (the row sums are taken in another order). */
   int split;
-  /* EXPERIMENTAL, ignored by the shipped library (honoured by a -DBTRAPZ_EXPERIMENTS build): 1 = start a cold solve
+  /* EXPERIMENTAL, honoured by a -DBTRAPZ_EXPERIMENTS build only (the shipped library answers start != 0 with
+   * BTRAPZ_EINVAL): 1 = start a cold solve
    * from the unconstrained optimum (one Newton step of the problem without its inequality rows) instead of the initial
    * state propagated at constant velocity.  The optimum does not depend on it; the iteration count does, for the worse
    * (DESIGN.md 3.2).  The field stays so that the struct's layout does. */

@@ -426,6 +426,14 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
   a.x_out = nullptr;
   const int elastic = opt ? opt->elastic : 0;
   if (elastic < 0 || elastic > 2) { c->err = "invalid argument: btrapz_options.elastic"; return BTRAPZ_EINVAL; }
+#ifndef BTRAPZ_EXPERIMENTS
+  // the two experimental schedules exist in -DBTRAPZ_EXPERIMENTS builds only: asking this build for one is an error, not a
+  // silent default (btrapz_build_has_experiments() tells a caller which build it holds)
+  if (opt && (opt->queue > 0 || opt->start != 0)) {
+    c->err = "invalid argument: btrapz_options.queue / .start are honoured by -DBTRAPZ_EXPERIMENTS builds only (this build has neither kernel)";
+    return BTRAPZ_EINVAL;
+  }
+#endif
   unsigned blocks;
   const int *hint = (warm && !seg_count) ? warm->hint : nullptr;   // uniform batches only
   // Candidates that cannot start (btrapz_options.compact): a pre-pass lists the live ones, the launches below take them

@@ -1416,6 +1416,13 @@ __global__ __launch_bounds__(64) void prestart_kernel(const KernelArgs a, int S_
     const bool any3 = (__ballot(act && dead3) & gmask) != 0, any2 = (__ballot(act && dead2) & gmask) != 0;
     st_axis[axis] = any3 ? BTRAPZ_PRIMAL_INFEASIBLE : any2 ? BTRAPZ_MAX_ITER_REACHED : 0;
   }
+  // A dropped candidate never reaches a solve kernel: its control points are written HERE, as NaN -- a caller that reads
+  // every row (eval_states feeding x0 of a later warm start, say) meets a value the warm start refuses instead of whatever
+  // the buffer held.  12 doubles per lane of the candidate's slot of 12 * seg_stride.
+  if (in_wave && a.ctrl && (!usable || st_axis[0] != 0 || st_axis[1] != 0)) {
+    double *dst = a.ctrl + ((size_t)b * stride + k) * 12;
+    UNROLL for (int i = 0; i < 12; i++) dst[i] = __longlong_as_double(0x7ff8000000000000LL);
+  }
   if (!in_wave || !first) return;
   if (!usable) {   // no usable corridor (what bucket_scatter_kernel writes for these)
     keys[b] = 0;

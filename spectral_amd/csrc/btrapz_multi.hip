@@ -14,7 +14,26 @@
 // Logical devices: the same ordinal may appear several times in `devices` -- every entry still gets its own context,
 // stream, buffers and shard, and the whole path (shard, solve, local arg-min, pack, gather, select) runs on a 1-GPU box.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>   // types and prototypes only: every RCCL function is called through dlsym
+// RCCL: types and prototypes only -- every function is called through dlsym.  A ROCm installation without the rccl
+// development headers still builds the whole library (single-GPU path and drop-in shims included): the handful of
+// declarations the step needs are then stated here, as RCCL's public header states them.
+#if __has_include(<rccl/rccl.h>) && !defined(BTRAPZ_NO_RCCL_HEADER)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5,
+               ncclFloat16 = 6, ncclHalf = 6, ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+ncclResult_t ncclCommInitAll(ncclComm_t *comms, int ndev, const int *devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+const char *ncclGetErrorString(ncclResult_t result);
+ncclResult_t ncclGetVersion(int *version);
+}
+#endif
 
 #include <dlfcn.h>
 
@@ -299,6 +318,12 @@ static int ensure_outputs(btrapz_multi *m, Shard &s, int S, int n_local, int n_g
   // record per group, packed straight into `gathered` (the select kernel runs on them with world = 1)
   const size_t rec = (m->global_groups ? ng : nl) * (2 + P), gat = m->global_groups ? rec * (size_t)m->G : rec;
   if (rec > s.rec_cap || gat > s.gat_cap) {
+    // rec is READ and gathered WRITTEN by the other devices (peer copies on their streams; RCCL's kernels over xGMI), and
+    // hipFree waits for the owning device only: every slot's stream is drained before the two go (ADVICE r5 -- a step
+    // issued after btrapz_multi_set_shards with more segments, the last step's gather still in flight on a peer)
+    for (Shard &o : m->sh)
+      if (o.stream) { MCHK(m, hipSetDevice(o.device)); MCHK(m, hipStreamSynchronize(o.stream)); }
+    MCHK(m, hipSetDevice(s.device));
     (void)hipFree(s.rec); (void)hipFree(s.gathered); s.rec = nullptr; s.gathered = nullptr; s.rec_cap = 0; s.gat_cap = 0;
     MCHK(m, hipMalloc(&s.rec, sizeof(long long) * rec)); MCHK(m, hipMalloc(&s.gathered, sizeof(long long) * gat));
     s.rec_cap = rec; s.gat_cap = gat;

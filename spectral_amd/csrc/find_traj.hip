@@ -129,12 +129,16 @@ bool wait_for_results(const double *h_out, hipStream_t stream, bool poll) {
   return hipStreamSynchronize(stream) == hipSuccess;
 }
 
-// BTRAPZ_ELASTIC=0 turns the rescue pass of find_traj off (strict mode: a QP without a solution is a failure);
-// BTRAPZ_ELASTIC_TOL overrides btrapz_options.elastic_tol (largest accepted row violation / |g|, default 0.01).
+// BTRAPZ_ACCEPT=reference (or its older spelling BTRAPZ_ELASTIC=0) turns the rescue pass of find_traj off -- the strict
+// mode: a QP without a solution is a failure, as it is for the reference whenever OSQP declares infeasibility
+// (trp_wrapper.cpp:191-200; INTEGRATION.md section 3 lists the bundled inputs on which the DEFAULT differs);
+// BTRAPZ_ACCEPT=rescue is the default.  BTRAPZ_ELASTIC_TOL overrides btrapz_options.elastic_tol (largest accepted row
+// violation / |g|, default 0.0125).
 struct ElasticEnv { bool on; double tol; };
 ElasticEnv elastic_env() {
-  const char *e = getenv("BTRAPZ_ELASTIC"), *t = getenv("BTRAPZ_ELASTIC_TOL");
+  const char *e = getenv("BTRAPZ_ELASTIC"), *t = getenv("BTRAPZ_ELASTIC_TOL"), *acc = getenv("BTRAPZ_ACCEPT");
   ElasticEnv r = {!(e && *e == '0'), 0.0};
+  if (acc && *acc) r.on = !(acc[0] == 'r' && acc[1] == 'e' && acc[2] == 'f');   // "reference": strict; anything else ("rescue"): the default
   if (t) { const double v = atof(t); if (v > 0) r.tol = v; }
   return r;
 }

@@ -96,6 +96,39 @@ def test_rescue_can_be_turned_off(tmp_path, monkeypatch):
     assert native.find_traj_native(0, p, os.path.join(GOLD, "inputs", "c7.txt"), str(tmp_path / "o.txt")) < 1e10
 
 
+def test_strict_mode_decides_as_the_reference_wherever_the_qp_has_no_optimum(tmp_path, monkeypatch):
+    """BTRAPZ_ACCEPT=reference (the strict mode; older spelling BTRAPZ_ELASTIC=0) on all 26 bundled rows,
+    through the drop-in libraries.  Wherever the QP has no optimum the call returns 1e11 -- the decision of the oracle's OSQP
+    port on every such row but one: c7.txt / trapezoid, where the reference returns OSQP's status 2, an ADMM iterate 0.49 m/s^2
+    outside its acceleration rows (no rule on the problem separates it from c7_7 / c7_10, which the same ADMM rejects).
+    Where the QP has an optimum the strict mode returns it, as the default does."""
+    monkeypatch.setenv("BTRAPZ_ACCEPT", "reference")
+    monkeypatch.setenv("BTRAPZ_OUTPUT_PREFIX", str(tmp_path / "t_"))
+    libs = {}
+    for v, name in ((0, "libtrp.so"), (1, "libcub.so")):
+        libs[v] = C.CDLL(os.path.join(native.LIB_DIR, name))
+        libs[v].find_traj.argtypes = (C.POINTER(trp_wrapper.Params),); libs[v].find_traj.restype = C.c_double
+    no_optimum, differs = 0, []
+    for r in TABLE["rows"]:
+        monkeypatch.setenv("BTRAPZ_INPUT", os.path.join(GOLD, "inputs", r["input"] + ".txt"))
+        accepted = libs[r["variant"]].find_traj(trp_wrapper.Params(*W, 3)) != SENTINEL
+        if r["exact_status"] in (1, 2):
+            assert accepted and r["hip_accepts"], r["input"]                    # an optimum is returned in either mode
+        else:
+            no_optimum += 1
+            assert not accepted, r["input"]                                     # strict: never an answer without an optimum
+            if r["port_accepts"]:
+                differs.append((r["input"], r["variant"]))
+    assert no_optimum == 9 and differs == [("c7", 0)]
+    # the default (and BTRAPZ_ACCEPT=rescue) on one of the five product-only rescued rows; BTRAPZ_ACCEPT wins over the old spelling
+    monkeypatch.setenv("BTRAPZ_INPUT", os.path.join(GOLD, "inputs", "c7_7.txt"))
+    monkeypatch.setenv("BTRAPZ_ACCEPT", "rescue")
+    monkeypatch.setenv("BTRAPZ_ELASTIC", "0")
+    assert libs[0].find_traj(trp_wrapper.Params(*W, 3)) != SENTINEL
+    monkeypatch.delenv("BTRAPZ_ACCEPT")
+    assert libs[0].find_traj(trp_wrapper.Params(*W, 3)) == SENTINEL
+
+
 def test_agreement_with_the_osqp_port_is_reported_separately():
     """agreement with the reference's (ported) OSQP decision, counted apart from agreement with the oracle's
     restatement of the product's own relaxed problem.  Of the 26 bundled rows the port and the product decide alike on

@@ -53,6 +53,14 @@ def test_bad_arguments_are_reported_not_fatal():
     assert lib.btrapz_prism_corridor_batch_device(h, 0, 8, 2, 71, None, p(o["cost"]), 5, C.c_double(0.1), *[p(o["cost"])] * 4, 16, p(o["cost"]),
                                                   p(o["status"]), p(o["cost"]), p(o["cost"]), None, None) == EINVAL   # no road
     assert lib.btrapz_destroy(None) == EINVAL
+    # the two experimental schedules: an error in the shipped build, not a silent default
+    if not lib.btrapz_build_has_experiments():
+        for kw in (dict(queue=1), dict(start=1)):
+            opt = native._options(**kw)
+            bad = list(args(8, 10)); bad[2] = C.byref(opt)
+            assert lib.btrapz_solve_batch_device(*bad) == EINVAL and b"EXPERIMENTS" in lib.btrapz_last_error(h)
+            with pytest.raises(native.BtrapzError):
+                solver.solve(db, sh, **kw)
     # the context still works, and gives the same answer
     o2 = solver.solve(db, sh)
     torch.cuda.synchronize()

@@ -38,6 +38,36 @@ def test_two_ranks_on_one_gpu_pick_the_single_rank_winner():
         assert line["roofline"]["frac"] > 0 and "cpu_baseline" in line and line["value"] > 0
 
 
+def test_one_process_host_returns_the_single_rank_winner_and_serves_as_fallback():
+    """`--host one-process` -- ONE host process over the C-ABI's btrapz_multi_* step, here with two LOGICAL
+    devices on the box's one GPU (own context, stream, buffers and shard each; copies as transport) -- returns the
+    single-rank winner bit for bit; and when the torch.distributed ranks cannot talk (a backend that does not exist stands
+    in for an RCCL bootstrap / IPC failure) the line still comes, from that host, and says so."""
+    one = run("--gpus", "1", "--scaling", "strong")
+    op = run("--gpus", "2", "--scaling", "strong", "--share-device", "--host", "one-process")
+    assert op["n_gpus"] == 2 and op["winner"] == one["winner"] and op["shard_sizes"] == [3000, 3000]
+    assert op["config"]["host"].startswith("one process, 2 device slot(s) [0, 0]") and "copies" in op["config"]["collective"]
+    assert op["config"]["fallback_from"] is None and op["roofline"]["frac"] > 0 and op["value"] > 0
+    # launched by bench.py itself: the ranks fail at first contact, rank 0 hands over
+    fb = run("--gpus", "2", "--scaling", "strong", "--share-device", "--backend", "no-such-backend")
+    assert fb["winner"] == one["winner"] and fb["config"]["host"].startswith("one process")
+    assert "no-such-backend" in fb["config"]["fallback_from"]
+    # ... and as the driver launches it: torch.distributed.run starts the ranks, bench.py is a rank
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "6000",
+                        "--no-cpu-baseline", "--latency-reps", "0", "--no-secondary", "--lean", "1", "--scaling", "strong", "--share-device",
+                        "--backend", "no-such-backend"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    drv = json.loads(lines[0])
+    assert drv["winner"] == one["winner"] and "rank 0's first collective" in drv["config"]["fallback_from"]
+
+
 def test_argmin_pairs_kernel_equals_the_torch_reduction():
     """btrapz_argmin_pairs_device (the last step of the multi-GPU arg-min) against dist.global_argmin's torch path on
     the same gathered pairs: ties -> lowest index, -1 and +inf for groups nobody solved, NaN never wins, indices beyond

@@ -74,6 +74,9 @@ def test_compaction_changes_no_result(solver, make):
         skipped = stc == 0
         assert skipped.sum() > batch.B // 16 and (sta[skipped] != 0).all(), label
         assert (c["status"][skipped.any(axis=1)] < 0).all(), label
+        # ... and their control points are NaN, written by the pre-pass (no solve kernel ever sees them: ADVICE r5) -- a
+        # warm start refuses such an x0 instead of starting from whatever the buffer held
+        assert np.isnan(c["ctrl"][skipped.any(axis=1)]).all(), label
 
 
 def test_compaction_on_ragged_batches(solver):

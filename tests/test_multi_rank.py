@@ -197,6 +197,37 @@ def test_bench_refuses_more_ranks_than_devices():
     assert p.returncode == 3 and "HIP device" in p.stderr and p.stdout.strip() == ""
 
 
+def test_launcher_starts_the_one_process_host_when_the_ranks_end_without_a_line():
+    """`bench.py --gpus N` has a second way to produce its line.  When the torch.distributed ranks end
+    non-zero before a line was printed (here: no HIP device, so every rank refuses at once; on a GPU box: RCCL's bootstrap
+    or IPC handles -- tests/test_gpu_bench_ranks.py), the LAUNCHER -- which never touches the GPU -- starts
+    `--host one-process` (the C-ABI's btrapz_multi_* step) as a fresh child and returns ITS exit code.  On this CPU box
+    that child refuses too (there is no CPU path), loudly."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present: the GPU suite runs the fallback to a real line")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--steps", "1",
+                        "--warmup", "0", "--batch", "600", "--no-cpu-baseline", "--latency-reps", "0", "--no-secondary"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    err = p.stderr
+    first = err.index("the 2 ranks ended with exit code")
+    assert "running the step with --host one-process" in err[first:]
+    assert err.count("bench.py needs a HIP device: the hot path has no CPU fallback") == 3     # two ranks, then the one process
+    assert err.rindex("needs a HIP device") > first                                            # ... the last one AFTER the hand-over
+
+
+def test_one_process_argv_drops_what_belongs_to_the_ranks(monkeypatch):
+    import sys
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--backend", "nccl", "--steps=7", "--master-port", "29511", "--host", "ranks",
+                                      "--scaling", "strong", "--backend=gloo", "--share-device"])
+    assert bench.one_process_argv() == ["--gpus", "4", "--steps=7", "--scaling", "strong", "--share-device"]
+
+
 def _launch(env_extra, timeout):
     import subprocess, sys, time
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}

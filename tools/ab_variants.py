@@ -17,7 +17,8 @@ def worker():
     for ci in [int(x) for x in os.environ.get("AB_CASES", "0,1").split(",")]:
         label, make = cases[ci]
         batch, sh = make(); db = solver.upload(batch)
-        for name, kw in (("one", dict(lean=1, cap_iter=-1)), ("two", dict(lean=1, cap_iter=int(os.environ.get("AB_CAP", "6"))))):
+        eps = float(os.environ.get("AB_EPS", "0"))
+        for name, kw in (("one", dict(lean=1, cap_iter=-1, eps=eps)), ("two", dict(lean=1, cap_iter=int(os.environ.get("AB_CAP", "6")), eps=eps))):
             for _ in range(3): o = solver.solve(db, sh, split=-1, **kw)
             torch.cuda.synchronize(dev)
             best = 1e9
@@ -42,6 +43,8 @@ if __name__ == "__main__":
     for arg in sys.argv[1:]:
         name, path = arg.split("=", 1)
         env = dict(os.environ, AB_WORKER="1")
+        if "@" in path:   # name=path@eps: the same library at another tolerance
+            path, env["AB_EPS"] = path.split("@", 1)
         if os.environ.get("AB_COMPARE"):
             d = os.path.join("/tmp", "ab_" + name); os.makedirs(d, exist_ok=True); env["AB_SAVE"] = d
         if path != "default": env["BTRAPZ_HIP_LIB"] = os.path.join(ROOT, path)
