@@ -203,14 +203,16 @@ def main(argv=None):
         prev = dict(db=db, ctrl=out["ctrl"], lam=out.get("lam"), j0=j0, iters=out["iters"])
     wall = time.perf_counter() - wall0
     lat = np.array(lat)
-    steady = lat[1:] if len(lat) > 1 else lat
+    # steps 0 and 1 are the first uses of the cold and of the warm-start kernels (code objects load on first launch: 310 ms
+    # and 65-80 ms, profiles/r06_mpc_trace.txt): a replanning loop pays them once, the steady state starts at step 2
+    steady = lat[2:] if len(lat) > 3 else (lat[1:] if len(lat) > 1 else lat)
     result = {
         "workload": "BASELINE.json config 5: %d agents x %d candidates, %d segments, replanned every %.0f ms, %d steps, %s"
                     % (G_all, C, S, 1e3 * a.dt, a.steps, "cold start every step" if a.cold else "warm start"),
         "mode": "cold" if a.cold else "warm", "min_first_segment_s": a.min_first,
         "achieved_hz": 1e3 / float(steady.mean()), "target_hz": 1.0 / a.dt,
         "p50_step_ms": float(np.percentile(steady, 50)), "p99_step_ms": float(np.percentile(steady, 99)),
-        "first_step_ms": float(lat[0]), "wall_s_incl_checks": wall,
+        "first_step_ms": float(lat[0]), "second_step_ms": float(lat[1]) if len(lat) > 1 else None, "wall_s_incl_checks": wall,
         "mean_ipm_iterations": float(np.mean(iters_mean[1:] if len(iters_mean) > 1 else iters_mean)),
         "mean_ipm_iterations_first_step": iters_mean[0],
         "solved_fraction_mean": float(np.mean(solved)), "solved_fraction_min": float(np.min(solved)),
