@@ -299,7 +299,8 @@ int btrapz_rescue_violations_device(btrapz_ctx *ctx, int B, double *viol, void *
 /* Which form of the solve kernel the context's last batched solve ran (scheduling only; results do not depend on it):
  * 0 packed (floor(64/S) candidates per wavefront), 1 split (btrapz_options.split), 2 long (65..256 segments),
  * 3 capped first launch + resume launch (btrapz_options.cap_iter), 4 candidate queue (experiment builds); -1 none yet.
- * + 8 when the launch(es) ran the two-wavefronts-per-SIMD form (btrapz_options.lean). */
+ * + 8 when the launch(es) ran the two-wavefronts-per-SIMD form (btrapz_options.lean); + 16 when the long form solved the
+ * candidates of more than 64 segments of a ragged batch beside it. */
 int btrapz_last_solve_form(const btrapz_ctx *ctx);
 
 /* Arg-min of cost over contiguous groups of `group` candidates (B % group == 0).
@@ -398,10 +399,12 @@ int btrapz_sample_device(btrapz_ctx *ctx, int B, int S, double delta, const doub
 
 /* ---- ragged batches and the device corridor stage -------------------------
  * Candidates may have different segment counts: seg[f][b][k] and ctrl[b][12*seg_stride] have
- * seg_stride slots per candidate, seg_count[b] in 1..min(64, seg_stride) of them are used (control
- * points of candidate b: s axis at ctrl[b][0 .. 6 S_b), l axis at ctrl[b][6 S_b .. 12 S_b)).  Candidates
- * are bucketed by segment count on the device and every bucket is solved by the same kernel in one
- * launch; candidates with an unusable count get status BTRAPZ_NO_CORRIDOR and cost +inf. */
+ * seg_stride slots per candidate, seg_count[b] in 1..min(BTRAPZ_MAX_SEGMENTS_LONG, seg_stride) of them are used
+ * (control points of candidate b: s axis at ctrl[b][0 .. 6 S_b), l axis at ctrl[b][6 S_b .. 12 S_b)).  Candidates
+ * of at most 64 segments are bucketed by segment count on the device and every bucket is solved by the same kernel
+ * in one launch; candidates of 65..256 segments (cold solves without a rescue pass; since round 6) are solved by the
+ * long form, one launch per count -- their counts come to the host for that, one stream synchronisation;
+ * candidates with an unusable count get status BTRAPZ_NO_CORRIDOR and cost +inf. */
 int btrapz_solve_ragged_device(btrapz_ctx *ctx, const btrapz_shared *shared,
                                const btrapz_options *opt, int B, int seg_stride,
                                const double *seg, const int *seg_count, const double *init,
@@ -413,7 +416,10 @@ int btrapz_solve_ragged_device(btrapz_ctx *ctx, const btrapz_shared *shared,
  *   s_bounds, l_bounds [B][num_obs][N][2]  per-knot (lower, upper), the order of the input file
  *   ds_bounds, dl_bounds_knots [B][N][2]   s_ref, l_ref [B][N]
  * outputs: seg [NUM_SEG_FIELDS][B][seg_stride], seg_count [B] (0: nothing selected, -1: overflow or a
- * segment with t <= 0), ref_end [B][2], dl_bounds [B][10].  N <= 512, num_obs <= 64. */
+ * segment with t <= 0), ref_end [B][2], dl_bounds [B][10].  Up to 512 knots and 64 obstacles: the wave-wide kernels
+ * (one wavefront per candidate, at most 64 selected segments); beyond (N <= 100 000, num_obs <= 1 000, seg_stride <=
+ * BTRAPZ_MAX_SEGMENTS_LONG: the bounds of find_traj's parser and of the solve): one LANE per candidate on lists in a
+ * workspace of the context -- the same statements, the same record, two orders of magnitude slower per candidate. */
 int btrapz_corridor_batch_device(btrapz_ctx *ctx, int variant, int B, int N, int num_obs,
                                  double delta, const double *s_bounds, const double *l_bounds,
                                  const double *ds_bounds, const double *dl_bounds_knots,

@@ -113,6 +113,8 @@ __global__ void prism_corridor_batch_kernel(const CorridorArgs a, int staged);  
 __global__ void prism_corridor_batch_short_kernel(const CorridorArgs a, int staged);
 __global__ void prism_corridor_first_kernel(const CorridorArgs a, int staged);
 __global__ void prism_corridor_first_short_kernel(const CorridorArgs a, int staged);
+struct Seg;
+__global__ void corridor_serial_kernel(const CorridorArgs a, Seg *ws_all, Seg *ws_sel);   // beyond the wave-wide kernels' limits: one lane per candidate
 // fixed_S = 0: bucket by segment count (ragged batches); > 0: uniform batch of fixed_S segments, bucket by hint class
 // candidates that cannot start: keys[b] = 0 and their records written here (btrapz_options.compact; btrapz_kernels.hip)
 __global__ void prestart_kernel(const KernelArgs a, int S_uniform, const int *seg_count, int *keys);

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include <cstddef>
 #include <type_traits>
@@ -123,6 +124,8 @@ struct btrapz_ctx {
   int *d_meta = nullptr;            // [198] histogram/cand_prefix, wave_prefix, cursors
   int *d_retry = nullptr; size_t retry_cap = 0;   // corridor stage: [0] count, [1..] candidates of the retry pass
   void *d_strips = nullptr; size_t strip_cap = 0; // btrapz_prism_corridor_batch_device's two-launch path: the strips
+  void *d_corr_ws = nullptr; size_t corr_ws_cap = 0;   // corridor_serial_kernel's segment lists (horizons beyond the wave-wide kernels)
+  int *d_long_list = nullptr; size_t long_list_cap = 0;   // ragged batches: the candidates of more than 64 segments, by count
   // rescue pass (btrapz_options.elastic): keys [2][B], per-axis candidate lists [2][B], bucket tables [2][198]
   // The workspaces above serve one launch sequence at a time.  Launches of one context issued on DIFFERENT streams are
   // ordered behind each other with this event (recorded after every sequence, waited for when the stream changes).
@@ -195,7 +198,7 @@ BTRAPZ_EXPORT int btrapz_destroy(btrapz_ctx *c) {
   (void)hipFree(c->d_axis_obj); (void)hipFree(c->d_axis_status); (void)hipFree(c->d_axis_iters); (void)hipFree(c->d_axis_viol);
   (void)hipFree(c->d_mqm); (void)hipFree(c->d_stage); (void)hipFree(c->d_istage); (void)hipFree(c->d_single);
   (void)hipFree(c->d_queue); (void)hipFree(c->d_single_warm); (void)hipFree(c->d_susp_state); (void)hipFree(c->d_susp_ints);
-  (void)hipFree(c->d_order); (void)hipFree(c->d_meta); (void)hipFree(c->d_retry); (void)hipFree(c->d_strips);
+  (void)hipFree(c->d_order); (void)hipFree(c->d_meta); (void)hipFree(c->d_retry); (void)hipFree(c->d_strips); (void)hipFree(c->d_corr_ws); (void)hipFree(c->d_long_list);
   (void)hipFree(c->d_rescue); (void)hipFree(c->d_rescue_meta); (void)hipFree(c->d_argmin_cost); (void)hipFree(c->d_argmin_idx);
   if (c->ws_free) (void)hipEventDestroy(c->ws_free);
   delete c;
@@ -700,6 +703,45 @@ static int solve_common(btrapz_ctx *c, const btrapz_shared *sh, const btrapz_opt
     hipLaunchKernelGGL(ipm_solve_elastic_kernel, dim3(eblocks), dim3(64), 0, stream, e, (const double *)c->d_mqm);
     HIPCHK(c, hipGetLastError());
   }
+  // Ragged batch with slots for more than 64 segments: the candidates that HAVE more than 64 (the bucket kernels have
+  // marked them "no usable corridor") are solved by the long form, one launch per segment count with the candidates of
+  // that count listed.  The counts come to the host for this (one synchronisation: horizons beyond 64 s are not the
+  // throughput path); cold solves without a rescue pass -- what the long form serves.  The reference has no limit on the
+  // segment count (std::vector, src/solve_3d.cc:323-486,729-772).
+  if (seg_count && S > BTRAPZ_MAX_SEGMENTS && !warm_kernel && elastic == 0) {
+    std::vector<int> counts((size_t)B);
+    HIPCHK(c, hipMemcpyAsync(counts.data(), seg_count, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, stream));
+    HIPCHK(c, hipStreamSynchronize(stream));
+    const int smax = S < BTRAPZ_MAX_SEGMENTS_LONG ? S : BTRAPZ_MAX_SEGMENTS_LONG;
+    std::vector<std::vector<int>> by_count((size_t)smax + 1);
+    size_t n_long = 0;
+    for (int b = 0; b < B; b++)
+      if (counts[b] > BTRAPZ_MAX_SEGMENTS && counts[b] <= smax) { by_count[(size_t)counts[b]].push_back(b); ++n_long; }
+    if (n_long) {
+      if (n_long > c->long_list_cap) {
+        (void)hipFree(c->d_long_list); c->d_long_list = nullptr; c->long_list_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_long_list, sizeof(int) * n_long));
+        c->long_list_cap = n_long;
+      }
+      std::vector<int> flat;
+      flat.reserve(n_long);
+      for (const auto &l : by_count) flat.insert(flat.end(), l.begin(), l.end());
+      HIPCHK(c, hipMemcpyAsync(c->d_long_list, flat.data(), sizeof(int) * n_long, hipMemcpyHostToDevice, stream));
+      HIPCHK(c, hipStreamSynchronize(stream));   // (flat goes out of scope)
+      size_t off = 0;
+      for (int s = BTRAPZ_MAX_SEGMENTS + 1; s <= smax; s++) {
+        const size_t n = by_count[(size_t)s].size();
+        if (!n) continue;
+        KernelArgs l = a;
+        l.S = s; l.order = c->d_long_list + off; l.bucket_S = (int)n; l.seg_count = nullptr; l.cand_prefix = nullptr; l.wave_prefix = nullptr;
+        l.x0 = nullptr; l.lam0 = nullptr; l.lam_out = nullptr; l.x_out = nullptr;
+        hipLaunchKernelGGL(ipm_solve_long_kernel, dim3(2u * (unsigned)n), dim3(64u * (unsigned)((s + 63) / 64)), 0, stream, l, (const double *)c->d_mqm);
+        HIPCHK(c, hipGetLastError());
+        off += n;
+      }
+      c->last_form |= 16;   // (+ 16: the long form served part of a ragged batch)
+    }
+  }
   hipLaunchKernelGGL(finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, B, c->d_axis_obj, c->d_axis_status,
                      c->d_axis_iters, cost, status, iters);
   HIPCHK(c, hipGetLastError());
@@ -760,8 +802,49 @@ BTRAPZ_EXPORT int btrapz_eval_states_device(btrapz_ctx *c, int B, int seg_stride
 
 // The launches of the corridor stage: `a` holds the shapes and every pointer but the retry list.  prisms: the fused
 // prism + corridor kernels (the strips are evaluated from a.prisms instead of read from a.s_bounds / a.l_bounds).
+// Beyond the wave-wide kernels' shapes (more than 512 knots or 64 obstacles): one lane per candidate on
+// lists in a workspace (corridor_serial_kernel).  Capacities: what the host driver of find_traj allows itself (2 N + 16
+// segments per obstacle) while the workspace stays below BTRAPZ_CORRIDOR_WS_MAX, else what a horizon of N knots needs when
+// its bounds break at most 64 times per obstacle; as many selected segments (before the de-dup) as there are segments, under
+// the same budget.
+#ifndef BTRAPZ_CORRIDOR_WS_MAX
+#define BTRAPZ_CORRIDOR_WS_MAX ((size_t)2 << 30)
+#endif
+static int launch_corridor_serial(btrapz_ctx *c, CorridorArgs a, hipStream_t stream) {
+  const size_t seg_bytes = 104;   // sizeof(Seg): corridor_kernels.hip asserts it
+  const size_t B = (size_t)a.B, O = (size_t)a.num_obs;
+  size_t cap_o = 2 * (size_t)a.N + 16;
+  const size_t cap_min = (size_t)(a.N - 1) / 10 + 1 + 64;
+  if (B * O * cap_o * seg_bytes > BTRAPZ_CORRIDOR_WS_MAX) {
+    cap_o = BTRAPZ_CORRIDOR_WS_MAX / (B * O * seg_bytes);
+    if (cap_o < cap_min) cap_o = cap_min;
+  }
+  // selected segments before the de-dup: every segment of every obstacle can be one (its copies: only for NaN segments)
+  size_t cap_sel = O * cap_o;
+  if (B * cap_sel * seg_bytes > BTRAPZ_CORRIDOR_WS_MAX) {
+    cap_sel = BTRAPZ_CORRIDOR_WS_MAX / (B * seg_bytes);
+    if (cap_sel < 2 * (size_t)a.seg_stride + 16) cap_sel = 2 * (size_t)a.seg_stride + 16;
+  }
+  const size_t need = (B * O * cap_o + B * cap_sel) * seg_bytes;
+  if (need > c->corr_ws_cap) {
+    (void)hipFree(c->d_corr_ws); c->d_corr_ws = nullptr; c->corr_ws_cap = 0;
+    if (hipMalloc(&c->d_corr_ws, need) != hipSuccess) { (void)hipGetLastError(); c->err = "corridor stage: no memory for the segment lists of this horizon"; return BTRAPZ_ENOMEM; }
+    c->corr_ws_cap = need;
+  }
+  if (c->ws_used && stream != c->ws_stream) HIPCHK(c, hipStreamWaitEvent(stream, c->ws_free, 0));
+  a.cap_o = (int)cap_o; a.cap_sel = (int)cap_sel; a.pass = 0; a.retry_list = nullptr; a.retry_count = nullptr;
+  Seg *all = reinterpret_cast<Seg *>(c->d_corr_ws);
+  Seg *sel = reinterpret_cast<Seg *>(reinterpret_cast<char *>(c->d_corr_ws) + B * O * cap_o * seg_bytes);
+  hipLaunchKernelGGL(corridor_serial_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, a, all, sel);
+  HIPCHK(c, hipGetLastError());
+  c->ws_stream = stream; c->ws_used = true;
+  HIPCHK(c, hipEventRecord(c->ws_free, stream));
+  return BTRAPZ_OK;
+}
+
 static int launch_corridor_stage(btrapz_ctx *c, CorridorArgs a, bool prisms, hipStream_t stream) {
   const int B = a.B, N = a.N, num_obs = a.num_obs, seg_stride = a.seg_stride;
+  if (!prisms && (N > 512 || num_obs > 64)) return launch_corridor_serial(c, a, stream);
   // Two passes (corridor_kernels.hip): lists sized for the usual case first -- LDS per workgroup is what limits the
   // wavefronts per CU -- then the candidates that overflowed them, with the full capacities.
   if ((size_t)B + 1 > c->retry_cap) {
@@ -822,8 +905,10 @@ BTRAPZ_EXPORT int btrapz_corridor_batch_device(btrapz_ctx *c, int variant, int B
                                             int seg_stride, double *seg, int *seg_count, double *ref_end,
                                             double *dl_bounds, void *stream_) {
   if (!c) return BTRAPZ_EINVAL;
-  if (variant < 0 || variant > 1 || B < 1 || N < 3 || N > 512 || num_obs < 1 || num_obs > 64 || !(delta > 0) ||
-      seg_stride < 1 || !s_bounds || !l_bounds || !ds_bounds || !dl_bounds_knots || !s_ref || !l_ref || !seg ||
+  // (N, num_obs: the reference has no limit -- std::vector --; the bounds here are those of find_traj's parser, corridor.cpp.
+  //  More than 512 knots or 64 obstacles: the one-lane-per-candidate kernel instead of the wave-wide ones)
+  if (variant < 0 || variant > 1 || B < 1 || N < 3 || N > 100000 || num_obs < 1 || num_obs > 1000 || !(delta > 0) ||
+      seg_stride < 1 || seg_stride > BTRAPZ_MAX_SEGMENTS_LONG || !s_bounds || !l_bounds || !ds_bounds || !dl_bounds_knots || !s_ref || !l_ref || !seg ||
       !seg_count || !ref_end || !dl_bounds) {
     c->err = "invalid argument";
     return BTRAPZ_EINVAL;

@@ -89,7 +89,7 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
                                                const int wave_id, const int lane, double *wgs = nullptr, const int wv = 0) {
   static_assert(!QUEUE || (!WARM && !ORDERED && !ELASTIC), "the queue serves uniform cold batches");
   static_assert(!SPLIT || (!ORDERED && !ELASTIC && !QUEUE), "the split form serves uniform batches");
-  static_assert(!MULTI || (!WARM && !ORDERED && !QUEUE && !SPLIT), "the long form serves uniform cold batches (and their rescue pass)");
+  static_assert(!MULTI || (!WARM && !ORDERED && !QUEUE && !SPLIT), "the long form serves uniform cold batches (and their rescue pass) -- and, launched once per segment count with a candidate list in a.order of a.bucket_S entries, the long candidates of a ragged batch");
   static_assert(!(CAPPED || RESUME) || (!WARM && !ELASTIC && !QUEUE && !SPLIT && !MULTI && !(CAPPED && RESUME)), "capped / resume: packed cold form");
   static_assert(!RESUME || ORDERED, "the resume pass reads its problems from per-axis lists");
   constexpr bool PERAXIS = ELASTIC || RESUME;   // one candidate list and one set of bucket tables per axis
@@ -651,10 +651,14 @@ __device__ __forceinline__ void ipm_solve_body(const KernelArgs &a, const double
     if (first && lane_in_group) next_cand = atomicAdd(a.queue + axis, 1);
   } else {
     long long cand = (SPLIT || MULTI) ? (long long)pair : (long long)pair * gpw + gl;
+    // (long form with a list: the candidates of a ragged batch that have a.S > 64 segments -- one launch per count,
+    //  btrapz_host.hip; the list's length travels in a.bucket_S, which this form has no other use for)
+    const bool listed = MULTI && a.order != nullptr;
+    if (listed) ncand = a.bucket_S;
     const bool valid0 = lane_in_group && cand < ncand;
     cand_live = cand < ncand ? 1 : 0;
     if (cand >= ncand) cand = ncand - 1;
-    const int b0 = ORDERED ? a.order[cand0 + (int)cand] : (int)cand;
+    const int b0 = ORDERED ? a.order[cand0 + (int)cand] : listed ? a.order[(int)cand] : (int)cand;
     begin_candidate(b0, valid0, load_record(b0));
   }
 

@@ -570,6 +570,78 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   }
 }
 
+// ---- the corridor stage without the wave-wide kernel's limits (round 6) ---------------------------------------------------
+// corridor_serial_kernel: ONE LANE per candidate runs the serial statements of corridor_core.h -- what the host driver of
+// find_traj runs (corridor.cpp: extract_segments, select_segments, order_segments_core) -- on segment lists in a workspace
+// in global memory.  The reference has no limit on knots, obstacles or segments (std::vector throughout,
+// src/solve_3d.cc:323-486,488-714,729-772); the wave-wide kernels above hold their lists in LDS and one selected segment
+// per lane: N <= 512 knots, <= 64 obstacles, <= 64 selected segments.  Beyond any of those the stage takes this kernel:
+// same statements, same arithmetic, same record -- slow (a lane walks every knot of every segment; the loads of
+// neighbouring lanes are a candidate apart) and without limits but the workspace the host sizes (cap_o segments per
+// obstacle, cap_sel selected ones: a candidate that needs more gets seg_count = -1, as in the first pass above).
+static_assert(sizeof(Seg) == 104, "btrapz_host.hip sizes the serial kernel's workspace with this");
+__global__ __launch_bounds__(64) void corridor_serial_kernel(const CorridorArgs a, Seg *ws_all, Seg *ws_sel) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const int N = a.N, O = a.num_obs, cap_o = a.cap_o, cap_sel = a.cap_sel;
+  Seg *all = ws_all + (size_t)b * O * cap_o, *sel = ws_sel + (size_t)b * cap_sel;
+  const double *gs = a.s_bounds + (size_t)b * O * N * 2, *gl = a.l_bounds + (size_t)b * O * N * 2;
+  const double *sref = a.s_ref + (size_t)b * N, *lref = a.l_ref + (size_t)b * N;
+  const double *dsb = a.ds_bounds + (size_t)b * N * 2;
+  int S = 0, nsel = 0, carry = 0;
+  bool overflow = false;
+  for (int o = 0; o < O && !overflow; o++) {
+    const BoundsView sb{gs + (size_t)o * N * 2}, lb{gl + (size_t)o * N * 2};
+    Seg *list = all + (size_t)o * cap_o;
+    const int n = extract_segments_core(a.variant, N, a.delta, sb, lb, SlopesOnTheFly{sb, a.delta}, list, cap_o);
+    if (n < 0) { overflow = true; break; }
+    for (int j = 0; j < n && !overflow; j++) {   // CollisionCheck's selection, solve_3d.cc:534-596
+      const Seg c = list[j];
+      int hits = 0;
+      for (int i = 0; i < N; i++) hits += knot_inside(c, sref[i], lref[i], (double)i, a.delta) ? 1 : 0;
+      for (int copies = selection_copies(selection_pushes(hits, carry), c); copies > 0; copies--) {
+        if (nsel >= cap_sel) { overflow = true; break; }
+        Seg t = c; t.count = 3; sel[nsel++] = t;
+      }
+    }
+  }
+  if (overflow) S = -1;
+  else if (nsel > 0) S = order_segments_core(a.variant, a.delta, sel, nsel);
+  bool bad = S > a.seg_stride;
+  if (S > 0 && !bad) {
+    const size_t BS = (size_t)a.B * a.seg_stride;
+    double *sg = a.seg;
+    for (int k = 0; k < S; k++) {
+      const Seg c = sel[k];
+      if (!(c.t > 0.0)) bad = true;
+      const size_t e = (size_t)b * a.seg_stride + k;
+      sg[BTRAPZ_F_T * BS + e] = c.t;
+      sg[BTRAPZ_F_DOWN_BIAS * BS + e] = c.down_bias; sg[BTRAPZ_F_DOWN_SKEW * BS + e] = c.down_skew;
+      sg[BTRAPZ_F_UPP_BIAS * BS + e] = c.upp_bias; sg[BTRAPZ_F_UPP_SKEW * BS + e] = c.upp_skew;
+      sg[BTRAPZ_F_L_DOWN_BIAS * BS + e] = c.l_down_bias; sg[BTRAPZ_F_L_DOWN_SKEW * BS + e] = c.l_down_skew;
+      sg[BTRAPZ_F_L_UPP_BIAS * BS + e] = c.l_upp_bias; sg[BTRAPZ_F_L_UPP_SKEW * BS + e] = c.l_upp_skew;
+      sg[BTRAPZ_F_BEG_L * BS + e] = c.beg_l; sg[BTRAPZ_F_END_L * BS + e] = c.end_l;
+      double lo = 0.0, hi = 1000.0;  // solve_3d.cc:835-841
+      for (int i = c.beg_t; i <= c.end_t; i++) {
+        const int ii = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
+        lo = fmax(dsb[2 * ii], lo);
+        hi = fmin(dsb[2 * ii + 1], hi);
+      }
+      sg[BTRAPZ_F_DS_LO * BS + e] = lo; sg[BTRAPZ_F_DS_HI * BS + e] = hi;
+      const int i0 = 10 * k > N - 1 ? N - 1 : 10 * k, i1 = 10 * k + 1 > N - 1 ? N - 1 : 10 * k + 1;  // :1161-1165, clamped
+      sg[BTRAPZ_F_X_SKEW * BS + e] = (sref[i1] - sref[i0]) / a.delta; sg[BTRAPZ_F_X_BIAS * BS + e] = sref[i0];
+      sg[BTRAPZ_F_Y_SKEW * BS + e] = (lref[i1] - lref[i0]) / a.delta; sg[BTRAPZ_F_Y_BIAS * BS + e] = lref[i0];
+    }
+  }
+  if (bad) S = -1;
+  a.seg_count[b] = S;
+  a.ref_end[(size_t)b * 2] = sref[N - 1]; a.ref_end[(size_t)b * 2 + 1] = lref[N - 1];
+  for (int j = 0; j < 10; j++) {
+    const int i = j >> 1, ii = i > N - 1 ? N - 1 : i;
+    a.dl10[(size_t)b * 10 + j] = a.dl_bounds[((size_t)b * N + ii) * 2 + (j & 1)];
+  }
+}
+
 // ---- bucketing by segment count ------------------------------------------------------------------
 // meta[0..65]: histogram, then cand_prefix ; meta[66..131]: wave_prefix ; meta[132..197]: cursors.
 // Counts are aggregated per workgroup in LDS first: with one global atomic per candidate a batch whose candidates

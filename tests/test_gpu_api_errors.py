@@ -41,8 +41,12 @@ def test_bad_arguments_are_reported_not_fatal():
     assert lib.btrapz_eval_states_device(h, 8, 10, None, p(db.seg), p(o["ctrl"]), 0, p(o["cost"]), p(o["cost"]), None) == EINVAL
     assert lib.btrapz_corridor_batch_device(h, 0, 8, 2, 1, C.c_double(0.1), *[p(o["cost"])] * 6, 16, p(o["cost"]), p(o["status"]),
                                             p(o["cost"]), p(o["cost"]), None) == EINVAL                     # N < 3
-    assert lib.btrapz_corridor_batch_device(h, 0, 8, 71, 65, C.c_double(0.1), *[p(o["cost"])] * 6, 16, p(o["cost"]),
-                                            p(o["status"]), p(o["cost"]), p(o["cost"]), None) == EINVAL     # num_obs > 64
+    assert lib.btrapz_corridor_batch_device(h, 0, 8, 71, 1001, C.c_double(0.1), *[p(o["cost"])] * 6, 16, p(o["cost"]),
+                                            p(o["status"]), p(o["cost"]), p(o["cost"]), None) == EINVAL     # num_obs > 1000 (the parser's bound; 65..1000: the serial kernel)
+    assert lib.btrapz_corridor_batch_device(h, 0, 8, 100001, 2, C.c_double(0.1), *[p(o["cost"])] * 6, 16, p(o["cost"]),
+                                            p(o["status"]), p(o["cost"]), p(o["cost"]), None) == EINVAL     # N > 100 000
+    assert lib.btrapz_corridor_batch_device(h, 0, 8, 71, 2, C.c_double(0.1), *[p(o["cost"])] * 6, 257, p(o["cost"]),
+                                            p(o["status"]), p(o["cost"]), p(o["cost"]), None) == EINVAL     # more slots than a solve takes
     # the fused prism + corridor entry point: the limits of the two calls it replaces
     road = native.CRoad.reference()
     pc = lambda P, N, O: lib.btrapz_prism_corridor_batch_device(h, 0, 8, P, N, C.byref(road), p(o["cost"]), O, C.c_double(0.1), *[p(o["cost"])] * 4,
