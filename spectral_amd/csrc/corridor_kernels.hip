@@ -407,9 +407,13 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     // that fails those conditions, or a reference that is not finite, takes all.
     // The reference's running hit counter (selection_pushes): its value when it reaches a segment is the number of
     // hits before it, mod 3 -- a scan over the lanes instead of a walk over the segments.
+    // (round 6) Up to 32 segments in all -- the usual case: 3 obstacles x 8 pieces -- TWO lanes per segment, lane l and lane
+    // l + 32 each walking half of its knots: the walk is the phase's cost (11 knots of a one-second piece, four edge
+    // functions each, for 24-30 busy lanes of 64), the counts are integers -- added through one cross-lane fetch.
     int carry = 0;
-    for (int q0 = 0; q0 < total; q0 += 64) {
-      const int q = q0 + lane;
+    const bool halves = total <= 32;                        // wave-uniform
+    for (int q0 = 0; q0 < total; q0 += halves ? 32 : 64) {
+      const int q = halves ? (lane & 31) : q0 + lane;
       int h = 0;
       bool equals_itself = true;  // false with a NaN among the fields same_segment compares
       if (q < total) {
@@ -417,13 +421,22 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
         equals_itself = same_segment(c, c);
         const double gap0 = c.upp_bias - c.down_bias, gap1 = c.down_skew * a.delta + c.down_bias - c.upp_skew * a.delta - c.upp_bias;
         const bool own_range = refs_finite && gap0 > 0.0 && gap0 < 1e300 && gap1 < 0.0 && gap1 > -1e300 && c.beg_t <= c.end_t;
-        const int i_lo = own_range ? (c.beg_t > 0 ? c.beg_t : 0) : 0;
-        const int i_hi = own_range ? (c.end_t < N - 1 ? c.end_t : N - 1) : N - 1;
+        int i_lo = own_range ? (c.beg_t > 0 ? c.beg_t : 0) : 0;
+        int i_hi = own_range ? (c.end_t < N - 1 ? c.end_t : N - 1) : N - 1;
+        if (halves) {
+          const int mid_i = i_lo + ((i_hi - i_lo + 1) >> 1);   // [i_lo, mid_i) for lane l, [mid_i, i_hi] for lane l + 32
+          if (lane < 32) i_hi = mid_i - 1; else i_lo = mid_i;
+        }
         for (int i = i_lo; i <= i_hi; i++) h += knot_inside(c, sref[i], lref[i], (double)i, a.delta) ? 1 : 0;
       }
+      if (halves) {
+        h += __shfl_xor(h, 32);
+        if (lane >= 32) { h = 0; }
+      }
+      const bool owner = !halves || lane < 32;              // the lane that speaks for segment q below
       const int upto = wave_inclusive_scan(h, lane);
       int counter = (carry + upto - h) % 3;
-      const int copies = q < total ? selection_copies(selection_pushes(h, counter), equals_itself) : 0;   // 1, but for NaN segments
+      const int copies = (q < total && owner) ? selection_copies(selection_pushes(h, counter), equals_itself) : 0;   // 1, but for NaN segments
       const int placed = wave_inclusive_scan(copies, lane);
       for (int j = 0, r = nsel + placed - copies; j < copies && r < cap_sel; j++, r++) pick[r] = slot_of[q];
       nsel += __builtin_amdgcn_readlane(placed, 63);
