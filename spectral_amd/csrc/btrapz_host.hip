@@ -862,6 +862,9 @@ static int launch_corridor_stage(btrapz_ctx *c, CorridorArgs a, bool prisms, hip
 #ifndef CABL_CAPO_EXTRA
 #define CABL_CAPO_EXTRA (N <= 128 ? 3 : 5)
 #endif
+  // (round 6, LDS once more: ocount[] cut to the obstacle count and 1.5 x seg_stride selected segments -- 7.4 -> 6.9 KB per
+  //  wavefront -- N = 71 x 3 obstacles 0.240 -> 0.246 ms, N = 201 x 2 0.569 -> 0.542; with +2 instead of +3 slots per obstacle
+  //  the retry pass takes over (0.84 ms at N = 201): LDS is not what holds this kernel any more)
   int cap_o_small = (N - 1) / 10 + CABL_CAPO_EXTRA, cap_sel_small = 2 * seg_stride < 16 ? 16 : 2 * seg_stride;
   if (cap_o_small > cap_o_big) cap_o_small = cap_o_big;
   if (cap_sel_small > cap_sel_big) cap_sel_small = cap_sel_big;

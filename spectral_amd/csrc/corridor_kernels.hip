@@ -25,6 +25,7 @@
 
 namespace btrapz {
 
+#define UNIFORM_BLOCK_C asm volatile("")
 enum { MAX_ALL = 160, MAX_SEL = 64 };   // capacities of the retry pass (see btrapz_corridor_batch_device)
 
 // LDS is what limits the wavefronts per CU here, and the serial phases of this kernel live on latency, so the
@@ -427,6 +428,17 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
           const int mid_i = i_lo + ((i_hi - i_lo + 1) >> 1);   // [i_lo, mid_i) for lane l, [mid_i, i_hi] for lane l + 32
           if (lane < 32) i_hi = mid_i - 1; else i_lo = mid_i;
         }
+        // six knots at most per lane (half of a one-second piece's eleven): a fixed-length, predicated walk whose twelve LDS
+        // reads are issued together instead of one dependent pair per step (bit-identical; 0.243 -> 0.239 ms)
+        if (__all(i_hi - i_lo < 6 || q >= total)) {
+          UNIFORM_BLOCK_C;
+#pragma unroll
+          for (int u = 0; u < 6; u++) {
+            const int i = i_lo + u, ic = i < N ? i : N - 1;
+            const bool in = knot_inside(c, sref[ic], lref[ic], (double)ic, a.delta);
+            h += (i <= i_hi && in) ? 1 : 0;
+          }
+        } else
         for (int i = i_lo; i <= i_hi; i++) h += knot_inside(c, sref[i], lref[i], (double)i, a.delta) ? 1 : 0;
       }
       if (halves) {
@@ -520,8 +532,14 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
       }
 #ifndef CABL_NOOVERLAP
       // overlap_segments_core, trapezoid: every step sees the spans the previous one left -- a serial walk over the
-      // neighbours, on the keys in the lanes; a span the walk assigned gets its duration recomputed, as there
+      // neighbours, on the keys in the lanes; a span the walk assigned gets its duration recomputed, as there.
+      // (round 6) The walk changes nothing unless SOME neighbouring pair meets one of its two conditions on the spans as
+      // they are now -- a step that assigns nothing leaves the next one what it would have seen anyway -- so one ballot over
+      // the pairs decides whether it runs at all (the usual corridor has no such pair).
       bool assigned = false;
+      const int nbt = __builtin_amdgcn_update_dpp(0, bt, 0x130, 0xf, 0xf, false), net = __builtin_amdgcn_update_dpp(0, et, 0x130, 0xf, 0xf, false);   // wave_shl:1: lane l + 1's
+      const bool pair_overlaps = lane + 1 < n && ((bt == nbt && et == net) || (bt > nbt && et <= net));
+      if (__ballot(pair_overlaps) != 0)
       for (int i = 0; i + 1 < n; i++) {
         const int a_bt = __builtin_amdgcn_readlane(bt, i), b_et = __builtin_amdgcn_readlane(et, i + 1);
         int a_et = __builtin_amdgcn_readlane(et, i), b_bt = __builtin_amdgcn_readlane(bt, i + 1);
