@@ -171,6 +171,24 @@ BTRAPZ_HD bool knot_inside(const Seg &c, double s, double l, double knot, double
   return !(pos && neg);
 }
 
+// knot_inside for a knot of the segment's OWN span, beg_t <= knot <= end_t, of a segment with finite fields and
+//   gap0 = upp_bias - down_bias in (0, 1e300),  gap1 = down_skew delta + down_bias - upp_skew delta - upp_bias in (-1e300, 0)
+// and a finite reference -- what the device's selection establishes before it restricts a segment's walk to its own knots
+// (corridor_kernels.hip).  There the first products of d0 and d2 are (finite) * (t - t) = +-0 exactly, and their second
+// ones are (knot - beg_t) * gap0 >= 0 and (knot - end_t) * gap1 >= 0, zero only at the span's ends and never rounded to
+// zero elsewhere (an integer of magnitude >= 1 times a non-zero double): d0 and d2 are never positive, d0 < 0 iff
+// knot > beg_t, d2 < 0 iff knot < end_t.  Same decision as knot_inside, bit for bit, without the two edge functions.
+BTRAPZ_HD bool knot_inside_own_span(const Seg &c, double s, double l, int knot_i, double delta) {
+  if (!(l <= c.end_l && l >= c.beg_l)) return false;
+  const double knot = (double)knot_i;
+  const double d1 = (s - c.upp_bias) * (c.end_t - c.beg_t) - (knot - c.beg_t) * (c.upp_skew * delta + c.upp_bias - c.upp_bias);
+  const double d3 = (s - c.down_bias - c.down_skew * delta) * (c.beg_t - c.end_t) -
+                    (knot - c.end_t) * (c.down_bias - c.down_skew * delta - c.down_bias);
+  const bool pos = d1 > 0 || d3 > 0;
+  const bool neg = knot_i > c.beg_t || knot_i < c.end_t || d1 < 0 || d3 < 0;
+  return !(pos && neg);
+}
+
 // The reference takes a segment each time a running hit counter reaches 3; the counter is shared by all
 // segments of all obstacles and reset only when a segment is taken (solve_3d.cc:584-596).  Given the
 // number of reference knots inside a segment and the counter carried in, this returns how many copies the

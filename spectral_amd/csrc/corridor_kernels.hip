@@ -26,6 +26,11 @@
 namespace btrapz {
 
 #define UNIFORM_BLOCK_C asm volatile("")
+#ifdef CABL_MARKS
+#define CABL_MARK(x) asm volatile("; ==PHASE " x)
+#else
+#define CABL_MARK(x)
+#endif
 enum { MAX_ALL = 160, MAX_SEL = 64 };   // capacities of the retry pass (see btrapz_corridor_batch_device)
 
 // LDS is what limits the wavefronts per CU here, and the serial phases of this kernel live on latency, so the
@@ -167,8 +172,9 @@ __device__ __forceinline__ bool find_breaks_wave(const CorridorArgs &a, int lane
 // prefetched reference over it there: held in registers any longer, the allocator spills the prefetch to scratch)
 template <class Src, class F>
 __device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int lane, const Src &src,
-                                                    const double *slopes, Seg *all, int cap_o, int *ocount, const int *brk,
+                                                    const double *slopes, Seg *all, int cap_o, int *ocount, int *brk_w,
                                                     short *first, int my_nb, F &&after_slopes) {
+  const int *brk = brk_w;
   const int N = a.N, O = a.num_obs;
   const double2 *sk2 = reinterpret_cast<const double2 *>(slopes);
   const int nbp = my_nb > 0 ? my_nb : 0;
@@ -212,25 +218,47 @@ __device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int l
   __syncthreads();
   if (mo >= 0 && mk == mn - 1 && ocount[mo] == 0) ocount[mo] = pos + cnt > cap_o ? -1 : pos + cnt;
   __syncthreads();
-  if (mo >= 0 && ocount[mo] > 0) {
-    Seg *w = all + mo * cap_o + pos;
-    while (s.t > 1) {   // CorridorSplit, solve_3d.cc:735-746
-      s.t = s.t - 1;
-      Seg head = seg_default();
-      head.beg_t = s.beg_t; head.end_t = head.beg_t + 10; head.t = 1.0;
-      head.down_skew = s.down_skew; head.down_bias = s.down_bias;
-      head.upp_skew = s.upp_skew; head.upp_bias = s.upp_bias;
-      if (a.variant == 0) {
-        head.l_down_skew = s.l_down_skew; head.l_down_bias = s.l_down_bias;
-        head.l_upp_skew = s.l_upp_skew; head.l_upp_bias = s.l_upp_bias;
+  // CorridorSplit, solve_3d.cc:735-746 -- one lane per PIECE (round 6; until then the lane of a base segment wrote its pieces one
+  // after the other: seven times thirteen LDS stores and a default-initialised Seg each on ONE lane for an obstacle corridor
+  // without slope breaks, the other lanes waiting).  A base lane leaves its segment in the slot of its last piece and marks its
+  // slots (piece number, distance to that slot) in brk[] -- free now: every break has been read --; then lane l builds the piece
+  // of slot base + l from the base segment it finds there: the reference's recurrences step by step (the bias after j pieces is
+  // j additions of the slope, the rest's duration cnt - 1 subtractions of 1), so the pieces are the serial statement's bit for bit.
+  const int cap_all = cap_o * O;
+  const bool okb = mo >= 0 && ocount[mo] > 0;
+  const int slot0 = okb ? mo * cap_o + pos : 0;
+  for (int i = lane; i < cap_all; i += 64) brk_w[i] = -1;
+  __syncthreads();
+  if (okb) {
+    all[slot0 + cnt - 1] = s;
+    for (int j = 0; j < cnt; j++) brk_w[slot0 + j] = j | ((cnt - 1 - j) << 8);
+  }
+  __syncthreads();
+  for (int base = 0; base < cap_all; base += 64) {
+    const int slot = base + lane;
+    const int code = slot < cap_all ? brk_w[slot] : -1;
+    Seg piece = seg_default();
+    if (code >= 0) {
+      const int j = code & 255, rem = code >> 8;
+      const Seg b = all[slot + rem];
+      double db = b.down_bias, ub = b.upp_bias, t = b.t;
+      for (int u = 0; u < j; u++) { db = db + 1.0 * b.down_skew; ub = ub + 1.0 * b.upp_skew; t = t - 1; }
+      if (rem == 0) {          // what is left of the base segment behind its pieces
+        piece = b;
+        piece.beg_t = b.beg_t + 10 * j; piece.t = t; piece.down_bias = db; piece.upp_bias = ub;
+      } else {
+        piece.beg_t = b.beg_t + 10 * j; piece.end_t = piece.beg_t + 10; piece.t = 1.0;
+        piece.down_skew = b.down_skew; piece.down_bias = db;
+        piece.upp_skew = b.upp_skew; piece.upp_bias = ub;
+        if (a.variant == 0) {
+          piece.l_down_skew = b.l_down_skew; piece.l_down_bias = b.l_down_bias;
+          piece.l_upp_skew = b.l_upp_skew; piece.l_upp_bias = b.l_upp_bias;
+        }
+        piece.beg_l = b.beg_l; piece.end_l = b.end_l;
       }
-      head.beg_l = s.beg_l; head.end_l = s.end_l;
-      s.beg_t = s.beg_t + 10;
-      s.down_bias = head.down_bias + 1.0 * head.down_skew;
-      s.upp_bias = head.upp_bias + 1.0 * head.upp_skew;
-      *w++ = head;
     }
-    *w = s;
+    __syncthreads();            // every lane has read its base segment: the slots of the rests may be overwritten
+    if (code >= 0) all[slot] = piece;
   }
 }
 
@@ -312,6 +340,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
         sk2[i] = make_double2((cur_lo[u] - prv_lo[u]) / a.delta, (cur_hi[u] - prv_hi[u]) / a.delta);
     }
   };
+  CABL_MARK("SLOPES");
   if (staged) {
     load_pairs(0);
     store_slopes(0);
@@ -319,6 +348,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   }
   // reference and ds bounds of the first 256 knots: issued behind the break search, in the same memory round trip
   // as the bounds at the segment starts
+  CABL_MARK("REFS");
   const double *gsr = a.s_ref + (size_t)b * N, *glr = a.l_ref + (size_t)b * N;
   const double2 *gds = reinterpret_cast<const double2 *>(a.ds_bounds + (size_t)b * N * 2);
   double ref_s[RB], ref_l[RB], ref_dlo[RB], ref_dhi[RB];   // (scalars: an array of double2 behind a lambda stays in scratch)
@@ -350,6 +380,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   load_refs(0);
 #else
   // hits / slot_of are free until the selection: scratch of the wave-wide extraction
+  CABL_MARK("BREAKS");
   int my_nb = 0;
   const bool wide = staged && find_breaks_wave(a, lane, slopes, cap_o, hits, my_nb);
   load_refs(0);
@@ -380,6 +411,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     }
   }
 #endif
+  CABL_MARK("REFSTORE");
   __syncthreads();                                         // the slope table has been read for the last time
   if (!refs_stored) store_refs(0);
   for (int base = 64 * RB; base < N; base += 64 * RB) { load_refs(base); store_refs(base); }
@@ -387,6 +419,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   __syncthreads();
   // ---- selection along the reference (solve_3d.cc:534-596): knots inside every segment, the lanes spread over
   // (segment, knot) pairs; the reference's running hit counter then reduces to a carry over the segments in order
+  CABL_MARK("SELECT");
   int total = 0;
   bool overflow = false;
   for (int o = 0; o < O; o++) {
@@ -430,12 +463,14 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
         }
         // six knots at most per lane (half of a one-second piece's eleven): a fixed-length, predicated walk whose twelve LDS
         // reads are issued together instead of one dependent pair per step (bit-identical; 0.243 -> 0.239 ms)
-        if (__all(i_hi - i_lo < 6 || q >= total)) {
+        // (and, every segment of the wavefront walking its own span only, without the two edge functions whose signs the
+        //  span decides: knot_inside_own_span, corridor_core.h)
+        if (__all(own_range && i_hi - i_lo < 6)) {
           UNIFORM_BLOCK_C;
 #pragma unroll
           for (int u = 0; u < 6; u++) {
-            const int i = i_lo + u, ic = i < N ? i : N - 1;
-            const bool in = knot_inside(c, sref[ic], lref[ic], (double)ic, a.delta);
+            const int i = i_lo + u, ic = i <= i_hi ? i : i_lo <= i_hi ? i_hi : (i_lo < N ? i_lo : N - 1);   // (a knot of the span, or any valid one for an empty half)
+            const bool in = knot_inside_own_span(c, sref[ic], lref[ic], ic, a.delta);
             h += (i <= i_hi && in) ? 1 : 0;
           }
         } else
@@ -458,6 +493,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   }
   __syncthreads();
   if (overflow && a.pass == 0 && a.retry_list && lane == 0) a.retry_list[atomicAdd(a.retry_count, 1)] = b;  // second chance
+  CABL_MARK("DEDUP");
   // ---- de-dup (keep first), stable sort by beg_t: lane j holds selected segment j ----
   int S = overflow ? -1 : 0;
   if (!overflow && nsel > 0) {
@@ -486,6 +522,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
           mine.beg_l == readlane_f64(mine.beg_l, i) && mine.end_l == readlane_f64(mine.end_l, i))
         keep = false;
     }
+  CABL_MARK("RANK");
     const unsigned long long kept = __ballot(keep);
     const int pos = __popcll(kept & ((1ull << lane) - 1ull)), n = __popcll(kept);
     int rank = pos;
@@ -501,6 +538,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     if (keep) sel[rank] = mine;
     __syncthreads();
     if (a.variant == 0) {
+  CABL_MARK("REORDER");
       // lane r holds the keys of position r
       double bl = 0.0;
       int bt = 0, et = 0, src = lane;
@@ -531,6 +569,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
         if (moves) sel[lane] = moved;
       }
 #ifndef CABL_NOOVERLAP
+  CABL_MARK("OVERLAP");
       // overlap_segments_core, trapezoid: every step sees the spans the previous one left -- a serial walk over the
       // neighbours, on the keys in the lanes; a span the walk assigned gets its duration recomputed, as there.
       // (round 6) The walk changes nothing unless SOME neighbouring pair meets one of its two conditions on the spans as
@@ -566,6 +605,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
 #endif
   }
   __syncthreads();
+  CABL_MARK("RECORD");
   // ---- batch record: lane k writes segment k ----
   bool bad = S > a.seg_stride;
   if (S > 0 && !bad && lane < S) {

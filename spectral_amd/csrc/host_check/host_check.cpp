@@ -8,6 +8,7 @@
 //   host_check corridor <variant> <file> [out.txt]   -> "S <n>" + one line per segment; writes a trajectory file when asked
 //   host_check text <seed> <count>                   -> parse_double / format_3 against strtod / snprintf
 //   host_check prisms <seed> <scenes>                -> strips of seeded scenes, one line per strip and knot sample
+//   host_check knots <seed> <count>                  -> knot_inside_own_span against knot_inside under its preconditions
 #include "simt_shim.h"
 
 #include <cstdio>
@@ -140,7 +141,42 @@ static int run_prisms(unsigned seed, int scenes) {
   return 0;
 }
 
+// knot_inside_own_span against knot_inside (corridor_core.h) on seeded segments that meet the former's preconditions --
+// finite fields, gap0 in (0, 1e300), gap1 in (-1e300, 0), a finite reference, a knot of the span -- ordinary ones, tiny and
+// huge gaps, denormals, spans of one knot, references on and across the edges.
+#include "../corridor_core.h"
+static int run_knots(unsigned seed, int count) {
+  std::mt19937_64 rng(seed);
+  auto uni = [&](double lo, double hi) { return lo + (hi - lo) * std::ldexp((double)(rng() >> 11), -53); };
+  auto mag = [&]() { return std::ldexp(uni(1.0, 2.0), (int)(rng() % 2000) - 1040); };   // 2^-1040 .. 2^959: denormals to 1e288
+  int bad = 0, tried = 0, inside = 0;
+  for (int n = 0; n < count; n++) {
+    Seg c = seg_default();
+    const double delta = (rng() % 4) ? 0.1 : uni(0.01, 1.0);
+    c.beg_t = (int)(rng() % 500); c.end_t = c.beg_t + (int)(rng() % 12);
+    const int kind = (int)(rng() % 4);
+    c.down_bias = kind == 3 ? uni(-1, 1) * mag() : uni(-50, 100);
+    c.upp_bias = c.down_bias + (kind == 0 ? uni(0.1, 30) : kind == 1 ? mag() : uni(1e-12, 1e-3));
+    c.down_skew = kind == 2 ? uni(-1, 1) * mag() : uni(-8, 8);
+    c.upp_skew = c.down_skew + (kind == 2 ? 0.0 : uni(-3, 3));
+    c.beg_l = uni(-5, 5); c.end_l = c.beg_l + uni(0, 4);
+    const double gap0 = c.upp_bias - c.down_bias, gap1 = c.down_skew * delta + c.down_bias - c.upp_skew * delta - c.upp_bias;
+    if (!(gap0 > 0.0 && gap0 < 1e300 && gap1 < 0.0 && gap1 > -1e300)) continue;
+    for (int i = c.beg_t; i <= c.end_t; i++) {
+      const double edge = (rng() & 1) ? c.down_bias + c.down_skew * delta * (i - c.beg_t) : c.upp_bias + c.upp_skew * delta * (i - c.beg_t);
+      const double s = (rng() % 3 == 0) ? edge : (rng() % 3 == 1) ? edge + uni(-1, 1) * std::ldexp(fabs(edge) + 1e-300, -50) : uni(c.down_bias - 5, c.upp_bias + 5);
+      const double l = (rng() % 8) ? uni(c.beg_l, c.end_l) : uni(-6, 10);
+      const bool a = knot_inside(c, s, l, (double)i, delta), b = knot_inside_own_span(c, s, l, i, delta);
+      tried++; inside += a;
+      if (a != b && bad++ < 5) printf("knot %d of [%d, %d]: knot_inside %d, own_span %d (s %a, gap0 %a, gap1 %a)\n", i, c.beg_t, c.end_t, a, b, s, gap0, gap1);
+    }
+  }
+  printf("knots %d decisions (%d inside), %d differences\n", tried, inside, bad);
+  return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc >= 4 && !strcmp(argv[1], "knots")) return run_knots((unsigned)atoi(argv[2]), atoi(argv[3]));
   if (argc >= 4 && !strcmp(argv[1], "corridor")) return run_corridor(atoi(argv[2]), argv[3], argc > 4 ? argv[4] : nullptr);
   if (argc >= 4 && !strcmp(argv[1], "text")) return run_text((unsigned)atoi(argv[2]), atoi(argv[3]));
   if (argc >= 4 && !strcmp(argv[1], "prisms")) return run_prisms((unsigned)atoi(argv[2]), atoi(argv[3]));

@@ -118,6 +118,18 @@ def test_scanner_and_writer_against_libc(check):
     assert "200000 values, 0 differences" in check("text", 11, 200000)
 
 
+def test_knot_test_of_a_segments_own_span_equals_the_general_one(check):
+    """corridor_core.h::knot_inside_own_span -- what the device's selection evaluates for the knots of a segment's own span
+    (round 6: two of the reference's four edge functions, solve_3d.cc:534-581, have their signs decided by the span there) --
+    against knot_inside on 1.2 M seeded decisions that meet its preconditions: ordinary corridors, gaps of 1e-300 and
+    1e+288, denormal slopes, one-knot spans, references on the edges and one ulp off them."""
+    for seed in (3, 4, 5):
+        out = check("knots", seed, 100000)
+        import re
+        n, inside, bad = (int(v) for v in re.match(r"knots (\d+) decisions \((\d+) inside\), (\d+) differences", out).groups())
+        assert n > 300000 and 0.2 * n < inside < 0.6 * n and bad == 0, out
+
+
 def test_prism_geometry_as_64_threads_equals_the_restatement(check):
     """prism_core.h (tables by ballot and barriers, strips per lane) run as 64 host threads per wavefront with a table
     block of exactly prism_tab_bytes(P): clean, and the strips are the CPU restatement's (oracle/prism_oracle.py) on
