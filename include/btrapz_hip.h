@@ -198,7 +198,7 @@ typedef struct btrapz_options {
    * control points would have to move), the reference's objective deciding among its minimisers.
    *   elastic        0: off (stalled candidates keep status -2, cost +inf) -- default of the batched entry points;
    *                  1: rescue pass over the stalled axis problems after the solve; 2: every candidate is solved
-   *                  with elastic rows straight away.  find_traj uses 1 (BTRAPZ_ELASTIC=0 turns it off).
+   *                  with elastic rows straight away.  find_traj uses 1 (BTRAPZ_ACCEPT=reference -- older spelling BTRAPZ_ELASTIC=0 -- turns it off: the strict mode).
    *   elastic_tol    a rescued problem whose largest row violation / |g| is at most this is reported as
    *                  BTRAPZ_SOLVED_INACCURATE (2), beyond it as BTRAPZ_PRIMAL_INFEASIBLE (-3); 0 -> default (0.0125:
    *                  at most 0.0125 t metres outside a position row, 0.088 on a velocity row, 0.61 on an acceleration
