@@ -28,6 +28,17 @@ namespace btrapz {
 #define UNIFORM_BLOCK_C asm volatile("")
 #ifdef CABL_MARKS
 #define CABL_MARK(x) asm volatile("; ==PHASE " x)
+#elif defined(CABL_TIMING)
+// -DCABL_TIMING (a measuring build, tools/corridor_bench.py --timing): the wall-clock cycles a wavefront spends between two
+// phase marks, summed over all wavefronts in a device array the host reads through btrapz_debug_corridor_timing()
+__device__ unsigned long long g_corridor_timing[16];
+extern "C" __attribute__((visibility("default"))) int btrapz_debug_corridor_timing(unsigned long long *out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_corridor_timing), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_corridor_timing), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#define CABL_PHASES "SLOPES REFS BREAKS REFSTORE SELECT DEDUP RANK REORDER OVERLAP RECORD END"
+#define CABL_MARK(name_) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_corridor_timing[cabl_phase_], t_ - cabl_t_); cabl_t_ = __builtin_readcyclecounter(); ++cabl_phase_; } while (0)
 #else
 #define CABL_MARK(x)
 #endif
@@ -270,6 +281,9 @@ __device__ __forceinline__ double from_lane_below(double v) {   // lane l gets l
 template <int RB, bool PRISMS, bool SERIAL>
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw) {
   const int lane = threadIdx.x;
+#ifdef CABL_TIMING
+  unsigned long long cabl_t_ = __builtin_readcyclecounter(); int cabl_phase_ = 0;   // slot 0: set-up up to the first mark
+#endif
   const int N = a.N, O = a.num_obs;
   const int cap_o = a.cap_o, cap_all = cap_o * O, cap_sel = a.cap_sel;
   Seg *all = reinterpret_cast<Seg *>(lds_raw);           // segments of every obstacle, obstacle o at [o * cap_o, ...)
@@ -639,6 +653,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     const int i = lane >> 1, ii = i > N - 1 ? N - 1 : i;
     a.dl10[(size_t)b * 10 + lane] = a.dl_bounds[((size_t)b * N + ii) * 2 + (lane & 1)];
   }
+  CABL_MARK("END");
 }
 
 // ---- the corridor stage without the wave-wide kernel's limits (round 6) ---------------------------------------------------

@@ -62,6 +62,21 @@ def main(argv=None):
     out = {"workload": ("scenario_1 at knot level" if a.scenario1 else "jittered " + a.input + ".txt") + ", %d candidates, N = %d, %d obstacles, variant %d" % (B, kb.N, kb.num_obs, a.variant),
            "corridor_ms": ms, "min_ms": float(np.min(t)), "hash": h, "mean_segments": float(np.mean(np.maximum(c, 0))), "refused": int((c < 0).sum()),
            "bytes_per_candidate": in_bytes + out_bytes, "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}}
+    # a -DCABL_TIMING build: where a wavefront's lifetime goes, phase by phase (wall-clock cycles between the phase marks,
+    # summed over the wavefronts of one more launch; slot 0 is the set-up in front of the first mark)
+    import ctypes as C
+    from spectral_amd import native
+    try:
+        fn = native.lib().btrapz_debug_corridor_timing
+    except AttributeError:
+        fn = None
+    if fn is not None:
+        buf = (C.c_ulonglong * 16)()
+        fn(None, 1); run(); torch.cuda.synchronize(); fn(buf, 0)
+        names = ["setup", "SLOPES", "REFS", "BREAKS", "REFSTORE", "SELECT", "DEDUP", "RANK", "REORDER", "OVERLAP", "RECORD"]
+        tot = float(sum(buf[:len(names)])) or 1.0
+        out["phase_share_of_wavefront_lifetime"] = {n: round(buf[i] / tot, 4) for i, n in enumerate(names)}
+        out["cycles_per_wavefront"] = tot / B
     print(json.dumps(out))
     return out
 
