@@ -19,6 +19,8 @@
 // References: src/solve_3d.cc:323-486,488-714,729-772,835-845,1159-1166 ; src/cuboid_3d.cc:301-573.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "btrapz_device.h"
 #include "corridor_core.h"
 #include "prism_core.h"
@@ -27,20 +29,27 @@ namespace btrapz {
 
 #define UNIFORM_BLOCK_C asm volatile("")
 #ifdef CABL_MARKS
-#define CABL_MARK(x) asm volatile("; ==PHASE " x)
+#define CABL_MARK(i_, x) asm volatile("; ==PHASE " x)
 #elif defined(CABL_TIMING)
 // -DCABL_TIMING (a measuring build, tools/corridor_bench.py --timing): the wall-clock cycles a wavefront spends between two
 // phase marks, summed over all wavefronts in a device array the host reads through btrapz_debug_corridor_timing()
-__device__ unsigned long long g_corridor_timing[16];
+// (1 024 sets of slots, a wavefront adds to set blockIdx & 1023: 65 536 atomics on ONE address cost more than the kernel)
+__device__ unsigned long long g_corridor_timing[1024][16];
 extern "C" __attribute__((visibility("default"))) int btrapz_debug_corridor_timing(unsigned long long *out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_corridor_timing), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_corridor_timing), z, sizeof z) != hipSuccess) return -1; }
+  static unsigned long long h[1024][16];
+  if (out) {
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_corridor_timing), sizeof h) != hipSuccess) return -1;
+    for (int q = 0; q < 16; q++) { out[q] = 0; for (int i = 0; i < 1024; i++) out[q] += h[i][q]; }
+  }
+  if (reset) { memset(h, 0, sizeof h); if (hipMemcpyToSymbol(HIP_SYMBOL(g_corridor_timing), h, sizeof h) != hipSuccess) return -1; }
   return 0;
 }
 #define CABL_PHASES "SLOPES REFS BREAKS REFSTORE SELECT DEDUP RANK REORDER OVERLAP RECORD END"
-#define CABL_MARK(name_) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_corridor_timing[cabl_phase_], t_ - cabl_t_); cabl_t_ = __builtin_readcyclecounter(); ++cabl_phase_; } while (0)
+// (the deltas stay in registers until the last mark: an atomic per mark would put its own latency into the next phase)
+#define CABL_MARK(i_, name_) do { const unsigned long long t_ = __builtin_readcyclecounter(); cabl_acc_[i_] = t_ - cabl_t_; cabl_t_ = t_; \
+    if (i_ == 10 && threadIdx.x == 0) { _Pragma("unroll") for (int q_ = 0; q_ < 16; q_++) atomicAdd(&g_corridor_timing[blockIdx.x & 1023][q_], cabl_acc_[q_]); } } while (0)
 #else
-#define CABL_MARK(x)
+#define CABL_MARK(i_, x)
 #endif
 enum { MAX_ALL = 160, MAX_SEL = 64 };   // capacities of the retry pass (see btrapz_corridor_batch_device)
 
@@ -73,6 +82,8 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
 #ifndef CABL_WAVES_SHORT
 #define CABL_WAVES_SHORT 4
 #endif
+// (the upper bound 8 holds the first-pass instantiations to 64 registers although LDS admits five wavefronts per SIMD; with
+//  5 or 6 -- 102 / 85 registers to schedule in -- nothing moves: 0.231 -> 0.233 / 0.230 ms at N = 71, round 6)
 template <int RB, bool PRISMS, bool SERIAL>
 __device__ __forceinline__ void corridor_batch_body(const CorridorArgs &a, int staged) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -282,7 +293,7 @@ template <int RB, bool PRISMS, bool SERIAL>
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw) {
   const int lane = threadIdx.x;
 #ifdef CABL_TIMING
-  unsigned long long cabl_t_ = __builtin_readcyclecounter(); int cabl_phase_ = 0;   // slot 0: set-up up to the first mark
+  unsigned long long cabl_t_ = __builtin_readcyclecounter(), cabl_acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // slot i: from mark i - 1 (or the start) to mark i
 #endif
   const int N = a.N, O = a.num_obs;
   const int cap_o = a.cap_o, cap_all = cap_o * O, cap_sel = a.cap_sel;
@@ -354,7 +365,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
         sk2[i] = make_double2((cur_lo[u] - prv_lo[u]) / a.delta, (cur_hi[u] - prv_hi[u]) / a.delta);
     }
   };
-  CABL_MARK("SLOPES");
+  CABL_MARK(0, "SLOPES");
   if (staged) {
     load_pairs(0);
     store_slopes(0);
@@ -362,7 +373,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   }
   // reference and ds bounds of the first 256 knots: issued behind the break search, in the same memory round trip
   // as the bounds at the segment starts
-  CABL_MARK("REFS");
+  CABL_MARK(1, "REFS");
   const double *gsr = a.s_ref + (size_t)b * N, *glr = a.l_ref + (size_t)b * N;
   const double2 *gds = reinterpret_cast<const double2 *>(a.ds_bounds + (size_t)b * N * 2);
   double ref_s[RB], ref_l[RB], ref_dlo[RB], ref_dhi[RB];   // (scalars: an array of double2 behind a lambda stays in scratch)
@@ -394,9 +405,12 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   load_refs(0);
 #else
   // hits / slot_of are free until the selection: scratch of the wave-wide extraction
-  CABL_MARK("BREAKS");
+  CABL_MARK(2, "BREAKS");
   int my_nb = 0;
   const bool wide = staged && find_breaks_wave(a, lane, slopes, cap_o, hits, my_nb);
+  CABL_MARK(11, "BREAKS_FOUND");
+  // (round 6: issued in FRONT of the break search instead -- so that its round trip runs behind the search's LDS chains --
+  //  N = 71 x 3 obstacles 0.231 -> 0.228 ms, N = 201 x 2 0.560 -> 0.574: five resident wavefronts hide it either way)
   load_refs(0);
   if (wide) {
     auto after_slopes = [&]() {
@@ -425,7 +439,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     }
   }
 #endif
-  CABL_MARK("REFSTORE");
+  CABL_MARK(3, "REFSTORE");
   __syncthreads();                                         // the slope table has been read for the last time
   if (!refs_stored) store_refs(0);
   for (int base = 64 * RB; base < N; base += 64 * RB) { load_refs(base); store_refs(base); }
@@ -433,7 +447,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   __syncthreads();
   // ---- selection along the reference (solve_3d.cc:534-596): knots inside every segment, the lanes spread over
   // (segment, knot) pairs; the reference's running hit counter then reduces to a carry over the segments in order
-  CABL_MARK("SELECT");
+  CABL_MARK(4, "SELECT");
   int total = 0;
   bool overflow = false;
   for (int o = 0; o < O; o++) {
@@ -507,7 +521,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   }
   __syncthreads();
   if (overflow && a.pass == 0 && a.retry_list && lane == 0) a.retry_list[atomicAdd(a.retry_count, 1)] = b;  // second chance
-  CABL_MARK("DEDUP");
+  CABL_MARK(5, "DEDUP");
   // ---- de-dup (keep first), stable sort by beg_t: lane j holds selected segment j ----
   int S = overflow ? -1 : 0;
   if (!overflow && nsel > 0) {
@@ -536,7 +550,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
           mine.beg_l == readlane_f64(mine.beg_l, i) && mine.end_l == readlane_f64(mine.end_l, i))
         keep = false;
     }
-  CABL_MARK("RANK");
+  CABL_MARK(6, "RANK");
     const unsigned long long kept = __ballot(keep);
     const int pos = __popcll(kept & ((1ull << lane) - 1ull)), n = __popcll(kept);
     int rank = pos;
@@ -552,7 +566,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     if (keep) sel[rank] = mine;
     __syncthreads();
     if (a.variant == 0) {
-  CABL_MARK("REORDER");
+  CABL_MARK(7, "REORDER");
       // lane r holds the keys of position r
       double bl = 0.0;
       int bt = 0, et = 0, src = lane;
@@ -583,7 +597,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
         if (moves) sel[lane] = moved;
       }
 #ifndef CABL_NOOVERLAP
-  CABL_MARK("OVERLAP");
+  CABL_MARK(8, "OVERLAP");
       // overlap_segments_core, trapezoid: every step sees the spans the previous one left -- a serial walk over the
       // neighbours, on the keys in the lanes; a span the walk assigned gets its duration recomputed, as there.
       // (round 6) The walk changes nothing unless SOME neighbouring pair meets one of its two conditions on the spans as
@@ -619,7 +633,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
 #endif
   }
   __syncthreads();
-  CABL_MARK("RECORD");
+  CABL_MARK(9, "RECORD");
   // ---- batch record: lane k writes segment k ----
   bool bad = S > a.seg_stride;
   if (S > 0 && !bad && lane < S) {
@@ -653,7 +667,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     const int i = lane >> 1, ii = i > N - 1 ? N - 1 : i;
     a.dl10[(size_t)b * 10 + lane] = a.dl_bounds[((size_t)b * N + ii) * 2 + (lane & 1)];
   }
-  CABL_MARK("END");
+  CABL_MARK(10, "END");
 }
 
 // ---- the corridor stage without the wave-wide kernel's limits (round 6) ---------------------------------------------------
