@@ -13,6 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def torch_device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
 def run(*args):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "6000",
@@ -52,6 +57,12 @@ def test_one_process_host_returns_the_single_rank_winner_and_serves_as_fallback(
     fb = run("--gpus", "2", "--scaling", "strong", "--share-device", "--backend", "no-such-backend")
     assert fb["winner"] == one["winner"] and fb["config"]["host"].startswith("one process")
     assert "no-such-backend" in fb["config"]["fallback_from"]
+    # a REAL RCCL refusal: two nccl ranks on the box's one GPU ("Duplicate GPU detected", ncclInvalidUsage at first contact) --
+    # both ranks raise, rank 0 hands over, the line comes from the one-process host and quotes RCCL's error
+    if torch_device_count() == 1:
+        dup = run("--gpus", "2", "--scaling", "strong", "--share-device", "--backend", "nccl")
+        assert dup["winner"] == one["winner"] and dup["config"]["host"].startswith("one process")
+        assert "nccl" in dup["config"]["fallback_from"] and "NCCL" in dup["config"]["fallback_from"]
     # ... and as the driver launches it: torch.distributed.run starts the ranks, bench.py is a rank
     import socket
     with socket.socket() as sk:
