@@ -58,7 +58,7 @@ def oracle_qp_from_batch(batch, sh, b):
     return O.AssembledQp(sh.variant, cubes, p, src)
 
 
-def fuzz_knot_batch(seed, B=16):
+def fuzz_knot_batch(seed, B=16, N=None, num_obs=None):
     """A random corridor-stage input: horizon and obstacle count from the edges of the device stage's range, s bounds
     with slope changes in runs of random length (some below, some above the 0.2 threshold), now and then an upper bound
     with breaks of its own, moving l bounds, collapsed bounds, nan / inf entries, a nan reference knot.  The shapes that
@@ -68,8 +68,10 @@ def fuzz_knot_batch(seed, B=16):
     from spectral_amd import synth
     from spectral_amd.knots import KnotBatch
     rng = np.random.default_rng(seed)
-    N = int(rng.choice([3, 4, 5, 11, 21, 64, 65, 66, 71, 101, 128, 129, 130, 201, 257, 300, 512]))
-    num_obs = int(rng.choice([1, 2, 3, 5, 8, 13, 64])) if N <= 130 else int(rng.choice([1, 2, 3, 5]))
+    N_ = int(rng.choice([3, 4, 5, 11, 21, 64, 65, 66, 71, 101, 128, 129, 130, 201, 257, 300, 512]))
+    O_ = int(rng.choice([1, 2, 3, 5, 8, 13, 64])) if N_ <= 130 else int(rng.choice([1, 2, 3, 5]))
+    N = N_ if N is None else int(N)                        # (overrides: shapes beyond the wave-wide kernels, round 6)
+    num_obs = O_ if num_obs is None else int(num_obs)
     tt = np.arange(N) * 0.1
     sb = np.zeros((B, num_obs, N, 2)); lb = np.zeros((B, num_obs, N, 2))
     for b in range(B):

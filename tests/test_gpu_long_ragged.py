@@ -136,3 +136,47 @@ def test_more_obstacles_than_lanes():
         assert n == counts[b], (b, n, counts[b])
         for f, name in FIELDS:
             assert np.array_equal(seg[f, b, :max(n, 0)], np.array([getattr(c, name) for c in cubes[:max(n, 0)]])), (b, name)
+
+
+@pytest.mark.parametrize("N,num_obs", [(513, 3), (700, 2), (1001, 1), (1500, 2), (71, 65), (130, 90)])
+def test_serial_corridor_kernel_equals_the_oracle_on_random_inputs(N, num_obs):
+    """corridor_serial_kernel on the fuzz family of the wave-wide kernels' test (slope changes in runs, breaks above and below
+    the 0.2 threshold, moving l bounds, collapsed bounds, nan / inf entries, a nan reference knot), at shapes only it serves:
+    count and every field of the record as the oracle's corridor stage computes them, both variants."""
+    import torch
+    from helpers import fuzz_knot_batch, oracle_corridor
+    from spectral_amd.solver import BatchSolver
+    solver = BatchSolver(0)
+    stride = 256
+    checked = usable = 0
+    for rd in range(3):
+        kb = fuzz_knot_batch(9000 + 10 * N + rd, B=6, N=N, num_obs=num_obs)
+        for variant in (0, 1):
+            rec = solver.corridor_batch(kb, variant, seg_stride=stride)
+            torch.cuda.synchronize()
+            seg = rec["seg"].cpu().numpy(); cnt = rec["seg_count"].cpu().numpy()
+            for b in range(kb.B):
+                n, cubes = oracle_corridor(kb, b, variant)
+                checked += 1
+                want = n if n > 0 else 0
+                if n > stride or any(not (c.t > 0) for c in cubes):
+                    want = -1
+                assert cnt[b] == want, (N, num_obs, rd, variant, b, cnt[b], want)
+                if want <= 0:
+                    continue
+                usable += 1
+                for k, c in enumerate(cubes):
+                    for f, attr in FIELDS:
+                        got, exp = seg[f, b, k], getattr(c, attr)
+                        assert got == exp or (np.isnan(got) and np.isnan(exp)), (N, num_obs, rd, variant, b, k, attr, got, exp)
+                    lo, hi = 0.0, 1000.0                        # solve_3d.cc:835-841
+                    for i in range(c.beg_t, c.end_t + 1):
+                        ii = min(max(i, 0), N - 1)
+                        lo = np.fmax(kb.ds_bounds[b, ii, 0], lo); hi = np.fmin(kb.ds_bounds[b, ii, 1], hi)
+                    i0, i1 = min(10 * k, N - 1), min(10 * k + 1, N - 1)
+                    derived = {L.F_DS_LO: lo, L.F_DS_HI: hi, L.F_X_SKEW: (kb.s_ref[b, i1] - kb.s_ref[b, i0]) / kb.delta,
+                               L.F_X_BIAS: kb.s_ref[b, i0], L.F_Y_SKEW: (kb.l_ref[b, i1] - kb.l_ref[b, i0]) / kb.delta, L.F_Y_BIAS: kb.l_ref[b, i0]}
+                    for f, exp in derived.items():
+                        got = seg[f, b, k]
+                        assert got == exp or (np.isnan(got) and np.isnan(exp)), (N, num_obs, rd, variant, b, k, f, got, exp)
+    assert checked == 36 and usable >= 6
