@@ -769,19 +769,20 @@ __global__ void bucket_hist_kernel(int B, int seg_stride, const int *seg_count, 
 }
 // Buckets are laid out by DESCENDING key (slot j holds key 65 - j): wavefronts of long corridors / hard classes are
 // launched first, so the longest-running wavefronts do not start at the tail of the launch.
-__global__ void bucket_prefix_kernel(int *meta, int fixed_S) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// (round 6: lane j - 1 owns slot j and the two prefixes are wave scans -- until then ONE lane walked the 64 slots, three
+//  dependent global accesses per step: 11.6 us per solve of the two-launch form for 64 additions, a third of its small kernels)
+__global__ __launch_bounds__(64) void bucket_prefix_kernel(int *meta, int fixed_S) {
+  if (blockIdx.x != 0) return;
   meta += blockIdx.y * 198;
-  int cand = 0, wave = 0;
-  meta[0] = 0; meta[66] = 0;
-  for (int j = 1; j <= 64; j++) {
-    const int key = 65 - j;
-    const int cnt = meta[132 + j], gpw = 64 / (fixed_S > 0 ? fixed_S : fixed_S < 0 ? -fixed_S : key);
-    meta[j] = cand; meta[66 + j] = wave;
-    cand += cnt; wave += (cnt + gpw - 1) / gpw;
-    meta[132 + j] = 0;  // becomes the scatter cursor
-  }
-  meta[65] = cand; meta[66 + 65] = wave;
+  const int lane = threadIdx.x, j = lane + 1;
+  const int key = 65 - j;
+  const int cnt = meta[132 + j], gpw = 64 / (fixed_S > 0 ? fixed_S : fixed_S < 0 ? -fixed_S : key);
+  const int waves = (cnt + gpw - 1) / gpw;
+  const int cand_incl = wave_inclusive_scan(cnt, lane), wave_incl = wave_inclusive_scan(waves, lane);
+  meta[j] = cand_incl - cnt; meta[66 + j] = wave_incl - waves;
+  meta[132 + j] = 0;  // becomes the scatter cursor
+  if (lane == 0) { meta[0] = 0; meta[66] = 0; }
+  if (lane == 63) { meta[65] = cand_incl; meta[66 + 65] = wave_incl; }
 }
 // Order inside a bucket: index order within a 256-candidate workgroup (stable ranks from ballots), workgroups in
 // the order their atomics land.  It only decides which candidates share a wavefront -- every group of a wavefront
