@@ -109,6 +109,10 @@ if [ "$QUICK" != "quick" ]; then
     # shellcheck disable=SC2086
     step "corridor_pmc$i" "$OUT/corridor_pmc$i.json" rocprofv3 --pmc $group --output-format csv -d "$OUT/corridor_pmc$i" -- python3 "$ROOT/tools/pipeline_bench.py" --reps 2
   done
+  # round 6: the corridor stage alone (time, roofline fraction, a hash of every output byte) on its three workloads
+  step corridor_bench "$OUT/corridor_bench.json" python3 "$ROOT/tools/corridor_bench.py"
+  step corridor_bench_s1 "$OUT/corridor_bench_scenario1.json" python3 "$ROOT/tools/corridor_bench.py" --scenario1
+  step corridor_bench_c1 "$OUT/corridor_bench_c1_cuboid.json" python3 "$ROOT/tools/corridor_bench.py" --input c1 --variant 1
   step mpc_2rank "$OUT/mpc_warm_2rank_gloo.json" python3 "$ROOT/tools/mpc_bench.py" --gpus 2 --backend gloo --share-device
   # round 4: the two-wavefronts-per-SIMD form against the packed one (one and two launches, small batches), its
   # hand-over sweep, the sibling warm start, and the counters of both forms' kernels on the scenario_1 batch
