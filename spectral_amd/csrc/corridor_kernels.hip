@@ -540,7 +540,22 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
       mine.count = 3;                                      // the reference pushes a counted copy (solve_3d.cc:590)
     }
     // a later twin of segment i goes (same_segment; equality is transitive, so "a twin of any earlier one" is the
-    // reference's "a twin of an earlier kept one"): the spans are compared first, the rest only when some lane matches
+    // reference's "a twin of an earlier kept one"): the spans are compared first, the rest only when some lane matches.
+    // (round 6) Twins share their first knot: every lane sets the bit of its beg_t in a bitmap (hits[] is free by now), and
+    // unless SOME lane finds its bit already set there is no twin to look for -- the usual corridor, one segment per second.
+    bool maybe_twins = true;
+#ifndef CABL_NO_TWIN_BITMAP
+    if (cap_all >= 16) {   // (16 words: first knots below 512 -- what the wave-wide kernels take)
+      unsigned *bits = reinterpret_cast<unsigned *>(hits);
+      if (lane < 16) bits[lane] = 0u;
+      __syncthreads();
+      unsigned seen = 0u;
+      const bool valid_bt = keep && mine.beg_t >= 0 && mine.beg_t < 512;
+      if (valid_bt) seen = atomicOr(&bits[mine.beg_t >> 5], 1u << (mine.beg_t & 31)) & (1u << (mine.beg_t & 31));
+      maybe_twins = __ballot((keep && !valid_bt) || seen != 0u) != 0;
+    }
+#endif
+    if (maybe_twins)
     for (int i = 0; i + 1 < nsel; i++) {
       const bool span = lane > i && lane < nsel && mine.beg_t == __builtin_amdgcn_readlane(mine.beg_t, i) &&
                         mine.end_t == __builtin_amdgcn_readlane(mine.end_t, i);
@@ -554,7 +569,11 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     const unsigned long long kept = __ballot(keep);
     const int pos = __popcll(kept & ((1ull << lane) - 1ull)), n = __popcll(kept);
     int rank = pos;
-    if (a.variant == 0) {  // stable rank by beg_t among the kept ones
+    // (round 6) nothing dropped and the first knots already in non-decreasing order along the lanes -- a corridor selected
+    // obstacle by obstacle in the order the reference passes them --: the stable rank IS the lane
+    const int bt_below = __builtin_amdgcn_update_dpp(0, mine.beg_t, 0x138, 0xf, 0xf, false);   // wave_shr:1: lane l - 1's
+    const bool in_order = n == nsel && __ballot(lane > 0 && lane < nsel && bt_below > mine.beg_t) == 0;
+    if (a.variant == 0 && !in_order) {  // stable rank by beg_t among the kept ones
       rank = 0;
       for (int i = 0; i < nsel; i++) {
         if (!((kept >> i) & 1ull)) continue;
@@ -575,10 +594,18 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
       // the keys (and the source slots) of lanes j and k
       // (positions without a continuation further on -- the usual case -- cost one ballot: the j loop of the serial
       //  statement does nothing once no lane beyond j matches)
-      for (int i = 0; i + 2 < n; i++) {
+      // (round 6: the outer loop visits only the positions i whose neighbour i + 1 has ANOTHER beg_l -- the statement's
+      //  `break` at j = i + 1 skips all the others --, found by one ballot over the pairs as they stand: a corridor that
+      //  changes lanes once has one such position, not n - 2)
+      for (int i_from = 0;;) {
+        const double bl_nx = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(bl), 0x130, 0xf, 0xf, false),
+                                              __builtin_amdgcn_update_dpp(0, __double2loint(bl), 0x130, 0xf, 0xf, false));   // wave_shl:1: lane l + 1's
+        const unsigned long long need = __ballot(lane >= i_from && lane + 2 < n && !(bl == bl_nx));
+        if (need == 0) break;
+        const int i = __ffsll((long long)need) - 1;
+        i_from = i + 1;
         const double bl_i = readlane_f64(bl, i);
         const int et_i = __builtin_amdgcn_readlane(et, i);
-        if (bl_i == readlane_f64(bl, i + 1)) continue;       // its `break` at j = i + 1
         for (int j = i + 1; j + 1 < n; j++) {
           const unsigned long long m = __ballot(lane > j && lane < n && bl == bl_i && bt == et_i);
           if (m == 0) break;
@@ -648,6 +675,8 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     sg[BTRAPZ_F_L_UPP_BIAS * BS + e] = c.l_upp_bias; sg[BTRAPZ_F_L_UPP_SKEW * BS + e] = c.l_upp_skew;
     sg[BTRAPZ_F_BEG_L * BS + e] = c.beg_l; sg[BTRAPZ_F_END_L * BS + e] = c.end_l;
     double lo = 0.0, hi = 1000.0;  // solve_3d.cc:835-841
+    // (round 6: this walk as a fixed-length predicated one with its reads issued together -- the selection's gain -- is no
+    //  gain here: 0.2164 -> 0.2189 ms; eight lanes, eleven steps)
     for (int i = c.beg_t; i <= c.end_t; i++) {
       const int ii = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
       lo = fmax(dsb[2 * ii], lo);
