@@ -45,9 +45,18 @@ extern "C" __attribute__((visibility("default"))) int btrapz_debug_corridor_timi
   return 0;
 }
 #define CABL_PHASES "SLOPES REFS BREAKS REFSTORE SELECT DEDUP RANK REORDER OVERLAP RECORD END"
-// (the deltas stay in registers until the last mark: an atomic per mark would put its own latency into the next phase)
-#define CABL_MARK(i_, name_) do { const unsigned long long t_ = __builtin_readcyclecounter(); cabl_acc_[i_] = t_ - cabl_t_; cabl_t_ = t_; \
-    if (i_ == 10 && threadIdx.x == 0) { _Pragma("unroll") for (int q_ = 0; q_ < 16; q_++) atomicAdd(&g_corridor_timing[blockIdx.x & 1023][q_], cabl_acc_[q_]); } } while (0)
+// (the deltas stay in the wavefront's LDS until the last mark: an atomic per mark would put its own latency into the next
+//  phase; LDS, not registers, so that a mark can sit inside any of the kernel's functions)
+__device__ __forceinline__ void cabl_mark(int i) {
+  __shared__ unsigned long long sh[18];
+  const unsigned long long t = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) {
+    if (i >= 0) sh[i] = t - sh[17];
+    sh[17] = __builtin_readcyclecounter();
+    if (i == 10) for (int q = 0; q < 16; q++) atomicAdd(&g_corridor_timing[blockIdx.x & 1023][q], q < 11 || (q >= 11 && q <= 14) ? sh[q] : 0ull);
+  }
+}
+#define CABL_MARK(i_, name_) cabl_mark(i_)
 #else
 #define CABL_MARK(i_, x)
 #endif
@@ -91,6 +100,8 @@ __device__ __forceinline__ void corridor_batch_body(const CorridorArgs &a, int s
     corridor_candidate<RB, PRISMS, SERIAL>(a, staged, (int)blockIdx.x, lds_raw);
   } else {  // retry pass: the candidates the first pass could not hold
     const int n = *a.retry_count;
+    // (round 6: two counters used alternately, this launch zeroing the next call's, so that a call needs no memset of its
+    //  own: no gain -- 0.2145 -> 0.217 ms, the memset runs behind the previous call's tail anyway)
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
       // (the candidate's number is the same in every lane: say so, or every address derived from it costs vector registers)
       corridor_candidate<RB, PRISMS, SERIAL>(a, staged, __builtin_amdgcn_readfirstlane(a.retry_list[i]), lds_raw);
@@ -212,7 +223,9 @@ __device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int l
   bool bad = false;
   double2 slope = make_double2(0.0, 0.0);
   if (mo >= 0) slope = sk2[(size_t)mo * N + brk[mo * cap_o + mk] + 1];
+  CABL_MARK(12, "SEG_MAPPED");
   after_slopes();
+  CABL_MARK(13, "SEG_REFS_STORED");
   if (mo >= 0) {
     const int beg = brk[mo * cap_o + mk];
     const double2 sb = src.s2(mo, beg), lb = src.l2(mo, beg);
@@ -246,6 +259,7 @@ __device__ __forceinline__ void build_segments_wave(const CorridorArgs &a, int l
   // slots (piece number, distance to that slot) in brk[] -- free now: every break has been read --; then lane l builds the piece
   // of slot base + l from the base segment it finds there: the reference's recurrences step by step (the bias after j pieces is
   // j additions of the slope, the rest's duration cnt - 1 subtractions of 1), so the pieces are the serial statement's bit for bit.
+  CABL_MARK(14, "SEG_BASES");
   const int cap_all = cap_o * O;
   const bool okb = mo >= 0 && ocount[mo] > 0;
   const int slot0 = okb ? mo * cap_o + pos : 0;
@@ -293,7 +307,7 @@ template <int RB, bool PRISMS, bool SERIAL>
 __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int staged, int b, unsigned char *lds_raw) {
   const int lane = threadIdx.x;
 #ifdef CABL_TIMING
-  unsigned long long cabl_t_ = __builtin_readcyclecounter(), cabl_acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // slot i: from mark i - 1 (or the start) to mark i
+  cabl_mark(-1);   // slot i: from the mark before it (or this start) to mark i
 #endif
   const int N = a.N, O = a.num_obs;
   const int cap_o = a.cap_o, cap_all = cap_o * O, cap_sel = a.cap_sel;

@@ -74,7 +74,8 @@ def main(argv=None):
         buf = (C.c_ulonglong * 16)()
         fn(None, 1); run(); torch.cuda.synchronize(); fn(buf, 0)
         # slot i = the stretch that ENDS at mark i: set-up, then the phase each mark closes
-        names = ["setup", "slopes", "refs issued", "segments built + split", "refs stored", "selection", "de-dup", "rank + place", "reorder", "overlap", "record", "break search"]
+        names = ["setup", "slopes", "refs issued", "segments: pieces (CorridorSplit)", "refs stored", "selection", "de-dup", "rank + place", "reorder", "overlap", "record", "break search",
+                 "segments: lanes mapped to base segments", "segments: references stored", "segments: base segments built (bounds at their starts)"]
         tot = float(sum(buf[:len(names)])) or 1.0
         out["phase_share_of_wavefront_lifetime"] = {n: round(buf[i] / tot, 4) for i, n in enumerate(names)}
         out["cycles_per_wavefront"] = tot / B
