@@ -399,6 +399,13 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
       ref_s[u] = gsr[ic]; ref_l[u] = glr[ic]; ref_dlo[u] = d.x; ref_dhi[u] = d.y;
     }
   };
+  // (round 6) the ten dl bounds the record carries: read HERE, with the streaming loads, not at the kernel's end -- a load
+  // in front of the last store is a memory round trip added to every wavefront's lifetime
+  double dl10_v = 0.0;
+  if (lane < 10) {
+    const int i = lane >> 1, ii = i > N - 1 ? N - 1 : i;
+    dl10_v = a.dl_bounds[((size_t)b * N + ii) * 2 + (lane & 1)];
+  }
   bool refs_finite = true;
   auto store_refs = [&](int base) {
     double2 *d2 = reinterpret_cast<double2 *>(dsb);
@@ -706,10 +713,7 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
     a.seg_count[b] = S;
     a.ref_end[(size_t)b * 2] = sref[N - 1]; a.ref_end[(size_t)b * 2 + 1] = lref[N - 1];
   }
-  if (lane < 10) {
-    const int i = lane >> 1, ii = i > N - 1 ? N - 1 : i;
-    a.dl10[(size_t)b * 10 + lane] = a.dl_bounds[((size_t)b * N + ii) * 2 + (lane & 1)];
-  }
+  if (lane < 10) a.dl10[(size_t)b * 10 + lane] = dl10_v;
   CABL_MARK(10, "END");
 }
 
