@@ -275,7 +275,6 @@ def one_process_main(a):
     call = m.prepared_step(shared, lean=a.lean)
     ev = HipEvents()
     stream0 = m.view(0).stream
-    native.lib()  # (bound)
     for _ in range(a.warmup):
         call()
     m.wait()
