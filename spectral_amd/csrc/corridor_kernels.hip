@@ -684,7 +684,11 @@ __device__ __forceinline__ void corridor_candidate(const CorridorArgs &a, int st
   CABL_MARK(9, "RECORD");
   // ---- batch record: lane k writes segment k ----
   bool bad = S > a.seg_stride;
+#ifdef CABL_NORECORD
+  if (false) {
+#else
   if (S > 0 && !bad && lane < S) {
+#endif
     const Seg c = sel[lane];
     if (!(c.t > 0.0)) bad = true;
     const size_t BS = (size_t)a.B * a.seg_stride, e = (size_t)b * a.seg_stride + lane;
